@@ -1,0 +1,162 @@
+/*
+ * ssnode_mi355x.h -- C ABI of libssnode.so (MI355X / gfx950 build).
+ *
+ * The library is a drop-in for the reference's tc_gan/ext/libssnode.so (built
+ * from tc_gan/ext/ssnode.c, bound by tc_gan/clib.py:16-33) plus an additive
+ * batched ABI for the GPU-resident hot path.  Plain C: pointers and sizes
+ * only, no C++/torch types.  Every entry point runs on the GPU; there is no
+ * CPU fallback -- without a usable HIP device the solver symbols return
+ * SSN_ERR_BASE + hipError_t (> 900, the range the reference's Python reserves
+ * for "library error", tc_gan/ssnode.py:267-268).
+ *
+ * Conventions
+ *   M = 2N neurons (E block first, then I).  W is row-major, W[i*M + j] is
+ *   the weight from neuron j to neuron i (ssnode.c:64-67 `W + dim * i`).
+ *   "device" pointers are hipMalloc'ed (or torch CUDA tensor) addresses on
+ *   the CURRENT HIP device of the calling thread; `stream` is a hipStream_t
+ *   passed as void* (NULL = the default stream).  Batched calls are
+ *   asynchronous on `stream` unless stated otherwise.
+ */
+#ifndef SSNODE_MI355X_H
+#define SSNODE_MI355X_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------
+ * 1. Drop-in symbols: exactly the exports of tc_gan/ext/ssnode.c.
+ * ------------------------------------------------------------------------ */
+
+/* Replaces ssnode.c:69-109 / 111-151 / 153-187 (ctypes decl clib.py:16-26).
+ * Host fp64 buffers, caller owned: W[M*M], ext[M] read-only; r0[M] in/out;
+ * r1[M] scratch.  Runs the fp64 HIP kernel (one workgroup), synchronous.
+ * Returns 0 converged / 1 max_iter / 2 reached rate_hard_bound (power and
+ * linear only) / >900 HIP failure.  On return the two caller buffers hold
+ * what the reference's pointer-swapping loop leaves in them (newest state in
+ * r0 on code 0; parity-dependent on codes 1 and 2 -- DESIGN.md "buffer
+ * parity").  Re-entrant, no global mutable state beyond the HIP runtime. */
+int solve_dynamics_asym_power_euler(int N, double *W, double *ext, double k, double n,
+                                    double *r0, double *r1, double tau_E, double tau_I,
+                                    double dt, int max_iter, double atol,
+                                    double rate_soft_bound, double rate_hard_bound);
+int solve_dynamics_asym_linear_euler(int N, double *W, double *ext, double k, double n,
+                                     double *r0, double *r1, double tau_E, double tau_I,
+                                     double dt, int max_iter, double atol,
+                                     double rate_soft_bound, double rate_hard_bound);
+int solve_dynamics_asym_tanh_euler(int N, double *W, double *ext, double k, double n,
+                                   double *r0, double *r1, double tau_E, double tau_I,
+                                   double dt, int max_iter, double atol,
+                                   double rate_soft_bound, double rate_hard_bound);
+
+/* Replace ssnode.c:21-53 (clib.py:28-33) and ssnode.c:10-19.  Scalar
+ * conveniences with the reference's signatures; each call evaluates the
+ * device function on the GPU for one element (see ssn_io_eval_f64 for the
+ * array form).  NaN on HIP failure. */
+double io_pow(double v, double r0, double r1, double v0, double k, double n);
+double io_alin(double v, double r0, double r1, double v0, double k, double n);
+double io_atanh(double v, double r0, double r1, double v0, double k, double n);
+double rate_to_volt(double rate, double k, double n);
+double dot(int dim, const double *x, const double *y);
+
+/* ------------------------------------------------------------------------
+ * 2. Additive batched ABI (new symbols).
+ * ------------------------------------------------------------------------ */
+
+#define SSN_IO_POWER  0   /* 'asym_power'  : ssnode.c io_pow   */
+#define SSN_IO_LINEAR 1   /* 'asym_linear' : ssnode.c io_alin  */
+#define SSN_IO_TANH   2   /* 'asym_tanh'   : ssnode.c io_atanh */
+#define SSN_ERR_BASE  1000
+
+/* Solver parameters; same meaning as the scalar arguments of the drop-in
+ * symbols (ssnode.c:55-62) / tc_gan.ssnode.fixed_point (ssnode.py:159-166). */
+typedef struct ssn_solver_params {
+    int io_type;             /* SSN_IO_* */
+    int max_iter;
+    double k, n;
+    double tau_E, tau_I;
+    double dt;
+    double atol;
+    double rate_soft_bound;
+    double rate_hard_bound;  /* for POWER/LINEAR: the rate_stop_at bound (ssnode.py:241-242); +inf disables */
+} ssn_solver_params;
+
+/* Library / device probes (host only). */
+int         ssn_abi_version(void);
+int         ssn_device_count(void);          /* <0: -hipError_t */
+const char *ssn_last_error(void);            /* thread-local, "" if none */
+/* Which kernel a (M, NB, dtype) solve would dispatch to: 1 = register-stationary
+ * DPP kernel, 0 = generic streaming kernel.  dtype_bytes is 4 or 8. */
+int         ssn_solver_fast_path(int M, int NB, int dtype_bytes);
+
+/*
+ * Batched fixed-point solve: B weight draws x NB stimuli.  Replaces the
+ * thread-pool-over-ctypes loop of tc_gan/ssnode.py:423-510 for one round of
+ * candidates.
+ *   W      device [B][M][M]
+ *   ext    device [NB][M] (ext_per_draw = 0) or [B][NB][M] (ext_per_draw = 1)
+ *   r      device [B][NB][M]  in: initial rates; out: newest state
+ *   r_prev device [B][NB][M] or NULL; out: state before the last executed step
+ *   codes  device int32 [B][NB]: 0 / 1 / 2 as the drop-in symbols
+ *   steps  device int32 [B][NB] or NULL: Euler steps executed
+ * Every (draw, stimulus) pair stops independently at its own convergence /
+ * bound step, exactly like an individual reference call.
+ * Returns 0 or SSN_ERR_BASE + hipError_t (launch errors only; async).
+ */
+int ssn_solve_batch_f32(const float *W, const float *ext, int ext_per_draw,
+                        float *r, float *r_prev, int *codes, int *steps,
+                        int B, int NB, int M, const ssn_solver_params *p, void *stream);
+int ssn_solve_batch_f64(const double *W, const double *ext, int ext_per_draw,
+                        double *r, double *r_prev, int *codes, int *steps,
+                        int B, int NB, int M, const ssn_solver_params *p, void *stream);
+/* Force a kernel variant (testing / A-B benchmarking): variant 0 = generic
+ * streaming kernel, 1 = register-stationary kernel (error if unsupported). */
+int ssn_solve_batch_f32_variant(int variant, const float *W, const float *ext, int ext_per_draw,
+                                float *r, float *r_prev, int *codes, int *steps,
+                                int B, int NB, int M, const ssn_solver_params *p, void *stream);
+int ssn_solve_batch_f64_variant(int variant, const double *W, const double *ext, int ext_per_draw,
+                                double *r, double *r_prev, int *codes, int *steps,
+                                int B, int NB, int M, const ssn_solver_params *p, void *stream);
+
+/* Host-buffer convenience forms of the above (numpy callers): allocate,
+ * copy in, solve, copy out, synchronise.  Same argument meaning, host
+ * pointers.  The PCIe copies are inside the call. */
+int ssn_solve_batch_host_f32(const float *W, const float *ext, int ext_per_draw,
+                             float *r, float *r_prev, int *codes, int *steps,
+                             int B, int NB, int M, const ssn_solver_params *p);
+int ssn_solve_batch_host_f64(const double *W, const double *ext, int ext_per_draw,
+                             double *r, double *r_prev, int *codes, int *steps,
+                             int B, int NB, int M, const ssn_solver_params *p);
+
+/*
+ * Connectivity from noise: W[b] = make_W_with_x(z[b]; J, D, S)
+ * (gradient_expressions/make_w_batch.py:8-34 == weight_gen.py:13-26).
+ *   z, W   device [B][M][M];  J, D, S  HOST float/double[4] row-major 2x2
+ *   (EE, EI, IE, II) -- signs applied inside (+ for E columns, - for I).
+ */
+int ssn_build_w_f32(const float *z, const float *J, const float *D, const float *S,
+                    float *W, int B, int N, void *stream);
+int ssn_build_w_f64(const double *z, const double *J, const double *D, const double *S,
+                    double *W, int B, int N, void *stream);
+
+/*
+ * Stimulus: ext[b][s][pN + i] = c[b][s] * sig((x_i + bw/2)/l) * sig((bw/2 - x_i)/l),
+ * x = linspace(-.5, .5, N), duplicated for E and I
+ * (stimuli.py:3-10; networks/ssn.py:167-193).
+ *   bandwidths, contrasts  device [B][NB];  ext device [B][NB][2N]
+ */
+int ssn_stimulus_f32(const float *bandwidths, const float *contrasts, float smoothness,
+                     float *ext, int B, int NB, int N, void *stream);
+int ssn_stimulus_f64(const double *bandwidths, const double *contrasts, double smoothness,
+                     double *ext, int B, int NB, int N, void *stream);
+
+/* I/O nonlinearity on arrays (device pointers), the device function the solver
+ * kernels use: out[i] = io(v[i]).  p->k, n, rate_soft_bound, rate_hard_bound,
+ * io_type are read; for SSN_IO_* semantics see ssnode.c:25-53. */
+int ssn_io_eval_f32(const float *v, float *out, long count, const ssn_solver_params *p, void *stream);
+int ssn_io_eval_f64(const double *v, double *out, long count, const ssn_solver_params *p, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSNODE_MI355X_H */

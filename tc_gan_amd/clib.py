@@ -1,0 +1,150 @@
+"""ctypes boundary to ``ext/libssnode.so`` (HIP / gfx950 build).
+
+Drop-in for the reference's ``tc_gan/clib.py`` (lines 7-33): same loader
+(``numpy.ctypeslib.load_library('libssnode', <pkg>/ext)`` at import time, so a
+missing library is an ``OSError`` on import), same ``libssnode`` object with the
+same argtypes/restype for the eight reference symbols, plus the additive
+batched ABI declared in ``include/ssnode_mi355x.h``.
+"""
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
+import ctypes
+import os
+
+import numpy
+
+# One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 /
+# libhsa-runtime64 (same SONAMEs as /opt/rocm's).  If libssnode.so pulled in the
+# system copies first, torch's later initialisation would find "No HIP GPUs".
+# Loading torch first makes the dynamic linker resolve libssnode's libamdhip64.so.7
+# to the copy that is already mapped, so kernels, streams and device pointers are
+# shared with torch tensors.  (torch is plumbing here: device memory and streams.)
+try:
+    import torch  # noqa: F401
+except ImportError:      # pure-ctypes use without torch: the system runtime is used
+    torch = None
+
+libdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ext')
+
+
+def load_library(name):
+    return numpy.ctypeslib.load_library(name, libdir)
+
+
+double_ptr = ctypes.POINTER(ctypes.c_double)
+
+libssnode = load_library('libssnode')
+
+# ---- reference symbols (tc_gan/clib.py:16-33) ---------------------------------
+for fun in [libssnode.solve_dynamics_asym_power_euler,
+            libssnode.solve_dynamics_asym_linear_euler,
+            libssnode.solve_dynamics_asym_tanh_euler]:
+    fun.argtypes = [
+        c_int, double_ptr, double_ptr, c_double, c_double,
+        double_ptr, double_ptr,
+        c_double, c_double,
+        c_double, c_int, c_double,
+        c_double, c_double,
+    ]
+    fun.restype = ctypes.c_int
+
+for fun in [libssnode.io_pow, libssnode.io_alin, libssnode.io_atanh]:
+    fun.argtypes = [c_double] * 6
+    fun.restype = c_double
+
+libssnode.rate_to_volt.argtypes = [c_double] * 3
+libssnode.rate_to_volt.restype = c_double
+
+libssnode.dot.argtypes = [c_int, double_ptr, double_ptr]
+libssnode.dot.restype = c_double
+
+
+# ---- additive batched ABI (include/ssnode_mi355x.h section 2) ------------------
+SSN_IO_POWER, SSN_IO_LINEAR, SSN_IO_TANH = 0, 1, 2
+SSN_ERR_BASE = 1000
+IO_CODES = {'asym_power': SSN_IO_POWER, 'asym_linear': SSN_IO_LINEAR, 'asym_tanh': SSN_IO_TANH}
+
+
+class SolverParams(Structure):
+    """``ssn_solver_params`` of include/ssnode_mi355x.h."""
+    _fields_ = [
+        ('io_type', c_int), ('max_iter', c_int),
+        ('k', c_double), ('n', c_double),
+        ('tau_E', c_double), ('tau_I', c_double),
+        ('dt', c_double), ('atol', c_double),
+        ('rate_soft_bound', c_double), ('rate_hard_bound', c_double),
+    ]
+
+
+_pp = POINTER(SolverParams)
+
+libssnode.ssn_abi_version.argtypes = []
+libssnode.ssn_abi_version.restype = c_int
+libssnode.ssn_device_count.argtypes = []
+libssnode.ssn_device_count.restype = c_int
+libssnode.ssn_last_error.argtypes = []
+libssnode.ssn_last_error.restype = c_char_p
+libssnode.ssn_solver_fast_path.argtypes = [c_int, c_int, c_int]
+libssnode.ssn_solver_fast_path.restype = c_int
+
+_solve_args = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+               c_int, c_int, c_int, _pp, c_void_p]
+for _name in ('ssn_solve_batch_f32', 'ssn_solve_batch_f64'):
+    getattr(libssnode, _name).argtypes = _solve_args
+    getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_solve_batch_f32_variant', 'ssn_solve_batch_f64_variant'):
+    getattr(libssnode, _name).argtypes = [c_int] + _solve_args
+    getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_solve_batch_host_f32', 'ssn_solve_batch_host_f64'):
+    getattr(libssnode, _name).argtypes = _solve_args[:-1]
+    getattr(libssnode, _name).restype = c_int
+
+libssnode.ssn_build_w_f32.argtypes = [c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float),
+                                      c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_build_w_f64.argtypes = [c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double),
+                                      c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_f32.argtypes = [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_f64.argtypes = [c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_io_eval_f32.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
+libssnode.ssn_io_eval_f64.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
+for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
+              'ssn_io_eval_f32', 'ssn_io_eval_f64'):
+    getattr(libssnode, _name).restype = c_int
+
+#: every symbol include/ssnode_mi355x.h declares (checked by tests/test_abi.py)
+DECLARED_SYMBOLS = (
+    'solve_dynamics_asym_power_euler', 'solve_dynamics_asym_linear_euler', 'solve_dynamics_asym_tanh_euler',
+    'io_pow', 'io_alin', 'io_atanh', 'rate_to_volt', 'dot',
+    'ssn_abi_version', 'ssn_device_count', 'ssn_last_error', 'ssn_solver_fast_path',
+    'ssn_solve_batch_f32', 'ssn_solve_batch_f64', 'ssn_solve_batch_f32_variant', 'ssn_solve_batch_f64_variant',
+    'ssn_solve_batch_host_f32', 'ssn_solve_batch_host_f64',
+    'ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
+    'ssn_io_eval_f32', 'ssn_io_eval_f64',
+)
+
+
+class GPUUnavailableError(RuntimeError):
+    """No usable HIP device: the product path refuses to run (no CPU fallback)."""
+
+
+class SSNLibraryError(RuntimeError):
+    """A libssnode entry point returned SSN_ERR_BASE + hipError_t."""
+
+
+def last_error():
+    return libssnode.ssn_last_error().decode()
+
+
+def check(rc, what):
+    """Raise on a non-zero status of an additive-ABI call."""
+    if rc != 0:
+        raise SSNLibraryError('{} failed: status {} ({})'.format(what, rc, last_error()))
+
+
+def require_gpu():
+    """Fail loudly when the HIP runtime sees no device."""
+    n = libssnode.ssn_device_count()
+    if n <= 0:
+        raise GPUUnavailableError(
+            'libssnode found no HIP device (ssn_device_count() = {}; {}). '
+            'tc_gan_amd has no CPU fallback.'.format(n, last_error()))
+    return n

@@ -1,0 +1,140 @@
+// Streaming helper kernels around the solver (gfx950): connectivity from noise,
+// stimulus profiles, array form of the I/O nonlinearity, and a dot product.
+// All are HBM-bound elementwise/reduction kernels.
+#include <hip/hip_runtime.h>
+#include "ssn_device.h"
+#include "ssn_host.h"
+
+namespace ssn {
+
+// W[b][pN+i][qN+j] = exp(-(x_i-x_j)^2/(2 S_pq^2)) * sign_q * (J_pq + D_pq z[b][pN+i][qN+j])
+// (gradient_expressions/make_w_batch.py:8-34; weight_gen.py:13-26).  8 B/element of HBM
+// traffic; one thread per 4 consecutive columns when M % 4 == 0 (16-B accesses).
+template <typename T>
+struct JDS { T J[4], D[4], inv2s2[4]; };
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) build_w_kernel(const T* __restrict__ z, T* __restrict__ W, JDS<T> p,
+                                                      int N, long total_vec) {
+    const int M = 2 * N;
+    const T inv_nm1 = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total_vec; v += (long)gridDim.x * blockDim.x) {
+        const long e0 = v * VEC;
+        const int col0 = (int)(e0 % M);
+        const int row = (int)((e0 / M) % M);
+        const int pp = row >= N, i = row - pp * N;
+        T zin[VEC], wout[VEC];
+        if constexpr (VEC == 4) {
+            using V4 = T __attribute__((ext_vector_type(4)));
+            const V4 q = *reinterpret_cast<const V4*>(z + e0);
+            zin[0] = q.x; zin[1] = q.y; zin[2] = q.z; zin[3] = q.w;
+        } else {
+            zin[0] = z[e0];
+        }
+#pragma unroll
+        for (int t = 0; t < VEC; ++t) {
+            const int col = col0 + t;
+            const int qq = col >= N, j = col - qq * N;
+            const int pq = pp * 2 + qq;
+            const T dx = (T)(i - j) * inv_nm1;
+            const T g = exp(-(dx * dx) * p.inv2s2[pq]);
+            const T sgn = qq ? (T)-1 : (T)1;
+            wout[t] = g * (sgn * p.J[pq] + sgn * p.D[pq] * zin[t]);
+        }
+        if constexpr (VEC == 4) {
+            using V4 = T __attribute__((ext_vector_type(4)));
+            V4 q; q.x = wout[0]; q.y = wout[1]; q.z = wout[2]; q.w = wout[3];
+            *reinterpret_cast<V4*>(W + e0) = q;
+        } else {
+            W[e0] = wout[0];
+        }
+    }
+}
+
+template <typename T>
+hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st) {
+    JDS<T> p;
+    for (int q = 0; q < 4; ++q) {
+        p.J[q] = jds12[q];
+        p.D[q] = jds12[4 + q];
+        p.inv2s2[q] = (T)1 / ((T)2 * jds12[8 + q] * jds12[8 + q]);
+    }
+    const int M = 2 * N;
+    const long total = (long)B * M * M;
+    if (total == 0) return hipSuccess;
+    const bool vec4 = (M % 4 == 0) && (((uintptr_t)z | (uintptr_t)W) % (4 * sizeof(T)) == 0);
+    const long nvec = vec4 ? total / 4 : total;
+    const int blocks = (int)((nvec + 255) / 256 < 256 * 8 ? (nvec + 255) / 256 : 256 * 8);
+    if (vec4) hipLaunchKernelGGL((build_w_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, z, W, p, N, nvec);
+    else      hipLaunchKernelGGL((build_w_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, z, W, p, N, nvec);
+    return hipGetLastError();
+}
+template hipError_t launch_build_w<float>(const float*, const float*, float*, int, int, hipStream_t);
+template hipError_t launch_build_w<double>(const double*, const double*, double*, int, int, hipStream_t);
+
+// ext[b][s][pN+i] = c * sig((x_i + bw/2)/l) * sig((bw/2 - x_i)/l)   (stimuli.py:3-10)
+template <typename T>
+__global__ void __launch_bounds__(256) stimulus_kernel(const T* __restrict__ bw, const T* __restrict__ con, T inv_l,
+                                                       T* __restrict__ ext, int N, long total) {
+    const int M = 2 * N;
+    const T step = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(e % M);
+        const long bs = e / M;
+        const int i = m >= N ? m - N : m;
+        const T x = (T)-0.5 + step * (T)i;
+        const T hb = bw[bs] * (T)0.5;
+        const T s1 = (T)1 / ((T)1 + exp(-(x + hb) * inv_l));
+        const T s2 = (T)1 / ((T)1 + exp(-(hb - x) * inv_l));
+        ext[e] = con[bs] * s1 * s2;
+    }
+}
+template <typename T>
+hipError_t launch_stimulus(const T* bw, const T* con, T smooth, T* ext, int B, int NB, int N, hipStream_t st) {
+    const long total = (long)B * NB * 2 * N;
+    if (total == 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL((stimulus_kernel<T>), dim3(blocks), dim3(256), 0, st, bw, con, (T)1 / smooth, ext, N, total);
+    return hipGetLastError();
+}
+template hipError_t launch_stimulus<float>(const float*, const float*, float, float*, int, int, int, hipStream_t);
+template hipError_t launch_stimulus<double>(const double*, const double*, double, double*, int, int, int, hipStream_t);
+
+template <typename T>
+__global__ void __launch_bounds__(256) io_eval_kernel(const T* __restrict__ v, T* __restrict__ out, long count, IoConsts<T> io) {
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < count; e += (long)gridDim.x * blockDim.x)
+        out[e] = io_eval(v[e], io);
+}
+template <typename T>
+hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st) {
+    if (count == 0) return hipSuccess;
+    const int blocks = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+    hipLaunchKernelGGL((io_eval_kernel<T>), dim3(blocks), dim3(256), 0, st, v, out, count, io);
+    return hipGetLastError();
+}
+template hipError_t launch_io_eval<float>(const float*, float*, long, const IoConsts<float>&, hipStream_t);
+template hipError_t launch_io_eval<double>(const double*, double*, long, const IoConsts<double>&, hipStream_t);
+
+// Single-workgroup dot product, sequential-in-chunks (ssnode.c:10-19 `dot`).
+template <typename T>
+__global__ void __launch_bounds__(256) dot_kernel(const T* __restrict__ x, const T* __restrict__ y, T* out, int dim) {
+    __shared__ T part[256];
+    T s = (T)0;
+    for (int j = threadIdx.x; j < dim; j += 256) s = fma(x[j], y[j], s);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0];
+}
+template <typename T>
+hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st) {
+    hipLaunchKernelGGL((dot_kernel<T>), dim3(1), dim3(256), 0, st, x, y, out, dim);
+    return hipGetLastError();
+}
+template hipError_t launch_dot<float>(const float*, const float*, float*, int, hipStream_t);
+template hipError_t launch_dot<double>(const double*, const double*, double*, int, hipStream_t);
+
+}  // namespace ssn

@@ -1,0 +1,271 @@
+// extern "C" surface of libssnode.so (see include/ssnode_mi355x.h).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+#include "ssn_host.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(hipError_t e, const char* where) {
+    g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+    return SSN_ERR_BASE + (int)e;
+}
+#define SSN_TRY(expr)                                     \
+    do {                                                  \
+        hipError_t e__ = (expr);                          \
+        if (e__ != hipSuccess) return fail(e__, #expr);   \
+    } while (0)
+
+template <typename T>
+int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T* r, T* r_prev, int* codes,
+                     int* steps, int B, int NB, int M, const ssn_solver_params* p, void* stream) {
+    if (B == 0 || NB == 0) return 0;   // empty batch: nothing to do (pointers may be null)
+    if (!p || !W || !ext || !r || !codes || B < 0 || NB < 0 || M <= 0 || (M & 1) || p->io_type < 0 ||
+        p->io_type > 2 || p->max_iter < 0) {
+        g_last_error = "ssn_solve_batch: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::SolveArgs<T> a;
+    a.W = W; a.ext = ext; a.r = r; a.r_prev = r_prev; a.codes = codes; a.steps = steps;
+    a.ext_per_draw = ext_per_draw; a.B = B; a.NB = NB; a.M = M; a.N = M / 2;
+    a.io = ssn::make_io_consts<T>(*p);
+    a.st = ssn::make_step_consts<T>(*p);
+    hipStream_t st = (hipStream_t)stream;
+    const bool fast_ok = ssn::regw_supported<T>(M, NB);
+    if (variant == 1 && !fast_ok) {
+        g_last_error = "ssn_solve_batch: register-stationary kernel has no instantiation for this size";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    const bool fast = (variant == 1) || (variant < 0 && fast_ok);
+    SSN_TRY(fast ? ssn::launch_regw<T>(a, st) : ssn::launch_stream<T>(a, st));
+    return 0;
+}
+
+template <typename T>
+int solve_batch_host_impl(const T* W, const T* ext, int ext_per_draw, T* r, T* r_prev, int* codes, int* steps,
+                          int B, int NB, int M, const ssn_solver_params* p) {
+    if (B == 0 || NB == 0) return 0;
+    const size_t nW = (size_t)B * M * M * sizeof(T);
+    const size_t nE = (size_t)(ext_per_draw ? B : 1) * NB * M * sizeof(T);
+    const size_t nR = (size_t)B * NB * M * sizeof(T);
+    const size_t nC = (size_t)B * NB * sizeof(int);
+    T *dW = nullptr, *dE = nullptr, *dR = nullptr, *dP = nullptr;
+    int *dC = nullptr, *dS = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        hipFree(dW); hipFree(dE); hipFree(dR); hipFree(dP); hipFree(dC); hipFree(dS);
+    };
+#define SSN_TRYC(expr)                                                    \
+    do {                                                                  \
+        hipError_t e__ = (expr);                                          \
+        if (e__ != hipSuccess) { cleanup(); return fail(e__, #expr); }    \
+    } while (0)
+    SSN_TRYC(hipMalloc(&dW, nW));
+    SSN_TRYC(hipMalloc(&dE, nE));
+    SSN_TRYC(hipMalloc(&dR, nR));
+    SSN_TRYC(hipMalloc(&dP, nR));
+    SSN_TRYC(hipMalloc(&dC, nC));
+    SSN_TRYC(hipMalloc(&dS, nC));
+    SSN_TRYC(hipMemcpy(dW, W, nW, hipMemcpyHostToDevice));
+    SSN_TRYC(hipMemcpy(dE, ext, nE, hipMemcpyHostToDevice));
+    SSN_TRYC(hipMemcpy(dR, r, nR, hipMemcpyHostToDevice));
+    rc = solve_batch_impl<T>(-1, dW, dE, ext_per_draw, dR, dP, dC, dS, B, NB, M, p, nullptr);
+    if (rc) { cleanup(); return rc; }
+    SSN_TRYC(hipDeviceSynchronize());
+    SSN_TRYC(hipMemcpy(r, dR, nR, hipMemcpyDeviceToHost));
+    if (r_prev) SSN_TRYC(hipMemcpy(r_prev, dP, nR, hipMemcpyDeviceToHost));
+    SSN_TRYC(hipMemcpy(codes, dC, nC, hipMemcpyDeviceToHost));
+    if (steps) SSN_TRYC(hipMemcpy(steps, dS, nC, hipMemcpyDeviceToHost));
+    cleanup();
+    return 0;
+#undef SSN_TRYC
+}
+
+// The reference's single-solve entry point on the GPU (fp64 kernel, one workgroup),
+// leaving the caller's two buffers as ssnode.c's pointer-swapping loop would.
+int legacy_solve(int io_type, int N, double* W, double* ext, double k, double n, double* r0, double* r1,
+                 double tau_E, double tau_I, double dt, int max_iter, double atol, double soft, double hard) {
+    if (N <= 0 || !W || !ext || !r0 || !r1) {
+        g_last_error = "solve_dynamics: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn_solver_params p;
+    p.io_type = io_type; p.max_iter = max_iter < 0 ? 0 : max_iter; p.k = k; p.n = n; p.tau_E = tau_E;
+    p.tau_I = tau_I; p.dt = dt; p.atol = atol; p.rate_soft_bound = soft; p.rate_hard_bound = hard;
+    const int M = 2 * N;
+    if (p.max_iter == 0) return 1;   // ssnode.c: loop body never runs, buffers untouched
+    std::vector<double> newest(r0, r0 + M), prev(M);
+    int code = -1, steps = 0;
+    int rc = solve_batch_host_impl<double>(W, ext, 0, newest.data(), prev.data(), &code, &steps, 1, 1, M, &p);
+    if (rc) return rc;
+    // Which caller buffer plays "r0" after `swaps` role exchanges (ssnode.c:104-106).
+    if (code == 0) {
+        // converged at step `steps`: swaps = steps-1; the newest state is copied into the current "r0"
+        // buffer, so BOTH roles hold it; the other caller buffer keeps what it had as "r1" = newest too.
+        std::memcpy(r0, newest.data(), M * sizeof(double));
+        std::memcpy(r1, newest.data(), M * sizeof(double));
+    } else {
+        // code 2: return before the exchange -> swaps = steps-1, newest is in the "r1" role.
+        // code 1: all max_iter exchanges done -> newest is in the "r0" role after `steps` swaps.
+        const int swaps = (code == 2) ? steps - 1 : steps;
+        const bool r0_role_is_caller_r0 = (swaps % 2 == 0);
+        const bool newest_in_r0_role = (code == 1);
+        const bool newest_to_caller_r0 = (newest_in_r0_role == r0_role_is_caller_r0);
+        std::memcpy(newest_to_caller_r0 ? r0 : r1, newest.data(), M * sizeof(double));
+        std::memcpy(newest_to_caller_r0 ? r1 : r0, prev.data(), M * sizeof(double));
+    }
+    return code;
+}
+
+double legacy_io(int io_type, double v, double r0, double r1, double v0, double k, double n) {
+    // The reference's scalar helpers take v0 explicitly (ssnode.c:25-53), so the constants are
+    // filled in directly instead of being derived from the soft bound.
+    ssn::IoConsts<double> c;
+    c.io_type = io_type; c.k = k; c.n = n; c.v0 = v0; c.soft = r0; c.hard = r1;
+    c.lin_slope = k * std::pow(v0, n - 1.0) * n;
+    c.tanh_gain = n * r0 / ((r1 - r0) * v0);
+    double *dv = nullptr, out = std::numeric_limits<double>::quiet_NaN();
+    if (hipMalloc(&dv, 2 * sizeof(double)) != hipSuccess) return out;
+    if (hipMemcpy(dv, &v, sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+        ssn::launch_io_eval<double>(dv, dv + 1, 1, c, nullptr) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess)
+        hipMemcpy(&out, dv + 1, sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dv);
+    return out;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ssn_abi_version(void) { return 1; }
+
+int ssn_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail(e, "hipGetDeviceCount"); return -(int)e; }
+    return n;
+}
+
+const char* ssn_last_error(void) { return g_last_error.c_str(); }
+
+int ssn_solver_fast_path(int M, int NB, int dtype_bytes) {
+    if (M <= 0 || (M & 1)) return 0;
+    return dtype_bytes == 8 ? ssn::regw_supported<double>(M, NB) : ssn::regw_supported<float>(M, NB);
+}
+
+int ssn_solve_batch_f32(const float* W, const float* ext, int ext_per_draw, float* r, float* r_prev, int* codes,
+                        int* steps, int B, int NB, int M, const ssn_solver_params* p, void* stream) {
+    return solve_batch_impl<float>(-1, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
+}
+int ssn_solve_batch_f64(const double* W, const double* ext, int ext_per_draw, double* r, double* r_prev,
+                        int* codes, int* steps, int B, int NB, int M, const ssn_solver_params* p, void* stream) {
+    return solve_batch_impl<double>(-1, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
+}
+int ssn_solve_batch_f32_variant(int variant, const float* W, const float* ext, int ext_per_draw, float* r,
+                                float* r_prev, int* codes, int* steps, int B, int NB, int M,
+                                const ssn_solver_params* p, void* stream) {
+    return solve_batch_impl<float>(variant ? 1 : 0, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
+}
+int ssn_solve_batch_f64_variant(int variant, const double* W, const double* ext, int ext_per_draw, double* r,
+                                double* r_prev, int* codes, int* steps, int B, int NB, int M,
+                                const ssn_solver_params* p, void* stream) {
+    return solve_batch_impl<double>(variant ? 1 : 0, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
+}
+int ssn_solve_batch_host_f32(const float* W, const float* ext, int ext_per_draw, float* r, float* r_prev,
+                             int* codes, int* steps, int B, int NB, int M, const ssn_solver_params* p) {
+    return solve_batch_host_impl<float>(W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p);
+}
+int ssn_solve_batch_host_f64(const double* W, const double* ext, int ext_per_draw, double* r, double* r_prev,
+                             int* codes, int* steps, int B, int NB, int M, const ssn_solver_params* p) {
+    return solve_batch_host_impl<double>(W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p);
+}
+
+int ssn_build_w_f32(const float* z, const float* J, const float* D, const float* S, float* W, int B, int N, void* stream) {
+    float jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_build_w<float>(z, jds, W, B, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_build_w_f64(const double* z, const double* J, const double* D, const double* S, double* W, int B, int N, void* stream) {
+    double jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_build_w<double>(z, jds, W, B, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_stimulus_f32(const float* bw, const float* con, float smoothness, float* ext, int B, int NB, int N, void* stream) {
+    SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, ext, B, NB, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_stimulus_f64(const double* bw, const double* con, double smoothness, double* ext, int B, int NB, int N, void* stream) {
+    SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, ext, B, NB, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_io_eval_f32(const float* v, float* out, long count, const ssn_solver_params* p, void* stream) {
+    SSN_TRY(ssn::launch_io_eval<float>(v, out, count, ssn::make_io_consts<float>(*p), (hipStream_t)stream));
+    return 0;
+}
+int ssn_io_eval_f64(const double* v, double* out, long count, const ssn_solver_params* p, void* stream) {
+    SSN_TRY(ssn::launch_io_eval<double>(v, out, count, ssn::make_io_consts<double>(*p), (hipStream_t)stream));
+    return 0;
+}
+
+// ---- drop-in symbols (tc_gan/ext/ssnode.c exports) ------------------------------
+int solve_dynamics_asym_power_euler(int N, double* W, double* ext, double k, double n, double* r0, double* r1,
+                                    double tau_E, double tau_I, double dt, int max_iter, double atol,
+                                    double rate_soft_bound, double rate_hard_bound) {
+    return legacy_solve(SSN_IO_POWER, N, W, ext, k, n, r0, r1, tau_E, tau_I, dt, max_iter, atol, rate_soft_bound, rate_hard_bound);
+}
+int solve_dynamics_asym_linear_euler(int N, double* W, double* ext, double k, double n, double* r0, double* r1,
+                                     double tau_E, double tau_I, double dt, int max_iter, double atol,
+                                     double rate_soft_bound, double rate_hard_bound) {
+    return legacy_solve(SSN_IO_LINEAR, N, W, ext, k, n, r0, r1, tau_E, tau_I, dt, max_iter, atol, rate_soft_bound, rate_hard_bound);
+}
+int solve_dynamics_asym_tanh_euler(int N, double* W, double* ext, double k, double n, double* r0, double* r1,
+                                   double tau_E, double tau_I, double dt, int max_iter, double atol,
+                                   double rate_soft_bound, double rate_hard_bound) {
+    return legacy_solve(SSN_IO_TANH, N, W, ext, k, n, r0, r1, tau_E, tau_I, dt, max_iter, atol, rate_soft_bound, rate_hard_bound);
+}
+
+double io_pow(double v, double r0, double r1, double v0, double k, double n) { return legacy_io(SSN_IO_POWER, v, r0, r1, v0, k, n); }
+double io_alin(double v, double r0, double r1, double v0, double k, double n) { return legacy_io(SSN_IO_LINEAR, v, r0, r1, v0, k, n); }
+double io_atanh(double v, double r0, double r1, double v0, double k, double n) { return legacy_io(SSN_IO_TANH, v, r0, r1, v0, k, n); }
+
+double rate_to_volt(double rate, double k, double n) {
+    // (rate/k)^(1/n) == the v at which io_pow(v) = rate: evaluate on the device through the same
+    // pow routine the kernels use:  k' * x^n' with k' = 1, x = rate/k, n' = 1/n.
+    ssn_solver_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.io_type = SSN_IO_POWER; p.k = 1.0; p.n = 1.0 / n; p.rate_soft_bound = 1.0; p.rate_hard_bound = 2.0;
+    const double x = rate / k;
+    double *dv = nullptr, out = std::numeric_limits<double>::quiet_NaN();
+    if (hipMalloc(&dv, 2 * sizeof(double)) != hipSuccess) return out;
+    if (hipMemcpy(dv, &x, sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+        ssn::launch_io_eval<double>(dv, dv + 1, 1, ssn::make_io_consts<double>(p), nullptr) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess)
+        hipMemcpy(&out, dv + 1, sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dv);
+    return out;
+}
+
+double dot(int dim, const double* x, const double* y) {
+    double out = std::numeric_limits<double>::quiet_NaN();
+    if (dim <= 0) return 0.0;
+    double* d = nullptr;
+    if (hipMalloc(&d, (2 * (size_t)dim + 1) * sizeof(double)) != hipSuccess) return out;
+    if (hipMemcpy(d, x, dim * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(d + dim, y, dim * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+        ssn::launch_dot<double>(d, d + dim, d + 2 * dim, dim, nullptr) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess)
+        hipMemcpy(&out, d + 2 * dim, sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d);
+    return out;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Stimulus profiles -- mirror of ``tc_gan/stimuli.py`` (lines 3-10), device evaluated.
+
+``input(bv, x, l, c, o)`` returns, contrast-major then offset then bandwidth,
+rows ``con * band(x - off, b, l)`` duplicated for the E and I populations.  The
+arithmetic runs on the GPU: the HIP kernel ``ssn_stimulus_f64`` when `x` is the
+canonical ``linspace(-.5, .5, N)`` grid without offsets (the only form the hot
+path uses, networks/ssn.py:167-193), elementwise torch-on-CUDA otherwise.
+"""
+import ctypes
+
+import numpy as np
+
+from . import clib
+from .clib import libssnode
+
+
+def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32'):
+    """Device form: `bandwidths`, `contrasts` of shape (B, NB) -> CUDA tensor (B, NB, 2*num_sites)
+    (networks/ssn.py:177-188)."""
+    import torch
+    clib.require_gpu()
+    td = {'float32': torch.float32, 'float64': torch.float64}[str(np.dtype(dtype))]
+    bw = torch.as_tensor(bandwidths).to('cuda', td).contiguous()
+    con = torch.as_tensor(contrasts).to('cuda', td).contiguous()
+    assert bw.shape == con.shape and bw.dim() == 2
+    B, NB = bw.shape
+    ext = torch.empty((B, NB, 2 * num_sites), device='cuda', dtype=td)
+    fn, ct = ((libssnode.ssn_stimulus_f32, ctypes.c_float) if td == torch.float32
+              else (libssnode.ssn_stimulus_f64, ctypes.c_double))
+    clib.check(fn(bw.data_ptr(), con.data_ptr(), ct(smoothness), ext.data_ptr(), int(B), int(NB),
+                  int(num_sites), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_stimulus')
+    return ext
+
+
+def sigm(x, l=.1):
+    import torch
+    return 1. / (1 + torch.exp(-x / l))
+
+
+def band(x, b, l=.1):
+    return sigm(x + (b / 2), l) * sigm((b / 2) - x, l)
+
+
+def input(bv, x, l=.1, c=[20.], o=[0.]):
+    import torch
+    clib.require_gpu()
+    x = np.asarray(x, dtype='double')
+    bv = [float(b) for b in bv]
+    c = [float(v) for v in c]
+    o = [float(v) for v in o]
+    N = len(x)
+    canonical = (N > 1 and list(o) == [0.0] and
+                 np.array_equal(x, np.linspace(-0.5, 0.5, N)))
+    if canonical:
+        bw = np.tile(np.asarray(bv), len(c))[None, :]
+        con = np.repeat(np.asarray(c), len(bv))[None, :]
+        return stimulus_batch(bw, con, l, N, dtype='float64')[0].cpu().numpy()
+    xd = torch.as_tensor(x, device='cuda')
+    rows = []
+    for con in c:
+        for off in o:
+            for b in bv:
+                prof = band(xd - off, b, l)
+                rows.append(con * torch.cat([prof, prof]))
+    return torch.stack(rows).cpu().numpy()
