@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the SSN fixed-point hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c2nb8|c1]
+
+Metric (BASELINE.json): SSN-steps/sec = neurons x batch x Euler-steps / s.
+Workload at N=1 (BASELINE config 2, the one `metric` is quoted on): 2N=200 neurons,
+batch 4096 independent weight draws, 2000 Euler steps, fp32, asym_tanh, atol=0 (so
+exactly 2000 steps execute), synthetic z ~ U(0,1) resident in
+HBM; W = make_W_with_x(z; new_JDS) is rebuilt on the device inside every step.
+A "step" = one pass of the hot path over one batch: build W from z, then one batched
+solve.  N>1: one process per GPU (torch.distributed / RCCL), every rank solves its own
+batch of 4096 draws (the path partitions over draws, no data-path collective) ->
+"scaling": "weak"; value = all ranks' units / max-over-ranks time.
+
+Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timed) and
+`cpu_baseline` (the reference's own C file, oracle/_ref, on the host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)"
+
+WORKLOADS = {
+    # name: (N, B, NB, T, description)
+    'c2': (100, 4096, 1, 2000, 'C2: SSN fixed-point forward, 2N=200, batch 4096, NB=1 stimulus, 2000 Euler steps'),
+    'c2nb8': (100, 4096, 8, 2000, 'C2/NB=8: 2N=200, batch 4096, 8 stimuli per draw, 2000 Euler steps'),
+    'c1': (50, 64, 1, 500, 'C1: 2N=100, batch 64, NB=1, 500 Euler steps'),
+}
+
+
+def new_jds():
+    # tc_gan/networks/fixed_time_sampler.py:12-21
+    J = np.array([[.0957, .0638], [.1197, .0479]])
+    D = np.array([[.7660, .5106], [.9575, .3830]])
+    S = np.array([[.6667, .2], [1.333, .2]]) / 8
+    return J + D / 2 - D / 4, D / 2, S
+
+
+def cpu_baseline(N, NB, T, sample_B, threads):
+    """Time the reference's C solver (oracle/_ref/libssnode.so, built from
+    tc_gan/ext/ssnode.c unmodified) driven as ssnode.find_fixed_points_parallel drives it
+    (ssnode.py:423-510): a pool of Python threads, one task per weight draw, each blocking
+    in ctypes with the GIL released.  Falls back to the oracle's C restatement ("port")
+    when the prebuilt reference library is absent."""
+    from multiprocessing.dummy import Pool
+    from oracle import ssn_numpy as on
+    ref = on.load_reference_lib()
+    kind = 'reference' if ref is not None else 'port'
+    J, D, S = new_jds()
+    M = 2 * N
+    rs = np.random.RandomState(0)
+    Ws = [on.generate_weight(N, J, D, S, rs.rand(M, M)) for _ in range(sample_B)]
+    bws = [1.0] if NB == 1 else on.DEFAULT_PARAMS['bandwidths'][:NB]
+    exts = on.stimulus_input(bws, np.linspace(-.5, .5, N), on.DEFAULT_PARAMS['smoothness'], [20.])
+    P = on.DEFAULT_PARAMS
+    lib = None if ref is not None else on.load_oracle_lib()
+
+    def task(W):
+        for ext in exts[::-1]:
+            r0 = np.zeros(M)
+            r1 = np.empty(M)
+            if ref is not None:
+                ref.solve_dynamics_asym_tanh_euler(N, on.ptr(W), on.ptr(ext), P['k'], P['n'], on.ptr(r0), on.ptr(r1),
+                                                   P['tau'][0], P['tau'][1], 8e-4, T, 0.0, 200., 1000.)
+            else:
+                lib.oracle_solve_euler(2, N, on.ptr(W), on.ptr(ext), P['k'], P['n'], on.ptr(r0), on.ptr(r1),
+                                       P['tau'][0], P['tau'][1], 8e-4, T, 0.0, 200., 1000., None)
+        return r0[0]
+
+    pool = Pool(threads)
+    pool.map(task, Ws[:threads])                      # warm-up
+    best = float('inf')
+    for _ in range(2):
+        t0 = time.perf_counter()
+        pool.map(task, Ws, chunksize=1)
+        best = min(best, time.perf_counter() - t0)
+    pool.close()
+    pool.join()
+    units = float(M) * sample_B * NB * T
+    return dict(value=units / best, unit='neuron*batch*Euler-steps/s', cores=threads, kind=kind,
+                sample='%d of the workload\'s weight draws x %d stimuli x %d steps, 2N=%d, fp64, '
+                       '%d Python threads over ctypes (best of 2 after warm-up, %.2f s)' %
+                       (sample_B, NB, T, M, threads, best))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming kernel, 1 register-stationary')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tc_gan_amd import clib
+    from tc_gan_amd.clib import libssnode
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if rank == 0:
+            print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    clib.require_gpu()
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    N, B, NB, T, desc = WORKLOADS[args.workload]
+    M = 2 * N
+    J, D, S = new_jds()
+    dev = torch.device('cuda', local_rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)                      # per-rank stream: independent weight draws
+    z = torch.rand((B, M, M), device=dev, dtype=torch.float32, generator=gen)
+    W = torch.empty_like(z)
+    bws = [1.0] if NB == 1 else [0, 0.0625, 0.125, 0.1875, 0.25, 0.5, 0.75, 1][:NB]
+    bw = torch.tensor([bws], device=dev, dtype=torch.float32)
+    con = torch.full_like(bw, 20.0)
+    ext = torch.empty((1, NB, M), device=dev, dtype=torch.float32)
+    r = torch.zeros((B, NB, M), device=dev, dtype=torch.float32)
+    codes = torch.empty((B, NB), device=dev, dtype=torch.int32)
+    steps_out = torch.empty((B, NB), device=dev, dtype=torch.int32)
+    p = clib.SolverParams(io_type=clib.SSN_IO_TANH, max_iter=T, k=0.01, n=2.2, tau_E=0.01589, tau_I=0.002,
+                          dt=8e-4, atol=0.0, rate_soft_bound=200.0, rate_hard_bound=1000.0)
+    f4 = ctypes.c_float * 4
+    Jc, Dc, Sc = (f4(*np.asarray(a, dtype=float).reshape(4)) for a in (J, D, S))
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    clib.check(libssnode.ssn_stimulus_f32(bw.data_ptr(), con.data_ptr(), ctypes.c_float(0.25 / 8), ext.data_ptr(),
+                                          1, NB, N, stream), 'ssn_stimulus_f32')
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+
+    def one_step(k=None):
+        r.zero_()
+        clib.check(libssnode.ssn_build_w_f32(z.data_ptr(), Jc, Dc, Sc, W.data_ptr(), B, N, stream), 'ssn_build_w_f32')
+        if k is not None:
+            ev[k][0].record()
+        if args.variant < 0:
+            rc = libssnode.ssn_solve_batch_f32(W.data_ptr(), ext.data_ptr(), 0, r.data_ptr(), None, codes.data_ptr(),
+                                               steps_out.data_ptr(), B, NB, M, ctypes.byref(p), stream)
+        else:
+            rc = libssnode.ssn_solve_batch_f32_variant(args.variant, W.data_ptr(), ext.data_ptr(), 0, r.data_ptr(), None,
+                                                       codes.data_ptr(), steps_out.data_ptr(), B, NB, M,
+                                                       ctypes.byref(p), stream)
+        clib.check(rc, 'ssn_solve_batch_f32')
+        if k is not None:
+            ev[k][1].record()
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the work really ran (all pairs took exactly T steps with code 1, states finite)
+    assert int((steps_out != T).sum()) == 0 and int((codes != 1).sum()) == 0
+    assert bool(torch.isfinite(r).all())
+
+    units_per_step = float(M) * B * NB * T                      # neuron x batch x Euler steps (per rank)
+    value = units_per_step * args.steps * world / elapsed
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    flops_per_unit = 2 * M + 8
+    achieved = units_per_step * flops_per_unit / (kernel_ms * 1e-3) * 1e-12
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')   # PMC-derived bytes per launch, if collected
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(args.workload)
+        except Exception:
+            traffic = None
+    fast = libssnode.ssn_solver_fast_path(M, NB, 4) if args.variant < 0 else args.variant
+    out = {
+        'metric': 'SSN-steps/sec', 'value': value, 'unit': 'neuron*batch*Euler-steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': desc + ', asym_tanh, atol=0, fp32, W rebuilt from resident z each step',
+                   'neurons': M, 'batch_per_gpu': B, 'stimuli_per_draw': NB, 'euler_steps': T,
+                   'kernel': 'solve_regw_kernel' if fast else 'solve_stream_kernel',
+                   'parallelism': 'draws sharded over %d GPU(s), no data-path collective' % world},
+        'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
+                     'kernel_ms': kernel_ms, 'flops_per_unit': flops_per_unit,
+                     'algorithmic_hbm_bytes': B * (4 * M * M + 12 * M * NB)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = min(len(os.sched_getaffinity(0)), 16)           # the 1-GPU box's CPU share
+        sample = args.cpu_sample or max(threads * 8, int(1024 / NB) if args.workload != 'c1' else 64)
+        out['cpu_baseline'] = cpu_baseline(N, NB, T, sample, threads)
+        out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -103,7 +103,9 @@ __global__ void __launch_bounds__(256) solve_stream_kernel(SolveArgs<T> a) {
 // compiler does not fold update_dpp into the fmac, so the sequence is spelled out).
 template <int BASE, int NW>
 __device__ __forceinline__ void chunk_fma(float& acc, float rv, const float (&w)[NW]) {
-    asm volatile(
+    // not `volatile`: the statement is a pure function of its operands, so the scheduler may hoist
+    // the LDS reads of later chunks above it (with `volatile` every chunk waited for its own read).
+    asm(
         "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
@@ -176,9 +178,28 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_regw_kernel(SolveA
     // ---- prologue: my row of W -> registers (zero padded), state -> LDS -----------
     T w[MP];
     {
+        // Unconditional loads from clamped (always valid) addresses, then masked by multiplication:
+        // a select would let the compiler put every load under an exec branch with its own
+        // s_waitcnt vmcnt(0), serialising 16*KCH HBM round trips per workgroup.
         const T* wrow = a.W + ((size_t)b * M + (row_ok ? i : 0)) * M;
+        const T rowmask = row_ok ? (T)1 : (T)0;
+        if ((M & 3) == 0) {
+            using V4 = T __attribute__((ext_vector_type(4)));
+            const V4* wrow4 = reinterpret_cast<const V4*>(wrow);
+            const int nv = M >> 2;
 #pragma unroll
-        for (int c = 0; c < MP; ++c) w[c] = (row_ok && c < M) ? wrow[c] : (T)0;
+            for (int c4 = 0; c4 < MP / 4; ++c4) {
+                const V4 q = wrow4[c4 < nv ? c4 : nv - 1];
+                const T m = (c4 < nv) ? rowmask : (T)0;
+                w[4 * c4 + 0] = q.x * m; w[4 * c4 + 1] = q.y * m; w[4 * c4 + 2] = q.z * m; w[4 * c4 + 3] = q.w * m;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < MP; ++c) {
+                const T v = wrow[c < M ? c : M - 1];
+                w[c] = v * ((c < M) ? rowmask : (T)0);
+            }
+        }
     }
     T rc[NB], rp[NB], ex[NB];
     bool live[NB];           // stimulus exists (tail group may be partial)
