@@ -85,8 +85,9 @@ typedef struct ssn_solver_params {
 int         ssn_abi_version(void);
 int         ssn_device_count(void);          /* <0: -hipError_t */
 const char *ssn_last_error(void);            /* thread-local, "" if none */
-/* Which kernel a (M, NB, dtype) solve would dispatch to: 1 = register-stationary
- * DPP kernel, 0 = generic streaming kernel.  dtype_bytes is 4 or 8. */
+/* Which kernel a (M, NB, dtype) solve dispatches to: 2 = register-stationary "tile"
+ * kernel, 1 = register-stationary DPP kernel, 0 = generic streaming kernel.
+ * dtype_bytes is 4 or 8. */
 int         ssn_solver_fast_path(int M, int NB, int dtype_bytes);
 
 /*
@@ -109,8 +110,9 @@ int ssn_solve_batch_f32(const float *W, const float *ext, int ext_per_draw,
 int ssn_solve_batch_f64(const double *W, const double *ext, int ext_per_draw,
                         double *r, double *r_prev, int *codes, int *steps,
                         int B, int NB, int M, const ssn_solver_params *p, void *stream);
-/* Force a kernel variant (testing / A-B benchmarking): variant 0 = generic
- * streaming kernel, 1 = register-stationary kernel (error if unsupported). */
+/* Force a kernel variant (testing / A-B benchmarking): 0 = generic streaming
+ * kernel, 1 = register-stationary DPP kernel, 2 = register-stationary tile kernel
+ * (error if the size has no instantiation), negative = automatic. */
 int ssn_solve_batch_f32_variant(int variant, const float *W, const float *ext, int ext_per_draw,
                                 float *r, float *r_prev, int *codes, int *steps,
                                 int B, int NB, int M, const ssn_solver_params *p, void *stream);

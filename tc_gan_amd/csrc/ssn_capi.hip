@@ -37,13 +37,18 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     a.io = ssn::make_io_consts<T>(*p);
     a.st = ssn::make_step_consts<T>(*p);
     hipStream_t st = (hipStream_t)stream;
-    const bool fast_ok = ssn::regw_supported<T>(M, NB);
-    if (variant == 1 && !fast_ok) {
-        g_last_error = "ssn_solve_batch: register-stationary kernel has no instantiation for this size";
+    // variant: -1 auto (tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile
+    const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
+    if ((variant == 1 && !regw_ok) || (variant == 2 && !tile_ok) || variant > 2) {
+        g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
-    const bool fast = (variant == 1) || (variant < 0 && fast_ok);
-    SSN_TRY(fast ? ssn::launch_regw<T>(a, st) : ssn::launch_stream<T>(a, st));
+    if (variant < 0) variant = tile_ok ? 2 : (regw_ok ? 1 : 0);
+    switch (variant) {
+        case 2: SSN_TRY(ssn::launch_tile<T>(a, st)); break;
+        case 1: SSN_TRY(ssn::launch_regw<T>(a, st)); break;
+        default: SSN_TRY(ssn::launch_stream<T>(a, st)); break;
+    }
     return 0;
 }
 
@@ -157,7 +162,9 @@ const char* ssn_last_error(void) { return g_last_error.c_str(); }
 
 int ssn_solver_fast_path(int M, int NB, int dtype_bytes) {
     if (M <= 0 || (M & 1)) return 0;
-    return dtype_bytes == 8 ? ssn::regw_supported<double>(M, NB) : ssn::regw_supported<float>(M, NB);
+    const bool tile = dtype_bytes == 8 ? ssn::tile_supported<double>(M, NB) : ssn::tile_supported<float>(M, NB);
+    const bool regw = dtype_bytes == 8 ? ssn::regw_supported<double>(M, NB) : ssn::regw_supported<float>(M, NB);
+    return tile ? 2 : (regw ? 1 : 0);
 }
 
 int ssn_solve_batch_f32(const float* W, const float* ext, int ext_per_draw, float* r, float* r_prev, int* codes,
@@ -171,12 +178,12 @@ int ssn_solve_batch_f64(const double* W, const double* ext, int ext_per_draw, do
 int ssn_solve_batch_f32_variant(int variant, const float* W, const float* ext, int ext_per_draw, float* r,
                                 float* r_prev, int* codes, int* steps, int B, int NB, int M,
                                 const ssn_solver_params* p, void* stream) {
-    return solve_batch_impl<float>(variant ? 1 : 0, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
+    return solve_batch_impl<float>(variant, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
 }
 int ssn_solve_batch_f64_variant(int variant, const double* W, const double* ext, int ext_per_draw, double* r,
                                 double* r_prev, int* codes, int* steps, int B, int NB, int M,
                                 const ssn_solver_params* p, void* stream) {
-    return solve_batch_impl<double>(variant ? 1 : 0, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
+    return solve_batch_impl<double>(variant, W, ext, ext_per_draw, r, r_prev, codes, steps, B, NB, M, p, stream);
 }
 int ssn_solve_batch_host_f32(const float* W, const float* ext, int ext_per_draw, float* r, float* r_prev,
                              int* codes, int* steps, int B, int NB, int M, const ssn_solver_params* p) {

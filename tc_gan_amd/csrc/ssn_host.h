@@ -24,6 +24,10 @@ template <typename T> bool regw_supported(int M, int NB);
 template <typename T> hipError_t launch_regw(const SolveArgs<T>& a, hipStream_t st);
 template <typename T> hipError_t launch_stream(const SolveArgs<T>& a, hipStream_t st);
 
+// ssn_tile.hip
+template <typename T> bool tile_supported(int M, int NB);
+template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st);
+
 // ssn_aux.hip
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, T* ext, int B, int NB, int N, hipStream_t st);

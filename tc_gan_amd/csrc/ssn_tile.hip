@@ -1,0 +1,278 @@
+// "Tile" register-stationary SSN solver (variant 2) for MI355X (gfx950).
+//
+// Same contract as solve_regw_kernel (ssn_solver.hip) -- the Euler loop of
+// tc_gan/ext/ssnode.c:69-187 over B draws x NB stimuli -- with a different
+// mapping of W onto the register file, chosen from measurements on the chip
+// (tools/microbench): a v_fmac_f32 whose r operand is DPP-broadcast issues at
+// ~2/3 of the rate of a plain VGPR-operand v_fmac_f32, and with one matrix row
+// per lane a 200-neuron solve keeps only 200 of 256 lanes busy.
+//
+// Layout: a wave is an 8 x 8 grid of lanes, lane = 8*rg + cg.
+//   * row group rg owns RA consecutive rows:  row = (8*wave + rg)*RA + a
+//   * column group cg owns C consecutive columns:  col = cg*C + c
+//   * each lane holds the RA x C tile W[rows(rg)][cols(cg)] in VGPRs for the
+//     whole solve (W is read from HBM once);
+//   * per Euler step the lane reads ITS C values of r from LDS with 16-byte
+//     reads (the 8 lanes of a column group read the same address -> broadcast;
+//     slabs are padded so the 8 column groups hit disjoint banks) and issues
+//     RA*C plain FMAs: every loaded r value feeds RA FMAs;
+//   * the 8 partial sums of a row sit in 8 ADJACENT lanes and are combined by
+//     three DPP adds (quad_perm xor-1, xor-2, row_half_mirror);
+//   * lane cg < RA then finishes row a = cg: + ext, I/O nonlinearity, Euler
+//     update, stop tests, and writes r' back to LDS.  ONE barrier per step.
+// For 2N = 200: C = 25, RA = 7, 4 waves (224 row slots, 200 used; all 200
+// columns exact), 175 W registers per lane, two workgroups per CU.
+#include <hip/hip_runtime.h>
+#include "ssn_device.h"
+#include "ssn_host.h"
+
+namespace ssn {
+
+// x + (x from the lane selected by a DPP control); folds to v_add_f32_dpp.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    const float y = __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+    return x + y;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return x + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+// Sum over the 8 adjacent lanes {8k .. 8k+7}; every lane ends with the total.
+template <typename T>
+__device__ __forceinline__ T sum8(T x) {
+    x = dpp_add<0xB1>(x);    // quad_perm:[1,0,3,2]
+    x = dpp_add<0x4E>(x);    // quad_perm:[2,3,0,1]
+    x = dpp_add<0x141>(x);   // row_half_mirror
+    return x;
+}
+
+template <int C> struct SlabPad {
+    // floats per column-group slab in LDS: multiple of 4 (16-B reads) with an ODD number of
+    // 16-B units, so the 8 slabs start on distinct 4-bank groups (conflict-free ds_read_b128).
+    static constexpr int q = (C + 3) / 4;
+    static constexpr int value = 4 * ((q & 1) ? q : q + 1);
+};
+
+template <typename T, int RA, int C, int NB, int MAXTHREADS, int MINWAVES>
+__global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveArgs<T> a) {
+    constexpr int CP = SlabPad<C>::value;
+    constexpr int NQ = (C + 3) / 4;              // 16-B reads per lane per stimulus
+    static_assert(RA <= 8, "a row group has 8 lanes to finish its rows");
+    using V4 = T __attribute__((ext_vector_type(4)));
+    __shared__ __align__(16) T rbuf[2][NB][8 * CP];
+    __shared__ int flags[3][2][NB];
+
+    const int M = a.M, N = a.N;
+    const int ngroups = (a.NB + NB - 1) / NB;
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * NB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane & 7, rg = lane >> 3;
+    const int rowbase = (8 * wave + rg) * RA;
+    const int colbase = cg * C;
+
+    // ---- prologue: my RA x C tile of W -> registers ---------------------------------
+    T w[RA][C];
+    {
+        const T* Wb = a.W + (size_t)b * M * M;
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
+            const int row = rowbase + r;
+            const T* wrow = Wb + (size_t)(row < M ? row : M - 1) * M;
+            const T rmask = (row < M) ? (T)1 : (T)0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int col = colbase + c;
+                const T v = wrow[col < M ? col : M - 1];      // clamped address, masked value
+                w[r][c] = v * ((col < M) ? rmask : (T)0);
+            }
+        }
+    }
+    // the row this lane finishes each step (a = cg), its LDS slot, input and state
+    const int myrow = rowbase + cg;
+    const bool fin = (cg < RA) && (myrow < M);
+    const int myslot = (myrow / C) * CP + (myrow % C);
+    T rc[NB], rp[NB], ex[NB];
+    bool live[NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        live[s] = (s0 + s) < a.NB;
+        const size_t vec = ((size_t)b * a.NB + (live[s] ? s0 + s : 0)) * M;
+        rc[s] = (fin && live[s]) ? a.r[vec + myrow] : (T)0;
+        rp[s] = rc[s];
+        ex[s] = (fin && live[s]) ? a.ext[(a.ext_per_draw ? vec : (size_t)(s0 + s) * M) + myrow] : (T)0;
+    }
+    for (int c = threadIdx.x; c < 2 * NB * 8 * CP; c += blockDim.x) (&rbuf[0][0][0])[c] = (T)0;
+    if (threadIdx.x < 3 * 2 * NB) (&flags[0][0][0])[threadIdx.x] = 0;
+    __syncthreads();
+    if (fin) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) rbuf[0][s][myslot] = rc[s];
+    }
+    __syncthreads();
+
+    const T eps = (myrow < N) ? a.st.eps_E : a.st.eps_I;
+    int code[NB], nsteps[NB];
+    bool frozen[NB];
+#pragma unroll
+    for (int s = 0; s < NB; ++s) { code[s] = 1; nsteps[s] = a.st.max_iter; frozen[s] = !live[s]; }
+
+    int cur = 0;
+    for (int step = 0; step < a.st.max_iter; ++step) {
+        // ---- partial sums over my C columns for my RA rows ---------------------------
+        T acc[NB][RA];
+#pragma unroll
+        for (int s = 0; s < NB; ++s)
+#pragma unroll
+            for (int r = 0; r < RA; ++r) acc[s][r] = (T)0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            V4 rv[NB];
+#pragma unroll
+            for (int s = 0; s < NB; ++s) rv[s] = *reinterpret_cast<const V4*>(&rbuf[cur][s][cg * CP + 4 * q]);
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                const T rr[4] = {rv[s].x, rv[s].y, rv[s].z, rv[s].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * q + e < C) {
+#pragma unroll
+                        for (int r = 0; r < RA; ++r) acc[s][r] = fma(w[r][4 * q + e], rr[e], acc[s][r]);
+                    }
+                }
+            }
+        }
+        // ---- combine the 8 column groups; lane cg keeps row a = cg --------------------
+        T u[NB];
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            u[s] = (T)0;
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+                const T tot = sum8(acc[s][r]);
+                u[s] = (cg == r) ? tot : u[s];
+            }
+        }
+        // ---- Euler update + stop tests for my row -------------------------------------
+        const int slot = step % 3;
+        unsigned ncmask = 0, hbmask = 0;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const T r1 = rc[s] + (-rc[s] + io_eval(u[s] + ex[s], a.io)) * eps;
+            if (fin && !frozen[s]) {
+                if (abs_t(r1 - rc[s]) >= a.st.atol) ncmask |= 1u << s;
+                if (a.st.check_hard && r1 >= a.st.hard_stop) hbmask |= 1u << s;
+                rp[s] = rc[s];
+                rc[s] = r1;
+            }
+            if (fin) rbuf[cur ^ 1][s][myslot] = rc[s];
+        }
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const bool nc = __any((ncmask >> s) & 1u);
+            const bool hb = __any((hbmask >> s) & 1u);
+            if (lane == 0) {
+                if (nc) flags[slot][0][s] = 1;
+                if (hb) flags[slot][1][s] = 1;
+            }
+        }
+        if (threadIdx.x < 2 * NB) (&flags[(step + 1) % 3][0][0])[threadIdx.x] = 0;
+        __syncthreads();
+        cur ^= 1;
+
+        int nfrozen = 0;
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            if (!frozen[s]) {
+                const int any_nc = flags[slot][0][s], any_hb = flags[slot][1][s];
+                if (!any_nc) { code[s] = 0; nsteps[s] = step + 1; frozen[s] = true; }
+                else if (any_hb) { code[s] = 2; nsteps[s] = step + 1; frozen[s] = true; }
+            }
+            nfrozen += frozen[s];
+        }
+        if (nfrozen == NB) break;
+    }
+
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+        if (!live[s]) continue;
+        const size_t vec = ((size_t)b * a.NB + s0 + s) * M;
+        if (fin) {
+            a.r[vec + myrow] = rc[s];
+            if (a.r_prev) a.r_prev[vec + myrow] = rp[s];
+        }
+        if (threadIdx.x == 0) {
+            a.codes[(size_t)b * a.NB + s0 + s] = code[s];
+            if (a.steps) a.steps[(size_t)b * a.NB + s0 + s] = nsteps[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// dispatch: C = columns per column group (8*C >= M), RA = 7 rows per lane,
+// waves = ceil(M / 56) <= 4.
+// ---------------------------------------------------------------------------------
+static constexpr int TILE_RA = 7;
+
+static int tile_pick_c(int M, int elem_bytes) {
+    const int need = (M + 7) / 8;
+    const int ladder32[] = {4, 8, 13, 19, 25, 26};
+    const int ladder64[] = {4, 8, 13};                 // fp64: 2 VGPRs per value
+    if (elem_bytes == 4) { for (int c : ladder32) if (need <= c) return c; }
+    else                 { for (int c : ladder64) if (need <= c) return c; }
+    return 0;
+}
+
+template <typename T>
+bool tile_supported(int M, int NB) { (void)NB; return (M % 2 == 0) && tile_pick_c(M, (int)sizeof(T)) != 0; }
+template bool tile_supported<float>(int, int);
+template bool tile_supported<double>(int, int);
+
+template <typename T, int RA, int C, int NB, int MINW>
+static hipError_t launch_tile_k(const SolveArgs<T>& a, hipStream_t st) {
+    constexpr int MAXW = (8 * C + 8 * RA - 1) / (8 * RA);
+    const int waves = (a.M + 8 * RA - 1) / (8 * RA);
+    const int ngroups = (a.NB + NB - 1) / NB;
+    hipLaunchKernelGGL((solve_tile_kernel<T, RA, C, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
+                       dim3(64 * waves), 0, st, a);
+    return hipGetLastError();
+}
+
+template <typename T, int C>
+static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 4, 2>(a, st);
+        if (a.NB >= 2) return launch_tile_k<T, TILE_RA, C, 2, 2>(a, st);
+        return launch_tile_k<T, TILE_RA, C, 1, 2>(a, st);
+    } else {
+        return launch_tile_k<T, TILE_RA, C, 1, 1>(a, st);
+    }
+}
+
+template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st);
+template <> hipError_t launch_tile<float>(const SolveArgs<float>& a, hipStream_t st) {
+    switch (tile_pick_c(a.M, 4)) {
+        case 4: return launch_tile_nb<float, 4>(a, st);
+        case 8: return launch_tile_nb<float, 8>(a, st);
+        case 13: return launch_tile_nb<float, 13>(a, st);
+        case 19: return launch_tile_nb<float, 19>(a, st);
+        case 25: return launch_tile_nb<float, 25>(a, st);
+        case 26: return launch_tile_nb<float, 26>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <> hipError_t launch_tile<double>(const SolveArgs<double>& a, hipStream_t st) {
+    switch (tile_pick_c(a.M, 8)) {
+        case 4: return launch_tile_nb<double, 4>(a, st);
+        case 8: return launch_tile_nb<double, 8>(a, st);
+        case 13: return launch_tile_nb<double, 13>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ssn

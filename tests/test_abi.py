@@ -36,10 +36,11 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_fast_path_table():
     from tc_gan_amd.clib import libssnode
-    assert libssnode.ssn_solver_fast_path(200, 1, 4) == 1
-    assert libssnode.ssn_solver_fast_path(204, 8, 4) == 1
+    assert libssnode.ssn_solver_fast_path(200, 1, 4) == 2      # tile kernel
+    assert libssnode.ssn_solver_fast_path(204, 8, 4) == 2
     assert libssnode.ssn_solver_fast_path(402, 8, 4) == 0      # falls back to the streaming kernel
-    assert libssnode.ssn_solver_fast_path(100, 1, 8) == 1
+    assert libssnode.ssn_solver_fast_path(100, 1, 8) == 2
+    assert libssnode.ssn_solver_fast_path(112, 1, 8) == 1      # fp64: DPP kernel only
     assert libssnode.ssn_solver_fast_path(200, 1, 8) == 0
     assert libssnode.ssn_solver_fast_path(7, 1, 4) == 0         # odd M is invalid
 

@@ -126,6 +126,9 @@ def test_test_inf_message():
     (50, 1, 1, 'float32'), (50, 8, 1, 'float32'), (100, 1, 1, 'float32'), (100, 8, 1, 'float32'),
     (100, 3, 1, 'float32'), (16, 5, 1, 'float32'), (100, 2, 0, 'float32'),
     (50, 2, 1, 'float64'), (100, 1, 0, 'float64'), (23, 1, 1, 'float64'),
+    (50, 1, 2, 'float32'), (50, 8, 2, 'float32'), (100, 1, 2, 'float32'), (100, 8, 2, 'float32'),
+    (100, 3, 2, 'float32'), (102, 5, 2, 'float32'), (16, 5, 2, 'float32'), (1, 1, 2, 'float32'),
+    (75, 2, 2, 'float32'), (50, 2, 2, 'float64'), (23, 3, 2, 'float64'),
 ])
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
@@ -142,7 +145,8 @@ def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     np.testing.assert_allclose(res.x, want, rtol=rtol, atol=rtol * 1e-2)
 
 
-@pytest.mark.parametrize('dtype,variant', [('float64', 0), ('float64', 1), ('float32', 1), ('float32', 0)])
+@pytest.mark.parametrize('dtype,variant', [('float64', 0), ('float64', 1), ('float64', 2), ('float32', 1),
+                                           ('float32', 2), ('float32', 0)])
 def test_converging_batch_codes_steps_states(oracle_lib, dtype, variant):
     """Default solver settings (atol 1e-5, dt 8e-4): per-pair convergence step and state."""
     from tc_gan_amd.ssnode import fixed_points_batch
@@ -175,7 +179,7 @@ def test_blowup_codes_match_oracle(oracle_lib):
     exts = np.stack([g['ext_%d' % bad[0]['id']]])
     want, wcodes, wsteps = _oracle_batch(oracle_lib, Ws, exts, 'asym_power', 100000, 1e-5, dt=5e-4, hard=200.)
     assert set(wcodes.flat) >= {2}
-    for dtype, variant in (('float64', 1), ('float64', 0), ('float32', 1)):
+    for dtype, variant in (('float64', 1), ('float64', 0), ('float64', 2), ('float32', 1), ('float32', 2)):
         res = fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=100000, atol=1e-5, dt=5e-4,
                                  io_type='asym_power', rate_stop_at=200., dtype=dtype, variant=variant)
         np.testing.assert_array_equal(res.codes, wcodes)
@@ -200,6 +204,8 @@ def test_variants_agree_and_edge_shapes(oracle_lib):
     a = fixed_points_batch(Ws, extb, P['k'], P['n'], r0=r0, max_iter=100, atol=0.0, dtype='float64', variant=1)
     b = fixed_points_batch(Ws, extb, P['k'], P['n'], r0=r0, max_iter=100, atol=0.0, dtype='float64', variant=0)
     np.testing.assert_allclose(a.x, b.x, rtol=1e-11)
+    c = fixed_points_batch(Ws, extb, P['k'], P['n'], r0=r0, max_iter=100, atol=0.0, dtype='float64', variant=2)
+    np.testing.assert_allclose(a.x, c.x, rtol=1e-11)
     for bb in range(B):
         want, _, _ = _oracle_batch(oracle_lib, Ws[bb:bb + 1], extb[bb], 'asym_tanh', 100, 0.0, r0=r0[bb:bb + 1])
         np.testing.assert_allclose(a.x[bb:bb + 1], want, rtol=RTOL64)
