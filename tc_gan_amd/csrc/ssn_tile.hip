@@ -26,6 +26,12 @@
 #include "ssn_device.h"
 #include "ssn_host.h"
 
+// Diagnostic builds only (tools/microbench/tile_ablate.hip): bit mask of loop phases to stub out
+// so their cost can be measured.  The product library is always built with SSN_ABLATE == 0.
+#ifndef SSN_ABLATE
+#define SSN_ABLATE 0
+#endif
+
 namespace ssn {
 
 // x + (x from the lane selected by a DPP control); folds to v_add_f32_dpp.
@@ -49,6 +55,46 @@ __device__ __forceinline__ T sum8(T x) {
     x = dpp_add<0x4E>(x);    // quad_perm:[2,3,0,1]
     x = dpp_add<0x141>(x);   // row_half_mirror
     return x;
+}
+
+template <int CTRL, typename T>
+__device__ __forceinline__ T dpp_get(T x);
+template <int CTRL>
+__device__ __forceinline__ float dpp_get_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_get_f(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Transpose-reduce over the 8 adjacent lanes of a row group: in: 8 per-lane partial sums
+// acc[0..7] (row a of the group, this lane's columns); out: lane cg holds the TOTAL of row cg.
+// Each stage halves the rows a lane still carries (keep the half selected by one bit of cg, send
+// the other half to the partner that keeps it): 4+2+1 = 7 DPP adds and 14 selects, instead of
+// 3 DPP adds per row for all 8 rows.
+template <typename T>
+__device__ __forceinline__ T reduce8_to_lane(const T (&acc)[8], int cg) {
+    const bool bA = cg & 4, bB = cg & 2, bC = cg & 1;
+    T n4[4], n2[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T keep = bA ? acc[k + 4] : acc[k];
+        const T send = bA ? acc[k] : acc[k + 4];
+        n4[k] = keep + dpp_get_f<0x141>(send);          // row_half_mirror: lane i <-> 7-i
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const T keep = bB ? n4[k + 2] : n4[k];
+        const T send = bB ? n4[k] : n4[k + 2];
+        n2[k] = keep + dpp_get_f<0x4E>(send);           // quad_perm:[2,3,0,1]: lane i <-> i^2
+    }
+    const T keep = bC ? n2[1] : n2[0];
+    const T send = bC ? n2[0] : n2[1];
+    return keep + dpp_get_f<0xB1>(send);                // quad_perm:[1,0,3,2]: lane i <-> i^1
 }
 
 template <int C> struct SlabPad {
@@ -97,7 +143,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
     const int myslot = (myrow / C) * CP + (myrow % C);
-    T rc[NB], rp[NB], ex[NB];
+    T rc[NB], rp[NB], ex[NB];            // x_k, x_{k-1} of my row; input of my row
     bool live[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
@@ -122,19 +168,33 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
 #pragma unroll
     for (int s = 0; s < NB; ++s) { code[s] = 1; nsteps[s] = a.st.max_iter; frozen[s] = !live[s]; }
 
+    // Stop protocol (no vote, no second barrier, no exposed LDS latency): in iteration i every lane
+    // whose row fails the convergence test (or hits the rate bound) stores 1 to flags[i%3]; the
+    // verdict of iteration i is READ in iteration i+1 (the loads are issued before the FMA block and
+    // consumed after it, BEFORE that iteration's state update, so rc/rp still hold x_{i+1}/x_i) and
+    // slot (i+1)%3 is cleared for iteration i+1.  The FMAs of the extra iteration are discarded.
     int cur = 0;
-    for (int step = 0; step < a.st.max_iter; ++step) {
+    int step = 0;
+    for (; step < a.st.max_iter; ++step) {
+        int fnc[NB], fhb[NB];
+        if (!(SSN_ABLATE & 4) && step > 0) {
+#pragma unroll
+            for (int s = 0; s < NB; ++s) { fnc[s] = flags[(step + 2) % 3][0][s]; fhb[s] = flags[(step + 2) % 3][1][s]; }
+        }
         // ---- partial sums over my C columns for my RA rows ---------------------------
-        T acc[NB][RA];
+        T acc[NB][8];
 #pragma unroll
         for (int s = 0; s < NB; ++s)
 #pragma unroll
-            for (int r = 0; r < RA; ++r) acc[s][r] = (T)0;
+            for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             V4 rv[NB];
 #pragma unroll
-            for (int s = 0; s < NB; ++s) rv[s] = *reinterpret_cast<const V4*>(&rbuf[cur][s][cg * CP + 4 * q]);
+            for (int s = 0; s < NB; ++s) {
+                if constexpr (SSN_ABLATE & 8) { rv[s].x = rc[s]; rv[s].y = rc[s] + 1; rv[s].z = rc[s] + 2; rv[s].w = rc[s] + 3; }
+                else rv[s] = *reinterpret_cast<const V4*>(&rbuf[cur][s][cg * CP + 4 * q]);
+            }
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 const T rr[4] = {rv[s].x, rv[s].y, rv[s].z, rv[s].w};
@@ -147,55 +207,52 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
                 }
             }
         }
-        // ---- combine the 8 column groups; lane cg keeps row a = cg --------------------
-        T u[NB];
+        // ---- verdict of the previous iteration (uniform over the workgroup) -----------
+        if (!(SSN_ABLATE & 4) && step > 0) {
+            int nfrozen = 0;
 #pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            u[s] = (T)0;
-#pragma unroll
-            for (int r = 0; r < RA; ++r) {
-                const T tot = sum8(acc[s][r]);
-                u[s] = (cg == r) ? tot : u[s];
+            for (int s = 0; s < NB; ++s) {
+                if (!frozen[s] && (!fnc[s] || fhb[s])) {
+                    code[s] = fnc[s] ? 2 : 0;
+                    nsteps[s] = step;                 // it stopped in iteration step-1
+                    frozen[s] = true;
+                }
+                nfrozen += frozen[s];
             }
+            if (nfrozen == NB) break;
         }
-        // ---- Euler update + stop tests for my row -------------------------------------
+        // ---- combine the 8 column groups; lane cg ends with the total of row a = cg ----
         const int slot = step % 3;
-        unsigned ncmask = 0, hbmask = 0;
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
-            const T r1 = rc[s] + (-rc[s] + io_eval(u[s] + ex[s], a.io)) * eps;
+            const T u = (SSN_ABLATE & 2) ? acc[s][0] : reduce8_to_lane(acc[s], cg);
+            // ---- Euler update + stop tests for my row ---------------------------------
+            const T fu = (SSN_ABLATE & 1) ? (u + ex[s]) : io_eval(u + ex[s], a.io);
+            const T r1 = rc[s] + (-rc[s] + fu) * eps;
             if (fin && !frozen[s]) {
-                if (abs_t(r1 - rc[s]) >= a.st.atol) ncmask |= 1u << s;
-                if (a.st.check_hard && r1 >= a.st.hard_stop) hbmask |= 1u << s;
+                if (!(SSN_ABLATE & 4)) {
+                    if (abs_t(r1 - rc[s]) >= a.st.atol) flags[slot][0][s] = 1;
+                    if (a.st.check_hard && r1 >= a.st.hard_stop) flags[slot][1][s] = 1;
+                }
                 rp[s] = rc[s];
                 rc[s] = r1;
             }
             if (fin) rbuf[cur ^ 1][s][myslot] = rc[s];
         }
-#pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            const bool nc = __any((ncmask >> s) & 1u);
-            const bool hb = __any((hbmask >> s) & 1u);
-            if (lane == 0) {
-                if (nc) flags[slot][0][s] = 1;
-                if (hb) flags[slot][1][s] = 1;
-            }
-        }
-        if (threadIdx.x < 2 * NB) (&flags[(step + 1) % 3][0][0])[threadIdx.x] = 0;
-        __syncthreads();
+        if (!(SSN_ABLATE & 4) && threadIdx.x < 2 * NB) (&flags[(step + 1) % 3][0][0])[threadIdx.x] = 0;
+        if constexpr (!(SSN_ABLATE & 16)) __syncthreads();
         cur ^= 1;
-
-        int nfrozen = 0;
+    }
+    // verdict of the last executed iteration (no extra step was taken, so no roll-back)
+    if (!(SSN_ABLATE & 4) && step == a.st.max_iter && step > 0) {
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
             if (!frozen[s]) {
-                const int any_nc = flags[slot][0][s], any_hb = flags[slot][1][s];
-                if (!any_nc) { code[s] = 0; nsteps[s] = step + 1; frozen[s] = true; }
-                else if (any_hb) { code[s] = 2; nsteps[s] = step + 1; frozen[s] = true; }
+                const int nc = flags[(step + 2) % 3][0][s], hb = flags[(step + 2) % 3][1][s];
+                if (!nc) { code[s] = 0; nsteps[s] = step; }
+                else if (hb) { code[s] = 2; nsteps[s] = step; }
             }
-            nfrozen += frozen[s];
         }
-        if (nfrozen == NB) break;
     }
 
 #pragma unroll
@@ -246,7 +303,8 @@ static hipError_t launch_tile_k(const SolveArgs<T>& a, hipStream_t st) {
 template <typename T, int C>
 static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st) {
     if constexpr (sizeof(T) == 4) {
-        if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 4, 2>(a, st);
+        // 7*C W registers + 8*NB accumulators + 4*NB states must stay under 256 VGPRs (no spills)
+        if constexpr (C <= 19) { if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 4, 2>(a, st); }
         if (a.NB >= 2) return launch_tile_k<T, TILE_RA, C, 2, 2>(a, st);
         return launch_tile_k<T, TILE_RA, C, 1, 2>(a, st);
     } else {
