@@ -1,12 +1,14 @@
 // Diagnostic: time solve_tile_kernel<float,7,25,1> at the C2 shape with loop phases stubbed out
 // (SSN_ABLATE bit mask: 1 nonlinearity, 2 DPP reduction, 4 stop flags, 8 LDS r reads, 16 barrier).
+// argv[1] = number of weight draws (256 = one workgroup per CU, 512 = two per CU).
 // Results are WRONG by construction; only the timing matters.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSSN_ABLATE=<mask> -o tile_ablate_<mask> tile_ablate.hip
 #include "../../tc_gan_amd/csrc/ssn_tile.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
-int main() {
-    const int B = 4096, M = 200, NB = 1, T = 2000;
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 4096, M = 200, NB = 1, T = 2000;
     std::vector<float> hW((size_t)B * M * M), hext(M, 1.0f);
     for (size_t i = 0; i < hW.size(); ++i) hW[i] = (((i * 2654435761u) % 1000) / 1000.f - 0.6f) * 0.01f;
     float *W, *ext, *r; int *codes, *steps;
@@ -27,6 +29,6 @@ int main() {
         hipEventRecord(e0); ssn::launch_tile<float>(a, nullptr); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
-    printf("SSN_ABLATE=%2d  %.3f ms  cycles/pair-step@2.4GHz=%.0f\n", SSN_ABLATE, best, best * 1e-3 * 2.4e9 / T / 8);
+    printf("SSN_ABLATE=%2d B=%d  %.3f ms  cycles per step per round(of 512 WGs)@2.4GHz=%.0f\n", SSN_ABLATE, B, best, best * 1e-3 * 2.4e9 / T / ((B + 511) / 512));
     return 0;
 }
