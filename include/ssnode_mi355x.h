@@ -152,6 +152,60 @@ int ssn_stimulus_f32(const float *bandwidths, const float *contrasts, float smoo
 int ssn_stimulus_f64(const double *bandwidths, const double *contrasts, double smoothness,
                      double *ext, int B, int NB, int N, void *stream);
 
+/* ------------------------------------------------------------------------
+ * 3. Fixed-time generator (BPTT path): replaces the compiled Theano graphs of
+ *    tc_gan/networks/ssn.py (EulerSSNCore.get_output_for 555-576, EulerSSNModel
+ *    598-633) and the reverse scan that theano.grad builds for
+ *    GeneratorTrainer (networks/wgan.py:218-260).
+ * ------------------------------------------------------------------------ */
+typedef struct ssn_gen_params {
+    int io_type;                 /* SSN_IO_* */
+    int seqlen;                  /* T: Euler steps from r = 0 */
+    int skip_steps;              /* first output index of the measurement window */
+    int reserved;
+    double k, n;
+    double tau_E, tau_I, dt;     /* eps = dt / tau per neuron */
+    double rate_soft_bound, rate_hard_bound;
+    double rate_penalty_threshold;
+} ssn_gen_params;
+
+/* 1 if the register-stationary generator kernels cover this size (2N <= 208 fp32, <= 104 fp64). */
+int ssn_gen_supported(int M, int dtype_bytes);
+
+/*
+ * Forward: r_{t+1} = (1-eps) r_t + eps f(W r_t + ext), r_0 = 0, T = seqlen steps.
+ *   W        device [B][M][M];  ext device [B][NB][M]
+ *   time_avg device [B][NB][M]  mean over output indices >= skip_steps
+ *   dyn_row  device [B][NB][M]  per-neuron SUM over the window of (x_{t+1}-x_t)^2
+ *   rate_row device [B][NB][M]  per-neuron SUM over the window of relu(x_t - threshold)
+ *            (dynamics_penalty = sum(dyn_row)/(B*(T-skip-1)*NB*M), rate_penalty =
+ *             sum(rate_row)/(B*(T-skip)*NB*M): the means of ssn.py:626,632)
+ *   traj, df device [B][NB][T][M] or both NULL: trajectory and f'(u_t) kept for the backward
+ */
+int ssn_gen_forward_f32(const float *W, const float *ext, float *time_avg, float *dyn_row, float *rate_row,
+                        float *traj, float *df, int B, int NB, int M, const ssn_gen_params *p, void *stream);
+int ssn_gen_forward_f64(const double *W, const double *ext, double *time_avg, double *dyn_row, double *rate_row,
+                        double *traj, double *df, int B, int NB, int M, const ssn_gen_params *p, void *stream);
+/*
+ * Backward (adjoint sweep).  g_time_avg = dL/d time_avg [B][NB][M]; c_dyn, c_rate = the
+ * coefficients multiplying sum(dyn_row) and sum(rate_row) in L.  `df_delta` holds the
+ * forward's df on entry and delta on exit, shifted so that
+ *     dL/dW[b] = df_delta[b].reshape(NB*T, M)^T @ traj[b].reshape(NB*T, M).
+ */
+int ssn_gen_backward_f32(const float *W, const float *traj, float *df_delta, const float *g_time_avg,
+                         double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
+int ssn_gen_backward_f64(const double *W, const double *traj, double *df_delta, const double *g_time_avg,
+                         double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
+/*
+ * Chain rule W -> (J, D, S) of make_W_with_x (make_w_batch.py:19-34): out[b][pq][0..2] =
+ * partial dL/dJ_pq, dL/dD_pq, dL/dS_pq of draw b (device fp64 [B][4][3]; sum over b on the caller's
+ * side in a fixed order).  J, D, S are HOST arrays of 4.
+ */
+int ssn_jds_grad_f32(const float *gW, const float *z, const float *J, const float *D, const float *S,
+                     double *out, int B, int N, void *stream);
+int ssn_jds_grad_f64(const double *gW, const double *z, const double *J, const double *D, const double *S,
+                     double *out, int B, int N, void *stream);
+
 /* I/O nonlinearity on arrays (device pointers), the device function the solver
  * kernels use: out[i] = io(v[i]).  p->k, n, rate_soft_bound, rate_hard_bound,
  * io_type are read; for SSN_IO_* semantics see ssnode.c:25-53. */

@@ -110,6 +110,33 @@ for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_sti
               'ssn_io_eval_f32', 'ssn_io_eval_f64'):
     getattr(libssnode, _name).restype = c_int
 
+class GenParams(Structure):
+    """``ssn_gen_params`` of include/ssnode_mi355x.h."""
+    _fields_ = [
+        ('io_type', c_int), ('seqlen', c_int), ('skip_steps', c_int), ('reserved', c_int),
+        ('k', c_double), ('n', c_double),
+        ('tau_E', c_double), ('tau_I', c_double), ('dt', c_double),
+        ('rate_soft_bound', c_double), ('rate_hard_bound', c_double),
+        ('rate_penalty_threshold', c_double),
+    ]
+
+
+_gp = POINTER(GenParams)
+libssnode.ssn_gen_supported.argtypes = [c_int, c_int]
+libssnode.ssn_gen_supported.restype = c_int
+for _name in ('ssn_gen_forward_f32', 'ssn_gen_forward_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p] * 7 + [c_int, c_int, c_int, _gp, c_void_p]
+    getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_gen_backward_f32', 'ssn_gen_backward_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p] * 4 + [c_double, c_double, c_int, c_int, c_int, _gp, c_void_p]
+    getattr(libssnode, _name).restype = c_int
+libssnode.ssn_jds_grad_f32.argtypes = [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float),
+                                       c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_jds_grad_f64.argtypes = [c_void_p, c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double),
+                                       c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_jds_grad_f32.restype = c_int
+libssnode.ssn_jds_grad_f64.restype = c_int
+
 #: every symbol include/ssnode_mi355x.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = (
     'solve_dynamics_asym_power_euler', 'solve_dynamics_asym_linear_euler', 'solve_dynamics_asym_tanh_euler',
@@ -119,6 +146,8 @@ DECLARED_SYMBOLS = (
     'ssn_solve_batch_host_f32', 'ssn_solve_batch_host_f64',
     'ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
     'ssn_io_eval_f32', 'ssn_io_eval_f64',
+    'ssn_gen_supported', 'ssn_gen_forward_f32', 'ssn_gen_forward_f64',
+    'ssn_gen_backward_f32', 'ssn_gen_backward_f64', 'ssn_jds_grad_f32', 'ssn_jds_grad_f64',
 )
 
 

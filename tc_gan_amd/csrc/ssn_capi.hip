@@ -145,9 +145,89 @@ double legacy_io(int io_type, double v, double r0, double r1, double v0, double 
     return out;
 }
 
+template <typename T>
+ssn::IoConsts<T> gen_io_consts(const ssn_gen_params& g) {
+    ssn_solver_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.io_type = g.io_type; p.k = g.k; p.n = g.n; p.rate_soft_bound = g.rate_soft_bound; p.rate_hard_bound = g.rate_hard_bound;
+    return ssn::make_io_consts<T>(p);
+}
+
+template <typename T>
+int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_row, T* traj, T* df, int B, int NB,
+                     int M, const ssn_gen_params* g, void* stream) {
+    if (B == 0 || NB == 0) return 0;
+    if (!g || !W || !ext || !time_avg || !dyn_row || !rate_row || (traj == nullptr) != (df == nullptr) || M <= 0 ||
+        (M & 1) || g->seqlen < 1 || g->skip_steps < 0 || g->skip_steps >= g->seqlen || g->io_type < 0 || g->io_type > 2 ||
+        !ssn::gen_supported<T>(M)) {
+        g_last_error = "ssn_gen_forward: invalid argument or unsupported size";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::GenFwdArgs<T> a;
+    a.W = W; a.ext = ext; a.time_avg = time_avg; a.dyn_row = dyn_row; a.rate_row = rate_row; a.traj = traj; a.df = df;
+    a.B = B; a.NB = NB; a.M = M; a.seqlen = g->seqlen; a.skip = g->skip_steps;
+    a.eps_E = (T)(g->dt / g->tau_E); a.eps_I = (T)(g->dt / g->tau_I); a.theta = (T)g->rate_penalty_threshold;
+    a.io = gen_io_consts<T>(*g);
+    SSN_TRY(ssn::launch_gen_forward<T>(a, (hipStream_t)stream));
+    return 0;
+}
+
+template <typename T>
+int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, double c_dyn, double c_rate, int B, int NB,
+                      int M, const ssn_gen_params* g, void* stream) {
+    if (B == 0 || NB == 0) return 0;
+    if (!g || !W || !traj || !delta || !gta || M <= 0 || (M & 1) || g->seqlen < 1 || g->skip_steps < 0 ||
+        g->skip_steps >= g->seqlen || !ssn::gen_supported<T>(M)) {
+        g_last_error = "ssn_gen_backward: invalid argument or unsupported size";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::GenBwdArgs<T> a;
+    a.W = W; a.traj = traj; a.delta = delta; a.g_time_avg = gta;
+    a.B = B; a.NB = NB; a.M = M; a.seqlen = g->seqlen; a.skip = g->skip_steps;
+    a.eps_E = (T)(g->dt / g->tau_E); a.eps_I = (T)(g->dt / g->tau_I); a.theta = (T)g->rate_penalty_threshold;
+    a.c_dyn = (T)c_dyn; a.c_rate = (T)c_rate;
+    SSN_TRY(ssn::launch_gen_backward<T>(a, (hipStream_t)stream));
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int ssn_gen_supported(int M, int dtype_bytes) {
+    if (M <= 0 || (M & 1)) return 0;
+    return dtype_bytes == 8 ? ssn::gen_supported<double>(M) : ssn::gen_supported<float>(M);
+}
+int ssn_gen_forward_f32(const float* W, const float* ext, float* time_avg, float* dyn_row, float* rate_row, float* traj,
+                        float* df, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
+    return gen_forward_impl<float>(W, ext, time_avg, dyn_row, rate_row, traj, df, B, NB, M, p, stream);
+}
+int ssn_gen_forward_f64(const double* W, const double* ext, double* time_avg, double* dyn_row, double* rate_row,
+                        double* traj, double* df, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
+    return gen_forward_impl<double>(W, ext, time_avg, dyn_row, rate_row, traj, df, B, NB, M, p, stream);
+}
+int ssn_gen_backward_f32(const float* W, const float* traj, float* df_delta, const float* g_time_avg, double c_dyn,
+                         double c_rate, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
+    return gen_backward_impl<float>(W, traj, df_delta, g_time_avg, c_dyn, c_rate, B, NB, M, p, stream);
+}
+int ssn_gen_backward_f64(const double* W, const double* traj, double* df_delta, const double* g_time_avg, double c_dyn,
+                         double c_rate, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
+    return gen_backward_impl<double>(W, traj, df_delta, g_time_avg, c_dyn, c_rate, B, NB, M, p, stream);
+}
+int ssn_jds_grad_f32(const float* gW, const float* z, const float* J, const float* D, const float* S, double* out,
+                     int B, int N, void* stream) {
+    float jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_jds_grad<float>(gW, z, jds, out, B, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_jds_grad_f64(const double* gW, const double* z, const double* J, const double* D, const double* S, double* out,
+                     int B, int N, void* stream) {
+    double jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_jds_grad<double>(gW, z, jds, out, B, N, (hipStream_t)stream));
+    return 0;
+}
 
 int ssn_abi_version(void) { return 1; }
 

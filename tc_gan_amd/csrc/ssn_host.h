@@ -19,6 +19,33 @@ struct SolveArgs {
     StepConsts<T> st;
 };
 
+// Fixed-time generator forward (ssn_gen.hip)
+template <typename T>
+struct GenFwdArgs {
+    const T* W;       // [B][M][M]
+    const T* ext;     // [B][NB][M]
+    T* time_avg;      // [B][NB][M]
+    T* dyn_row;       // [B][NB][M]  sum over the window of (x_{t+1}-x_t)^2 per neuron
+    T* rate_row;      // [B][NB][M]  sum over the window of relu(x_t - theta) per neuron
+    T* traj;          // [B][NB][T][M] or nullptr: x_t, index t-1
+    T* df;            // [B][NB][T][M] or nullptr: f'(u_t), index t-1
+    int B, NB, M, seqlen, skip;
+    T eps_E, eps_I, theta;
+    IoConsts<T> io;
+};
+// BPTT adjoint sweep (ssn_gen.hip)
+template <typename T>
+struct GenBwdArgs {
+    const T* W;            // [B][M][M]
+    const T* traj;         // [B][NB][T][M]
+    T* delta;              // in: f'(u_t) (the forward's df); out: delta_t at index t-2, slot T-1 zero
+    const T* g_time_avg;   // [B][NB][M]  dL/d time_avg
+    int B, NB, M, seqlen, skip;
+    T eps_E, eps_I, theta, c_dyn, c_rate;
+};
+template <typename T>
+struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };
+
 // ssn_solver.hip
 template <typename T> bool regw_supported(int M, int NB);
 template <typename T> hipError_t launch_regw(const SolveArgs<T>& a, hipStream_t st);
@@ -27,6 +54,12 @@ template <typename T> hipError_t launch_stream(const SolveArgs<T>& a, hipStream_
 // ssn_tile.hip
 template <typename T> bool tile_supported(int M, int NB);
 template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st);
+
+// ssn_gen.hip
+template <typename T> bool gen_supported(int M);
+template <typename T> hipError_t launch_gen_forward(const GenFwdArgs<T>& a, hipStream_t st);
+template <typename T> hipError_t launch_gen_backward(const GenBwdArgs<T>& a, hipStream_t st);
+template <typename T> hipError_t launch_jds_grad(const T* gW, const T* z, const T* jds12, double* out, int B, int N, hipStream_t st);
 
 // ssn_aux.hip
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);

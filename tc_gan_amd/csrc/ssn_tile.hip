@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include "ssn_device.h"
 #include "ssn_host.h"
+#include "ssn_tile_core.h"
 
 // Diagnostic builds only (tools/microbench/tile_ablate.hip): bit mask of loop phases to stub out
 // so their cost can be measured.  The product library is always built with SSN_ABLATE == 0.
@@ -33,76 +34,6 @@
 #endif
 
 namespace ssn {
-
-// x + (x from the lane selected by a DPP control); folds to v_add_f32_dpp.
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float x) {
-    const float y = __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-    return x + y;
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_add(double x) {
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return x + __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-// Sum over the 8 adjacent lanes {8k .. 8k+7}; every lane ends with the total.
-template <typename T>
-__device__ __forceinline__ T sum8(T x) {
-    x = dpp_add<0xB1>(x);    // quad_perm:[1,0,3,2]
-    x = dpp_add<0x4E>(x);    // quad_perm:[2,3,0,1]
-    x = dpp_add<0x141>(x);   // row_half_mirror
-    return x;
-}
-
-template <int CTRL, typename T>
-__device__ __forceinline__ T dpp_get(T x);
-template <int CTRL>
-__device__ __forceinline__ float dpp_get_f(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_get_f(double x) {
-    const long long b = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Transpose-reduce over the 8 adjacent lanes of a row group: in: 8 per-lane partial sums
-// acc[0..7] (row a of the group, this lane's columns); out: lane cg holds the TOTAL of row cg.
-// Each stage halves the rows a lane still carries (keep the half selected by one bit of cg, send
-// the other half to the partner that keeps it): 4+2+1 = 7 DPP adds and 14 selects, instead of
-// 3 DPP adds per row for all 8 rows.
-template <typename T>
-__device__ __forceinline__ T reduce8_to_lane(const T (&acc)[8], int cg) {
-    const bool bA = cg & 4, bB = cg & 2, bC = cg & 1;
-    T n4[4], n2[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const T keep = bA ? acc[k + 4] : acc[k];
-        const T send = bA ? acc[k] : acc[k + 4];
-        n4[k] = keep + dpp_get_f<0x141>(send);          // row_half_mirror: lane i <-> 7-i
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const T keep = bB ? n4[k + 2] : n4[k];
-        const T send = bB ? n4[k] : n4[k + 2];
-        n2[k] = keep + dpp_get_f<0x4E>(send);           // quad_perm:[2,3,0,1]: lane i <-> i^2
-    }
-    const T keep = bC ? n2[1] : n2[0];
-    const T send = bC ? n2[0] : n2[1];
-    return keep + dpp_get_f<0xB1>(send);                // quad_perm:[1,0,3,2]: lane i <-> i^1
-}
-
-template <int C> struct SlabPad {
-    // floats per column-group slab in LDS: multiple of 4 (16-B reads) with an ODD number of
-    // 16-B units, so the 8 slabs start on distinct 4-bank groups (conflict-free ds_read_b128).
-    static constexpr int q = (C + 3) / 4;
-    static constexpr int value = 4 * ((q & 1) ? q : q + 1);
-};
 
 template <typename T, int RA, int C, int NB, int MAXTHREADS, int MINWAVES>
 __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveArgs<T> a) {

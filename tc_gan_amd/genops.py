@@ -1,0 +1,97 @@
+"""Thin Python wrappers over the fixed-time generator kernels (include/ssnode_mi355x.h section 3).
+
+Everything here takes and returns torch CUDA tensors; the arithmetic is in
+``csrc/ssn_gen.hip`` (forward + BPTT adjoint) and one plain batched GEMM
+(``torch.bmm`` -> rocBLAS) for dL/dW = delta^T . traj.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import clib
+from .clib import libssnode
+
+_DT = {torch.float32: ('f32', ctypes.c_float), torch.float64: ('f64', ctypes.c_double)}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_gen_params(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=0.1, seqlen=1200,
+                    skip_steps=1000, rate_soft_bound=200., rate_hard_bound=1000.,
+                    rate_penalty_threshold=200.):
+    """Defaults: networks/wgan.py:39-63 (tau_E=10, tau_I=1, dt=0.1, seqlen=1200, skip_steps=1000)."""
+    return clib.GenParams(io_type=clib.IO_CODES[io_type], seqlen=int(seqlen), skip_steps=int(skip_steps),
+                          reserved=0, k=float(k), n=float(n), tau_E=float(tau_E), tau_I=float(tau_I),
+                          dt=float(dt), rate_soft_bound=float(rate_soft_bound),
+                          rate_hard_bound=float(rate_hard_bound),
+                          rate_penalty_threshold=float(rate_penalty_threshold))
+
+
+def gen_forward(W, ext, gp, save=False):
+    """W (B, M, M), ext (B, NB, M) CUDA tensors -> dict(time_avg, dynamics_penalty, rate_penalty[, traj, df]).
+
+    dynamics_penalty / rate_penalty are the means of networks/ssn.py:626,632 (0-dim tensors)."""
+    clib.require_gpu()
+    assert W.is_cuda and ext.is_cuda and W.dtype == ext.dtype and W.dtype in _DT
+    W = W.contiguous(); ext = ext.contiguous()
+    B, NB, M = ext.shape
+    assert W.shape == (B, M, M)
+    T, skip = gp.seqlen, gp.skip_steps
+    suffix, _ = _DT[W.dtype]
+    ta = torch.empty_like(ext); dyn = torch.empty_like(ext); rate = torch.empty_like(ext)
+    traj = df = None
+    if save:
+        traj = torch.empty((B, NB, T, M), device=W.device, dtype=W.dtype)
+        df = torch.empty_like(traj)
+    rc = getattr(libssnode, 'ssn_gen_forward_' + suffix)(
+        W.data_ptr(), ext.data_ptr(), ta.data_ptr(), dyn.data_ptr(), rate.data_ptr(),
+        traj.data_ptr() if save else None, df.data_ptr() if save else None,
+        B, NB, M, ctypes.byref(gp), _stream())
+    clib.check(rc, 'ssn_gen_forward_' + suffix)
+    n_dyn = B * (T - skip - 1) * NB * M
+    n_rate = B * (T - skip) * NB * M
+    out = dict(time_avg=ta,
+               dynamics_penalty=(dyn.sum(dtype=torch.float64) / n_dyn) if n_dyn > 0 else dyn.sum() * float('nan'),
+               rate_penalty=rate.sum(dtype=torch.float64) / n_rate,
+               n_dyn=n_dyn, n_rate=n_rate)
+    if save:
+        out.update(traj=traj, df=df)
+    return out
+
+
+def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp):
+    """Adjoint sweep; `df` is overwritten by the shifted delta and returned.
+    c_dyn / c_rate multiply SUM(dyn_row) / SUM(rate_row) in the loss."""
+    clib.require_gpu()
+    B, NB, T, M = traj.shape
+    suffix, _ = _DT[W.dtype]
+    g_time_avg = g_time_avg.to(W.dtype).contiguous()
+    rc = getattr(libssnode, 'ssn_gen_backward_' + suffix)(
+        W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(), float(c_dyn), float(c_rate),
+        B, NB, M, ctypes.byref(gp), _stream())
+    clib.check(rc, 'ssn_gen_backward_' + suffix)
+    return df
+
+
+def weight_grad(delta, traj):
+    """dL/dW[b] = delta[b]^T . traj[b] over K = NB*T (one plain batched GEMM, rocBLAS)."""
+    B, NB, T, M = traj.shape
+    return torch.bmm(delta.reshape(B, NB * T, M).transpose(1, 2), traj.reshape(B, NB * T, M))
+
+
+def jds_grad(gW, z, J, D, S):
+    """Chain rule through make_W_with_x: returns (gJ, gD, gS) as float64 numpy (2, 2) arrays."""
+    clib.require_gpu()
+    B, M, _ = gW.shape
+    N = M // 2
+    suffix, ct = _DT[gW.dtype]
+    arrs = [(ct * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (J, D, S)]
+    out = torch.empty((B, 4, 3), device=gW.device, dtype=torch.float64)
+    rc = getattr(libssnode, 'ssn_jds_grad_' + suffix)(gW.contiguous().data_ptr(), z.contiguous().data_ptr(),
+                                                      arrs[0], arrs[1], arrs[2], out.data_ptr(), B, N, _stream())
+    clib.check(rc, 'ssn_jds_grad_' + suffix)
+    tot = out.sum(dim=0).cpu().numpy()           # (4, 3), fixed summation order
+    return tot[:, 0].reshape(2, 2), tot[:, 1].reshape(2, 2), tot[:, 2].reshape(2, 2)

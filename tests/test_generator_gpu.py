@@ -1,0 +1,80 @@
+"""GPU parity of the fixed-time generator (forward reductions, BPTT adjoint, J/D/S gradients)
+against the fp64 torch restatement oracle/gan_torch.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_torch as og
+from oracle import ssn_numpy as on
+
+pytestmark = pytest.mark.gpu
+P = on.DEFAULT_PARAMS
+GEN = dict(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=0.1)
+
+
+def _problem(N, B, NB, seed, T, skip, theta):
+    rs = np.random.RandomState(seed)
+    jds = on.new_JDS()
+    z = rs.rand(B, 2 * N, 2 * N)
+    bws = np.tile(np.asarray(P['bandwidths'])[None, :NB], (B, 1))
+    con = np.tile(rs.choice([5., 20.], size=(B, 1)), (1, NB))
+    return jds, z, bws, con
+
+
+@pytest.mark.parametrize('io_type', ['asym_tanh', 'asym_power', 'asym_linear'])
+@pytest.mark.parametrize('N,B,NB,dtype', [(10, 3, 8, 'float64'), (50, 2, 4, 'float32'), (100, 2, 3, 'float32'),
+                                           (102, 2, 1, 'float32'), (26, 3, 5, 'float64')])
+def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype):
+    from tc_gan_amd import genops, stimuli, weight_gen
+    T, skip, theta = 60, 40, 2.0
+    jds, z, bws, con = _problem(N, B, NB, N + NB, T, skip, theta)
+    gen = dict(GEN, io_type=io_type)
+    ext_o = og.stimulus(bws, con, P['smoothness'], N)
+    W_o = og.make_W(og.t64(z), *(og.t64(jds[k]) for k in 'JDS'), N)
+    ta_o, dyn_o, rate_o, traj_o = og.euler_ssn(W_o, ext_o, seqlen=T, skip_steps=skip, rate_penalty_threshold=theta,
+                                                return_trajectory=True, **gen)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype=dtype)
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype=dtype)
+    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, **gen)
+    out = genops.gen_forward(W, ext, gp, save=True)
+    rtol = 1e-4 if dtype == 'float32' else 1e-9
+    np.testing.assert_allclose(out['time_avg'].cpu().numpy(), ta_o.numpy(), rtol=rtol, atol=rtol * 1e-2)
+    np.testing.assert_allclose(float(out['dynamics_penalty']), float(dyn_o), rtol=10 * rtol)
+    np.testing.assert_allclose(float(out['rate_penalty']), float(rate_o), rtol=10 * rtol, atol=1e-12)
+    # trajectory layout [B][NB][T][M] vs oracle (B, T, NB, M)
+    np.testing.assert_allclose(out['traj'].cpu().numpy(), traj_o.permute(0, 2, 1, 3).numpy(), rtol=rtol, atol=rtol * 1e-2)
+
+
+@pytest.mark.parametrize('io_type', ['asym_tanh', 'asym_power'])
+@pytest.mark.parametrize('N,B,NB,dtype', [(6, 3, 3, 'float64'), (20, 2, 8, 'float64'), (50, 2, 2, 'float32'),
+                                           (100, 2, 2, 'float32')])
+def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype):
+    """dL/dJ, dL/dD, dL/dS for L = sum(G * time_avg) + c_d * dyn_pen + c_r * rate_pen."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    T, skip, theta = 50, 30, 1.0
+    jds, z, bws, con = _problem(N, B, NB, 7 * N + NB, T, skip, theta)
+    gen = dict(GEN, io_type=io_type)
+    rs = np.random.RandomState(5)
+    G = rs.randn(B, NB, 2 * N) * (rs.rand(B, NB, 2 * N) < 0.1)       # sparse, like a probe gather
+    dyn_cost, rate_cost = 1.0, 0.01
+    # oracle
+    J, D, S = (og.t64(jds[k]).clone().requires_grad_(True) for k in 'JDS')
+    ext_o = og.stimulus(bws, con, P['smoothness'], N)
+    W_o = og.make_W(og.t64(z), J, D, S, N)
+    ta_o, dyn_o, rate_o = og.euler_ssn(W_o, ext_o, seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, **gen)
+    loss = (og.t64(G) * ta_o).sum() + dyn_cost * dyn_o + rate_cost * rate_o
+    gJ_o, gD_o, gS_o = torch.autograd.grad(loss, [J, D, S])
+    # device
+    zt = torch.as_tensor(z).to('cuda', getattr(torch, dtype))
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], zt, dtype=dtype)
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype=dtype)
+    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, **gen)
+    out = genops.gen_forward(W, ext, gp, save=True)
+    Gd = torch.as_tensor(G).to('cuda', getattr(torch, dtype))
+    delta = genops.gen_backward(W, out['traj'], out['df'], Gd, dyn_cost / out['n_dyn'], rate_cost / out['n_rate'], gp)
+    gW = genops.weight_grad(delta, out['traj'])
+    gJ, gD, gS = genops.jds_grad(gW, zt, jds['J'], jds['D'], jds['S'])
+    rtol = 2e-3 if dtype == 'float32' else 1e-8
+    for got, want in ((gJ, gJ_o), (gD, gD_o), (gS, gS_o)):
+        want = want.numpy()
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * np.abs(want).max())
