@@ -206,6 +206,47 @@ int ssn_jds_grad_f32(const float *gW, const float *z, const float *J, const floa
 int ssn_jds_grad_f64(const double *gW, const double *z, const double *J, const double *D, const double *S,
                      double *out, int B, int N, void *stream);
 
+/* ------------------------------------------------------------------------
+ * 4. WGAN-GP critic and optimizers: replace the compiled Theano graphs of
+ *    ConditionalDiscriminator / ConditionalCriticTrainer (networks/cwgan.py:123-214),
+ *    the critic part of GeneratorTrainer's loss (networks/wgan.py:236) and
+ *    Updater (networks/wgan.py:111-165 over lasagne.updates.*).
+ *    Network: h0 = [x(nx), contrast, |norm_probe|, cell_type]; L hidden ReLU layers
+ *    (normalization 'none'); linear 1-unit output without bias.
+ *    params / grads: ONE flat fp32 device buffer [W_1 (n0 x n1) row-major, b_1, ...,
+ *    W_L, b_L, w_out (n_L)] -- the order of lasagne.layers.get_all_params.
+ *    dims: HOST int[L+1] = {n0 = nx+3, n1, ..., nL}.
+ *    precision: 0 = bf16 MFMA operands (fp32 accumulate), 1 = fp32 MFMA.
+ * ------------------------------------------------------------------------ */
+long   ssn_critic_num_params(const int *dims, int nlayers);
+size_t ssn_critic_workspace_floats(const int *dims, int nlayers, int batch_gd, int batch_p);
+/* out[batch] = D(x, cond).  x device [batch][nx], cond device [batch][3] (contrast, norm_probe, cell_type). */
+int ssn_critic_forward(const float *params, const int *dims, int nlayers, const float *x, const float *cond,
+                       int batch, int hide_cell_type, float *out, float *workspace, int precision, void *stream);
+/* loss = mean D(xg) - mean D(xd) + lmd * mean((||dD/dxp|| - 1)^2) and d loss / d params.
+ * stats device float[4] = {mean D(xg), mean D(xd), penalty, loss}; dvals device [ng+nd] = D of [xg; xd]. */
+int ssn_critic_loss_grad(const float *params, const int *dims, int nlayers,
+                         const float *xg, const float *cg, const float *xd, const float *cd,
+                         const float *xp, const float *cp, int ng, int nd, int np, float lmd,
+                         int hide_cell_type, float *grads, float *stats, float *dvals,
+                         float *workspace, int precision, void *stream);
+/* gx[batch][nx] = scale * d(mean-free sum_b D_b)/dx, stats[0] = mean D(x)  (generator side: scale = -1/batch). */
+int ssn_critic_input_grad(const float *params, const int *dims, int nlayers, const float *x, const float *cond,
+                          int batch, int hide_cell_type, float scale, float *gx, float *stats,
+                          float *workspace, int precision, void *stream);
+
+typedef struct ssn_opt_params {
+    int kind;                 /* 0 sgd, 1 adam, 2 rmsprop (lasagne.updates) */
+    int step;                 /* 1-based update count (adam bias correction) */
+    int clip;                 /* clamp the new value to [clip_lo, clip_hi] (wgan.py:244-251) */
+    int reserved;
+    double learning_rate, beta1, beta2, epsilon, rho;
+    double reg_l2_penalty, reg_l1_penalty, reg_l2_decay, reg_l1_decay;   /* wgan.py:121-129 */
+    double clip_lo, clip_hi;
+} ssn_opt_params;
+/* In-place update of p[n] from g[n]; s1, s2 optimizer state (adam: m, v; rmsprop: s1 only; sgd: unused). */
+int ssn_optimizer_step(float *p, const float *g, float *s1, float *s2, long n, const ssn_opt_params *o, void *stream);
+
 /* I/O nonlinearity on arrays (device pointers), the device function the solver
  * kernels use: out[i] = io(v[i]).  p->k, n, rate_soft_bound, rate_hard_bound,
  * io_type are read; for SSN_IO_* semantics see ssnode.c:25-53. */

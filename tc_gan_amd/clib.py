@@ -137,6 +137,33 @@ libssnode.ssn_jds_grad_f64.argtypes = [c_void_p, c_void_p, POINTER(c_double), PO
 libssnode.ssn_jds_grad_f32.restype = c_int
 libssnode.ssn_jds_grad_f64.restype = c_int
 
+class OptParams(Structure):
+    """``ssn_opt_params`` of include/ssnode_mi355x.h."""
+    _fields_ = [
+        ('kind', c_int), ('step', c_int), ('clip', c_int), ('reserved', c_int),
+        ('learning_rate', c_double), ('beta1', c_double), ('beta2', c_double), ('epsilon', c_double),
+        ('rho', c_double),
+        ('reg_l2_penalty', c_double), ('reg_l1_penalty', c_double),
+        ('reg_l2_decay', c_double), ('reg_l1_decay', c_double),
+        ('clip_lo', c_double), ('clip_hi', c_double),
+    ]
+
+
+_ip = POINTER(c_int)
+libssnode.ssn_critic_num_params.argtypes = [_ip, c_int]
+libssnode.ssn_critic_num_params.restype = c_long
+libssnode.ssn_critic_workspace_floats.argtypes = [_ip, c_int, c_int, c_int]
+libssnode.ssn_critic_workspace_floats.restype = ctypes.c_size_t
+libssnode.ssn_critic_forward.argtypes = [c_void_p, _ip, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                         c_int, c_void_p]
+libssnode.ssn_critic_loss_grad.argtypes = [c_void_p, _ip, c_int] + [c_void_p] * 6 + [c_int, c_int, c_int, c_float,
+                                           c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_input_grad.argtypes = [c_void_p, _ip, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                                            c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_optimizer_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_long, POINTER(OptParams), c_void_p]
+for _name in ('ssn_critic_forward', 'ssn_critic_loss_grad', 'ssn_critic_input_grad', 'ssn_optimizer_step'):
+    getattr(libssnode, _name).restype = c_int
+
 #: every symbol include/ssnode_mi355x.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = (
     'solve_dynamics_asym_power_euler', 'solve_dynamics_asym_linear_euler', 'solve_dynamics_asym_tanh_euler',
@@ -148,6 +175,8 @@ DECLARED_SYMBOLS = (
     'ssn_io_eval_f32', 'ssn_io_eval_f64',
     'ssn_gen_supported', 'ssn_gen_forward_f32', 'ssn_gen_forward_f64',
     'ssn_gen_backward_f32', 'ssn_gen_backward_f64', 'ssn_jds_grad_f32', 'ssn_jds_grad_f64',
+    'ssn_critic_num_params', 'ssn_critic_workspace_floats', 'ssn_critic_forward', 'ssn_critic_loss_grad',
+    'ssn_critic_input_grad', 'ssn_optimizer_step',
 )
 
 

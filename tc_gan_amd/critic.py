@@ -1,0 +1,180 @@
+"""WGAN-GP critic on the GPU (C ABI section 4 of include/ssnode_mi355x.h).
+
+Host-side mirror of ``ConditionalDiscriminator`` + ``ConditionalCriticTrainer``
+(networks/cwgan.py:123-214) and ``Updater`` (networks/wgan.py:111-165): parameters live
+in ONE flat fp32 device buffer in Lasagne's ``get_all_params`` order
+[W_1, b_1, ..., W_L, b_L, W_out]; every pass is a chain of MFMA GEMM launches in
+``csrc/ssn_critic.hip``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import clib
+from .clib import libssnode
+
+PRECISION = {'bf16': 0, 'fp32': 1}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Critic(object):
+    """MLP critic: input = [tuning curve (nx), contrast, |norm_probe|, cell_type]."""
+
+    def __init__(self, nx, layers, seed=0, hide_cell_type=False, precision='bf16',
+                 normalization='none', nonlinearity='rectify', device=None):
+        if normalization not in ('none', ('none',) * len(layers), ['none'] * len(layers)):
+            raise NotImplementedError("only normalization='none' is implemented on the GPU path")
+        if nonlinearity != 'rectify':
+            raise NotImplementedError("only nonlinearity='rectify' is implemented on the GPU path")
+        clib.require_gpu()
+        self.nx = int(nx)
+        self.layers = [int(w) for w in layers]
+        self.dims = [self.nx + 3] + self.layers
+        self.nlayers = len(self.layers)
+        self.hide_cell_type = int(bool(hide_cell_type))
+        self.precision = PRECISION[precision]
+        self._dims_c = (ctypes.c_int * len(self.dims))(*self.dims)
+        self.num_params = int(libssnode.ssn_critic_num_params(self._dims_c, self.nlayers))
+        self.device = device or torch.device('cuda', torch.cuda.current_device())
+        self.params = torch.empty(self.num_params, device=self.device, dtype=torch.float32)
+        self.grads = torch.zeros_like(self.params)
+        self.stats = torch.zeros(4, device=self.device, dtype=torch.float32)
+        self._ws = None
+        self._ws_key = None
+        self.init_params(np.random.RandomState(seed))
+
+    # -- parameters ------------------------------------------------------------------
+    def param_shapes(self):
+        shapes = []
+        for l in range(self.nlayers):
+            shapes.append(('W', (self.dims[l], self.dims[l + 1])))
+            shapes.append(('b', (self.dims[l + 1],)))
+        shapes.append(('W', (self.dims[-1], 1)))
+        return shapes
+
+    def init_params(self, rng):
+        """Lasagne defaults: W ~ GlorotUniform, hidden b ~ Normal(std=.01) (simple_discriminator.py:149-150),
+        linear output layer without bias (160-161)."""
+        flat = []
+        for kind, shape in self.param_shapes():
+            if kind == 'W':
+                a = np.sqrt(6.0 / (shape[0] + shape[1]))
+                flat.append(rng.uniform(-a, a, size=shape).ravel())
+            else:
+                flat.append(rng.normal(0.0, 0.01, size=shape).ravel())
+        self.set_flat(np.concatenate(flat))
+
+    def set_flat(self, flat):
+        flat = np.asarray(flat, dtype=np.float32)
+        assert flat.shape == (self.num_params,)
+        self.params.copy_(torch.from_numpy(flat))
+
+    def get_flat(self):
+        return self.params.detach().cpu().numpy()
+
+    def get_param_values(self):
+        """List of arrays in ``lasagne.layers.get_all_param_values`` order."""
+        flat = self.get_flat()
+        out, off = [], 0
+        for _, shape in self.param_shapes():
+            n = int(np.prod(shape))
+            out.append(flat[off:off + n].reshape(shape))
+            off += n
+        return out
+
+    def get_param_names(self):
+        return [kind for kind, _ in self.param_shapes()]
+
+    # -- passes ----------------------------------------------------------------------
+    def _workspace(self, bgd, bp):
+        key = (bgd, bp)
+        if self._ws_key != key:
+            n = int(libssnode.ssn_critic_workspace_floats(self._dims_c, self.nlayers, int(bgd), int(bp)))
+            self._ws = torch.empty(n, device=self.device, dtype=torch.float32)
+            self._ws_key = key
+        return self._ws
+
+    @staticmethod
+    def _f32(t):
+        return torch.as_tensor(t).to('cuda', torch.float32).contiguous()
+
+    def forward(self, x, cond):
+        x, cond = self._f32(x), self._f32(cond)
+        batch = x.shape[0]
+        out = torch.empty(batch, device=self.device, dtype=torch.float32)
+        ws = self._workspace(batch, 0)
+        clib.check(libssnode.ssn_critic_forward(self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(),
+                                                cond.data_ptr(), batch, self.hide_cell_type, out.data_ptr(),
+                                                ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward')
+        return out
+
+    def loss_grad(self, xg, cg, xd, cd, xp, cp, lmd):
+        """Fills ``self.grads`` and ``self.stats`` = [mean D(xg), mean D(xd), penalty, loss] (device)."""
+        xg, cg, xd, cd, xp, cp = (self._f32(t) for t in (xg, cg, xd, cd, xp, cp))
+        ng, nd, npn = xg.shape[0], xd.shape[0], xp.shape[0]
+        ws = self._workspace(ng + nd, npn)
+        self._dvals = torch.empty(ng + nd, device=self.device, dtype=torch.float32)
+        clib.check(libssnode.ssn_critic_loss_grad(
+            self.params.data_ptr(), self._dims_c, self.nlayers, xg.data_ptr(), cg.data_ptr(), xd.data_ptr(),
+            cd.data_ptr(), xp.data_ptr(), cp.data_ptr(), ng, nd, npn, float(lmd), self.hide_cell_type,
+            self.grads.data_ptr(), self.stats.data_ptr(), self._dvals.data_ptr(), ws.data_ptr(), self.precision,
+            _stream()), 'ssn_critic_loss_grad')
+        return self.stats
+
+    def input_grad(self, x, cond, scale):
+        """gx = scale * dD/dx summed over nothing (per sample), stats[0] = mean D(x)."""
+        x, cond = self._f32(x), self._f32(cond)
+        batch = x.shape[0]
+        gx = torch.empty((batch, self.nx), device=self.device, dtype=torch.float32)
+        ws = self._workspace(batch, batch)
+        clib.check(libssnode.ssn_critic_input_grad(
+            self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
+            self.hide_cell_type, float(scale), gx.data_ptr(), self.stats.data_ptr(), ws.data_ptr(), self.precision,
+            _stream()), 'ssn_critic_input_grad')
+        return gx, self.stats[0]
+
+    def accuracy(self, xg, cg, xd, cd):
+        """mean D(xg) - mean D(xd) (cwgan.py:139-147)."""
+        return float(self.forward(xg, cg).mean() - self.forward(xd, cd).mean())
+
+
+class Updater(object):
+    """wgan.py:111-165: 'adam-wgan' = Adam(beta1=.5, beta2=.9); any of adam / rmsprop / sgd by name;
+    L2/L1 penalty (through the loss) and decoupled L2/L1 decay; optional clipping of the new value."""
+
+    _named = {'adam-wgan': ('adam', dict(beta1=0.5, beta2=0.9))}
+    _kinds = {'sgd': 0, 'adam': 1, 'rmsprop': 2}
+
+    def __init__(self, learning_rate=0.001, update_name='adam-wgan', update_config=None,
+                 reg_l2_penalty=0.0, reg_l2_decay=0.0, reg_l1_penalty=0.0, reg_l1_decay=0.0):
+        name, default = self._named.get(update_name, (update_name, {}))
+        if name not in self._kinds:
+            raise ValueError('Unknown update method: {}'.format(update_name))
+        cfg = dict(dict(beta1=0.9, beta2=0.999, epsilon=1e-8 if name == 'adam' else 1e-6, rho=0.9), **default)
+        cfg.update(update_config or {})
+        self.update_name = update_name
+        self.learning_rate = learning_rate
+        self.kind = self._kinds[name]
+        self.cfg = cfg
+        self.reg = (reg_l2_penalty, reg_l1_penalty, reg_l2_decay, reg_l1_decay)
+        self.step = 0
+        self._state = None
+
+    def __call__(self, params, grads, clip=None):
+        """In-place update of the flat device tensor `params` from `grads`."""
+        if self._state is None or self._state[0].shape != params.shape:
+            self._state = (torch.zeros_like(params), torch.zeros_like(params))
+        self.step += 1
+        o = clib.OptParams(kind=self.kind, step=self.step, clip=int(clip is not None), reserved=0,
+                           learning_rate=self.learning_rate, beta1=self.cfg['beta1'], beta2=self.cfg['beta2'],
+                           epsilon=self.cfg['epsilon'], rho=self.cfg['rho'],
+                           reg_l2_penalty=self.reg[0], reg_l1_penalty=self.reg[1],
+                           reg_l2_decay=self.reg[2], reg_l1_decay=self.reg[3],
+                           clip_lo=clip[0] if clip else 0.0, clip_hi=clip[1] if clip else 0.0)
+        clib.check(libssnode.ssn_optimizer_step(params.data_ptr(), grads.data_ptr(), self._state[0].data_ptr(),
+                                                self._state[1].data_ptr(), params.numel(), ctypes.byref(o), _stream()),
+                   'ssn_optimizer_step')

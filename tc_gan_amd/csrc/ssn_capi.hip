@@ -194,6 +194,55 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, double 
 
 extern "C" {
 
+long ssn_critic_num_params(const int* dims, int nlayers) {
+    long n = 0;
+    for (int l = 0; l < nlayers; ++l) n += (long)dims[l] * dims[l + 1] + dims[l + 1];
+    return n + dims[nlayers];
+}
+size_t ssn_critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p) {
+    return ssn::critic_workspace_floats(dims, nlayers, batch_gd, batch_p);
+}
+int ssn_critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                       int hide_cell_type, float* out, float* workspace, int precision, void* stream) {
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_forward(params, dims, nlayers, x, cond, batch, hide_cell_type, out, workspace, precision == 0,
+                                (hipStream_t)stream));
+    return 0;
+}
+int ssn_critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
+                         const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
+                         float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* workspace,
+                         int precision, void* stream) {
+    SSN_TRY(ssn::critic_loss_grad(params, dims, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type, grads,
+                                  stats, dvals, workspace, precision == 0, (hipStream_t)stream));
+    return 0;
+}
+int ssn_critic_input_grad(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                          int hide_cell_type, float scale, float* gx, float* stats, float* workspace, int precision,
+                          void* stream) {
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_input_grad(params, dims, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats, workspace,
+                                   precision == 0, (hipStream_t)stream));
+    return 0;
+}
+int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, void* stream) {
+    if (!o || n < 0 || o->kind < 0 || o->kind > 2) {
+        g_last_error = "ssn_optimizer_step: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::OptArgs a;
+    a.p = p; a.g = g; a.s1 = s1; a.s2 = s2; a.n = n; a.kind = o->kind;
+    a.lr = (float)o->learning_rate; a.beta1 = (float)o->beta1; a.beta2 = (float)o->beta2; a.eps = (float)o->epsilon;
+    a.rho = (float)o->rho;
+    // lasagne.updates.adam: a_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
+    a.a_t = (float)(o->learning_rate * std::sqrt(1.0 - std::pow(o->beta2, o->step)) / (1.0 - std::pow(o->beta1, o->step)));
+    a.l2_penalty = (float)o->reg_l2_penalty; a.l1_penalty = (float)o->reg_l1_penalty;
+    a.l2_decay = (float)o->reg_l2_decay; a.l1_decay = (float)o->reg_l1_decay;
+    a.clip = o->clip; a.clip_lo = (float)o->clip_lo; a.clip_hi = (float)o->clip_hi;
+    SSN_TRY(ssn::optimizer_step(a, (hipStream_t)stream));
+    return 0;
+}
+
 int ssn_gen_supported(int M, int dtype_bytes) {
     if (M <= 0 || (M & 1)) return 0;
     return dtype_bytes == 8 ? ssn::gen_supported<double>(M) : ssn::gen_supported<float>(M);

@@ -1,0 +1,475 @@
+// WGAN-GP critic on MI355X (gfx950): MLP forward / backward / gradient-penalty
+// double-backward as a chain of small MFMA GEMMs, plus the optimizer kernels.
+//
+// Reference semantics (Lasagne/Theano graphs; restated in oracle/gan_torch.py):
+//   network  networks/cwgan.py:123-175 + simple_discriminator.py:139-165 ('none' normalization):
+//            h0 = [x, contrast, |norm_probe|, cell_type]; h_l = relu(h_{l-1} W_l + b_l);
+//            D = h_L w_out (no bias).
+//   loss     cwgan.py:190-214: mean D(xg) - mean D(xd) + lambda * mean((||dD(xp)/dxp||_2 - 1)^2),
+//            gradient taken w.r.t. the tuning-curve part of the input only.
+//   updates  wgan.py:111-165 (Updater: adam-wgan / rmsprop / sgd, L1/L2 penalty and decay).
+//
+// The gradient penalty needs the gradient of an input-gradient.  For a ReLU MLP the
+// input gradient is a LINEAR chain in the weights once the activation masks m_l are
+// fixed:  v_L = m_L * w_out^T,  v_{l-1} = m_{l-1} * (v_l W_l^T),  g = v_1 W_1^T,
+// so its parameter gradient is ordinary backprop through that chain with upstream
+// dP/dg = 2 (||g_x|| - 1)/||g_x|| * g_x / batch (Theano's jacobian builds a
+// batch x batch x NB tensor for the same quantity, cwgan.py:210-211).
+//
+// GEMM kernel: 64x64 tile per 256-thread workgroup, 4 waves x one 32x32 MFMA tile.
+//   bf16 path  v_mfma_f32_32x32x16_bf16, operands converted from the fp32 master copies
+//              while staging into LDS (fp32 accumulate, fp32 results);
+//   fp32 path  v_mfma_f32_32x32x2_f32 (exact fp32 products) for parity tests.
+// The layer GEMMs here are tiny (batch x 11..512 x 512): they are launch/latency bound,
+// not MFMA bound; the tile is chosen for simplicity and full generality in the strides.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include "ssn_host.h"
+
+namespace ssn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short to_bf16(float x) {
+    // round-to-nearest-even (plain cast semantics; keeps NaN a NaN)
+    __hip_bfloat16 h = __float2bfloat16(x);
+    return __builtin_bit_cast(unsigned short, h);
+}
+
+enum { EPI_PLAIN = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2 };
+
+struct GemmArgs {
+    const float* A; long sam, sak;     // op(A)(m,k) = A[m*sam + k*sak]
+    const float* B; long sbk, sbn;     // op(B)(k,n) = B[k*sbk + n*sbn]
+    float* C; long ldc;                // C[m*ldc + n]
+    int M, N, K;
+    float alpha, beta;                 // C = alpha*acc + beta*C   (PLAIN only)
+    const float* bias;                 // [N]          (BIAS_RELU)
+    const float* mask; long ldm;       // [M][ldm] > 0 (MASK): C = acc * (mask > 0)
+    int epilogue;
+};
+
+template <bool BF16>
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = BF16 ? 32 : 16;
+    // staged as [outer index][k], k contiguous: both MFMA operands then read consecutive k
+    __shared__ __align__(16) unsigned short As16[BF16 ? BM : 1][BF16 ? BK + 8 : 1];
+    __shared__ __align__(16) unsigned short Bs16[BF16 ? BN : 1][BF16 ? BK + 8 : 1];
+    __shared__ float As32[BF16 ? 1 : BM][BF16 ? 1 : BK + 1];
+    __shared__ float Bs32[BF16 ? 1 : BN][BF16 ? 1 : BK + 1];
+
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;          // 2 x 2 waves, 32 x 32 each
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        // ---- stage op(A)[m0:m0+64][k0:k0+BK] and op(B)[k0:k0+BK][n0:n0+64] ----------------
+        for (int e = tid; e < BM * BK; e += 256) {
+            // make the index that is contiguous in memory the fastest-varying one
+            int mi, ki;
+            if (g.sak == 1) { ki = e % BK; mi = e / BK; } else { mi = e % BM; ki = e / BM; }
+            const int m = m0 + mi, k = k0 + ki;
+            const float v = (m < g.M && k < g.K) ? g.A[m * g.sam + k * g.sak] : 0.f;
+            if constexpr (BF16) As16[mi][ki] = to_bf16(v); else As32[mi][ki] = v;
+        }
+        for (int e = tid; e < BN * BK; e += 256) {
+            int ni, ki;
+            if (g.sbk == 1) { ki = e % BK; ni = e / BK; } else { ni = e % BN; ki = e / BN; }
+            const int n = n0 + ni, k = k0 + ki;
+            const float v = (n < g.N && k < g.K) ? g.B[k * g.sbk + n * g.sbn] : 0.f;
+            if constexpr (BF16) Bs16[ni][ki] = to_bf16(v); else Bs32[ni][ki] = v;
+        }
+        __syncthreads();
+        if constexpr (BF16) {
+            // lane l: A[row l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][col l&31], j = 0..7 (per 16-deep step)
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 16) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(&As16[wr * 32 + (lane & 31)][kk + 8 * (lane >> 5)]);
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&Bs16[wc * 32 + (lane & 31)][kk + 8 * (lane >> 5)]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+            }
+        } else {
+            // lane l: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31] (per 2-deep step)
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float af = As32[wr * 32 + (lane & 31)][kk + (lane >> 5)];
+                const float bf = Bs32[wc * 32 + (lane & 31)][kk + (lane >> 5)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -----------
+    const int n = n0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (m < g.M && n < g.N) {
+            float v = acc[reg];
+            float* c = g.C + m * g.ldc + n;
+            if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : 0.f; }
+            else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : 0.f; }
+            else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
+            *c = v;
+        }
+    }
+}
+
+static hipError_t gemm(const GemmArgs& g, bool bf16, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+    if (bf16) hipLaunchKernelGGL((gemm_mfma_kernel<true>), grid, dim3(256), 0, st, g);
+    else      hipLaunchKernelGGL((gemm_mfma_kernel<false>), grid, dim3(256), 0, st, g);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// small elementwise / reduction kernels of the critic
+// ---------------------------------------------------------------------------------
+// h0[b] = [x[b][0:nx], c0, |c1|, c2]   (cwgan.py:164-170; hide_cell_type zeroes c2, 178-187)
+__global__ void __launch_bounds__(256) critic_input_kernel(const float* __restrict__ x, const float* __restrict__ cond,
+                                                           float* __restrict__ h0, int batch, int nx, int hide_cell_type) {
+    const int n0 = nx + 3;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)batch * n0; e += gridDim.x * 256L) {
+        const int b = (int)(e / n0), j = (int)(e % n0);
+        float v;
+        if (j < nx) v = x[(long)b * nx + j];
+        else if (j == nx) v = cond[b * 3 + 0];
+        else if (j == nx + 1) v = fabsf(cond[b * 3 + 1]);
+        else v = hide_cell_type ? 0.f : cond[b * 3 + 2];
+        h0[e] = v;
+    }
+}
+
+// v_L[b][k] = (h_L[b][k] > 0) * w_out[k] * up[b]   (up = per-sample upstream of D; nullptr -> 1)
+__global__ void __launch_bounds__(256) critic_outgrad_kernel(const float* __restrict__ hL, const float* __restrict__ wout,
+                                                             const float* __restrict__ up, float* __restrict__ vL,
+                                                             int batch, int nL) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)batch * nL; e += gridDim.x * 256L) {
+        const int b = (int)(e / nL), k = (int)(e % nL);
+        vL[e] = (hL[e] > 0.f) ? wout[k] * (up ? up[b] : 1.f) : 0.f;
+    }
+}
+
+// column sums: out[n] (+)= sum_b X[b][n]    (bias gradients)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int batch, int n,
+                                                     float beta) {
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int part = threadIdx.x >> 6;
+    __shared__ float red[4][64];
+    float s = 0.f;
+    if (col < n)
+        for (int b = part; b < batch; b += 4) s += X[(long)b * n + col];
+    red[part][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (part == 0 && col < n) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        out[col] = t + (beta != 0.f ? beta * out[col] : 0.f);
+    }
+}
+
+// gradient-penalty head: per sample norm of g[:, :nx]; writes ghat = 2 (norm-1)/norm * g_x / batch (zero
+// beyond nx) and accumulates sum_b (norm_b - 1)^2 into pen[0] (one workgroup; fixed order -> deterministic).
+__global__ void __launch_bounds__(256) gp_head_kernel(const float* __restrict__ g, float* __restrict__ ghat,
+                                                      float* __restrict__ pen, int batch, int n0, int nx) {
+    __shared__ float red[256];
+    float local = 0.f;
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        float s = 0.f;
+        for (int j = 0; j < nx; ++j) { const float v = g[(long)b * n0 + j]; s += v * v; }
+        const float nrm = sqrtf(s);
+        local += (nrm - 1.f) * (nrm - 1.f);
+        const float coef = (nrm > 0.f) ? 2.f * (nrm - 1.f) / nrm / (float)batch : 0.f;
+        for (int j = 0; j < n0; ++j) ghat[(long)b * n0 + j] = (j < nx) ? coef * g[(long)b * n0 + j] : 0.f;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pen[0] = red[0] / (float)batch;
+}
+
+// out[0] = mean(d[0:ng]), out[1] = mean(d[ng:ng+nd])   (one workgroup)
+__global__ void __launch_bounds__(256) two_means_kernel(const float* __restrict__ d, float* __restrict__ out, int ng, int nd) {
+    __shared__ float red[2][256];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < ng; i += 256) a += d[i];
+    for (int i = threadIdx.x; i < nd; i += 256) b += d[ng + i];
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = ng ? red[0][0] / ng : 0.f; out[1] = nd ? red[1][0] / nd : 0.f; }
+}
+
+__global__ void __launch_bounds__(256) fill_updown_kernel(float* up, int ng, int nd) {
+    // upstream of mean D(xg) - mean D(xd) for the concatenated [xg; xd] batch
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ng + nd; i += gridDim.x * 256)
+        up[i] = (i < ng) ? 1.f / (float)ng : -1.f / (float)nd;
+}
+
+// stats[3] = mean D(xg) - mean D(xd) + lmd * penalty
+__global__ void loss_combine_kernel(float* stats, float lmd) { stats[3] = stats[0] - stats[1] + lmd * stats[2]; }
+
+// gx[b][j] = s * v0[b][j], j < nx   (tuning-curve part of the input gradient)
+__global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restrict__ v0, float* __restrict__ gx, int batch,
+                                                           int n0, int nx, float s) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)batch * nx; e += gridDim.x * 256L) {
+        const int b = (int)(e / nx), j = (int)(e % nx);
+        gx[e] = s * v0[(long)b * n0 + j];
+    }
+}
+
+__global__ void __launch_bounds__(256) axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += gridDim.x * 256L) y[e] += a * x[e];
+}
+
+// ---------------------------------------------------------------------------------
+// critic passes
+// ---------------------------------------------------------------------------------
+struct CriticNet {
+    int nlayers;           // hidden layers L
+    int dims[10];          // n_0 .. n_L
+    const float* W[9];
+    const float* b[9];
+    const float* wout;     // [n_L]
+    long nparams;
+};
+
+static bool parse_net(const float* params, const int* dims, int nlayers, CriticNet& net) {
+    if (nlayers < 0 || nlayers > 8) return false;
+    net.nlayers = nlayers;
+    long off = 0;
+    for (int l = 0; l <= nlayers; ++l) net.dims[l] = dims[l];
+    for (int l = 0; l < nlayers; ++l) {
+        net.W[l] = params + off; off += (long)dims[l] * dims[l + 1];
+        net.b[l] = params + off; off += dims[l + 1];
+    }
+    net.wout = params + off; off += dims[nlayers];
+    net.nparams = off;
+    return true;
+}
+
+static int blocks_for(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+
+// activations h[l] (l = 0..L) for `batch` rows live at act + offsets; returns D in dout[batch]
+static hipError_t critic_forward_pass(const CriticNet& net, float* const* h, float* dout, int batch, bool bf16, hipStream_t st) {
+    hipError_t e;
+    for (int l = 0; l < net.nlayers; ++l) {
+        GemmArgs g{};
+        g.A = h[l]; g.sam = net.dims[l]; g.sak = 1;
+        g.B = net.W[l]; g.sbk = net.dims[l + 1]; g.sbn = 1;
+        g.C = h[l + 1]; g.ldc = net.dims[l + 1];
+        g.M = batch; g.N = net.dims[l + 1]; g.K = net.dims[l];
+        g.bias = net.b[l]; g.epilogue = EPI_BIAS_RELU;
+        if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+    }
+    GemmArgs g{};
+    const int L = net.nlayers;
+    g.A = h[L]; g.sam = net.dims[L]; g.sak = 1;
+    g.B = net.wout; g.sbk = 1; g.sbn = 1;
+    g.C = dout; g.ldc = 1; g.M = batch; g.N = 1; g.K = net.dims[L];
+    g.alpha = 1.f; g.beta = 0.f; g.epilogue = EPI_PLAIN;
+    return gemm(g, bf16, st);
+}
+
+// Backward chain with masks from h[]: v[L] given; computes v[l-1] = m_{l-1} * (v[l] W_l^T) down to
+// v[0] = v[1] W_1^T (no mask on the input).  If grads != nullptr also accumulates parameter gradients
+// of "sum_b up_b D_b" style losses: dW_l += h_{l-1}^T v_l,  db_l += colsum(v_l).
+static hipError_t critic_backward_chain(const CriticNet& net, float* const* h, float* const* v, int batch, float* grads,
+                                        bool want_input_grad, bool bf16, hipStream_t st) {
+    hipError_t e;
+    long off_end = net.nparams - net.dims[net.nlayers];
+    long off = off_end;
+    for (int l = net.nlayers - 1; l >= 0; --l) {
+        const int nin = net.dims[l], nout = net.dims[l + 1];
+        off -= nout;                    // bias of layer l
+        const long off_b = off;
+        off -= (long)nin * nout;        // weight of layer l
+        const long off_w = off;
+        if (grads) {
+            GemmArgs g{};               // dW_l[i][k] += scale * sum_b h_l[b][i] v_{l+1}[b][k]
+            g.A = h[l]; g.sam = 1; g.sak = nin;            // op(A)(i, b) = h[b][i]
+            g.B = v[l + 1]; g.sbk = nout; g.sbn = 1;        // op(B)(b, k)
+            g.C = grads + off_w; g.ldc = nout; g.M = nin; g.N = nout; g.K = batch;
+            g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+            hipLaunchKernelGGL(colsum_kernel, dim3((nout + 63) / 64), dim3(256), 0, st, v[l + 1], grads + off_b, batch, nout, 1.f);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (l > 0 || want_input_grad) {
+            GemmArgs g{};               // v_l = (v_{l+1} W_l^T) [* mask_l]
+            g.A = v[l + 1]; g.sam = nout; g.sak = 1;
+            g.B = net.W[l]; g.sbk = 1; g.sbn = nout;        // op(B)(k, i) = W[i][k]
+            g.C = v[l]; g.ldc = nin; g.M = batch; g.N = nin; g.K = nout;
+            if (l > 0) { g.epilogue = EPI_MASK; g.mask = h[l]; g.ldm = nin; }
+            else { g.alpha = 1.f; g.beta = 0.f; g.epilogue = EPI_PLAIN; }
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p) {
+    // (1) h_0..h_L and v_0..v_L for the [xg; xd] rows + upstream; (2) h, v, e for the xp rows + D(xp); + scratch
+    long per_row = 0, maxd = 0;
+    for (int l = 0; l <= nlayers; ++l) { per_row += dims[l]; if (dims[l] > maxd) maxd = dims[l]; }
+    return (size_t)(2L * batch_gd * per_row + batch_gd + 3L * batch_p * per_row + batch_p + maxd + 64);
+}
+
+// D values for a batch (inference / accuracy): out[batch]
+hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                          int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st) {
+    CriticNet net;
+    if (!parse_net(params, dims, nlayers, net)) return hipErrorInvalidValue;
+    const int nx = dims[0] - 3;
+    float* h[10];
+    float* p = ws;
+    for (int l = 0; l <= nlayers; ++l) { h[l] = p; p += (long)batch * dims[l]; }
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type);
+    return critic_forward_pass(net, h, out, batch, bf16, st);
+}
+
+// Full critic loss + gradient.  stats[0..3] = mean D(xg), mean D(xd), penalty, loss.
+hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
+                            const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
+                            float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* ws, bool bf16,
+                            hipStream_t st) {
+    CriticNet net;
+    if (!parse_net(params, dims, nlayers, net)) return hipErrorInvalidValue;
+    hipError_t e;
+    const int L = nlayers, nx = dims[0] - 3;
+    const int bgd = ng + nd;
+    if ((e = hipMemsetAsync(grads, 0, net.nparams * sizeof(float), st)) != hipSuccess) return e;
+    float* p = ws;
+    // ---------------- (1) mean D(xg) - mean D(xd) on the concatenated batch -------------------
+    float *h[10], *v[10];
+    for (int l = 0; l <= L; ++l) { h[l] = p; p += (long)bgd * dims[l]; }
+    for (int l = 0; l <= L; ++l) { v[l] = p; p += (long)bgd * dims[l]; }
+    float* up = p; p += bgd;
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type);
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type);
+    if ((e = critic_forward_pass(net, h, dvals, bgd, bf16, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dvals, stats, ng, nd);
+    hipLaunchKernelGGL(fill_updown_kernel, dim3(blocks_for(bgd)), dim3(256), 0, st, up, ng, nd);
+    // d/dw_out = sum_b up_b h_L[b][:]
+    {
+        GemmArgs g{};
+        g.A = h[L]; g.sam = 1; g.sak = dims[L];      // op(A)(k, b) = h_L[b][k]
+        g.B = up; g.sbk = 1; g.sbn = 1;
+        g.C = grads + (net.nparams - dims[L]); g.ldc = 1; g.M = dims[L]; g.N = 1; g.K = bgd;
+        g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
+        if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)bgd * dims[L])), dim3(256), 0, st, h[L], net.wout, up, v[L], bgd, dims[L]);
+    if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st)) != hipSuccess) return e;
+
+    // ---------------- (2) gradient penalty on xp ------------------------------------------------
+    float *hp[10], *vp[10], *ep[10];
+    for (int l = 0; l <= L; ++l) { hp[l] = p; p += (long)np * dims[l]; }
+    for (int l = 0; l <= L; ++l) { vp[l] = p; p += (long)np * dims[l]; }
+    for (int l = 0; l <= L; ++l) { ep[l] = p; p += (long)np * dims[l]; }
+    float* dp = p; p += np;
+    float* tmp = p; p += dims[L];
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type);
+    if ((e = critic_forward_pass(net, hp, dp, np, bf16, st)) != hipSuccess) return e;
+    // input gradient g = dD/dh0 per sample: v_L = m_L * w_out, chain down to vp[0]
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, st, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L]);
+    if ((e = critic_backward_chain(net, hp, vp, np, nullptr, true, bf16, st)) != hipSuccess) return e;
+    // penalty and its gradient w.r.t. g: ep[0] = ghat (np x n0)
+    hipLaunchKernelGGL(gp_head_kernel, dim3(1), dim3(256), 0, st, vp[0], ep[0], stats + 2, np, dims[0], nx);
+    // backprop through the linear chain g = v_1 W_1^T, v_{l} = m_l * (v_{l+1} W_{l+1}^T), v_L = m_L * w_out:
+    //   dW_l[i][k] += lmd * sum_b e_{l-1}[b][i] v_l[b][k],   e_l = m_l * (e_{l-1} W_l)   (e_0 = ghat)
+    long off = 0;
+    for (int l = 0; l < L; ++l) {
+        const int nin = dims[l], nout = dims[l + 1];
+        {
+            GemmArgs g{};
+            g.A = ep[l]; g.sam = 1; g.sak = nin;               // op(A)(i, b) = e_l[b][i]
+            g.B = vp[l + 1]; g.sbk = nout; g.sbn = 1;
+            g.C = grads + off; g.ldc = nout; g.M = nin; g.N = nout; g.K = np;
+            g.alpha = lmd; g.beta = 1.f; g.epilogue = EPI_PLAIN;
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+        }
+        {
+            GemmArgs g{};                                       // e_{l+1} = m_{l+1} * (e_l W_l)
+            g.A = ep[l]; g.sam = nin; g.sak = 1;
+            g.B = net.W[l]; g.sbk = nout; g.sbn = 1;
+            g.C = ep[l + 1]; g.ldc = nout; g.M = np; g.N = nout; g.K = nin;
+            g.epilogue = EPI_MASK; g.mask = hp[l + 1]; g.ldm = nout;
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+        }
+        off += (long)nin * nout + nout;
+    }
+    // d/dw_out[k] += lmd * sum_b e_L[b][k]      (v_L = m_L * w_out, mask already applied in e_L)
+    hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(256), 0, st, ep[L], tmp, np, dims[L], 0.f);
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(dims[L])), dim3(256), 0, st, grads + (net.nparams - dims[L]), tmp, lmd, (long)dims[L]);
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
+    return hipGetLastError();
+}
+
+// Gradient of  -mean D(x)  w.r.t. the tuning-curve part of the input (generator side, wgan.py:236):
+// gx[batch][nx];  also returns mean D in stats[0].
+hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                             int hide_cell_type, float scale, float* gx, float* stats, float* ws, bool bf16, hipStream_t st) {
+    CriticNet net;
+    if (!parse_net(params, dims, nlayers, net)) return hipErrorInvalidValue;
+    hipError_t e;
+    const int L = nlayers, nx = dims[0] - 3;
+    float *h[10], *v[10];
+    float* p = ws;
+    for (int l = 0; l <= L; ++l) { h[l] = p; p += (long)batch * dims[l]; }
+    for (int l = 0; l <= L; ++l) { v[l] = p; p += (long)batch * dims[l]; }
+    float* dv = p; p += batch;
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type);
+    if ((e = critic_forward_pass(net, h, dv, batch, bf16, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dv, stats, batch, 0);
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)batch * dims[L])), dim3(256), 0, st, h[L], net.wout, (const float*)nullptr, v[L], batch, dims[L]);
+    if ((e = critic_backward_chain(net, h, v, batch, nullptr, true, bf16, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(gather_scale_kernel, dim3(blocks_for((long)batch * nx)), dim3(256), 0, st, v[0], gx, batch, dims[0], nx, scale);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
+// optimizers (wgan.py:111-165 on top of lasagne.updates.{adam,rmsprop,sgd})
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) optimizer_kernel(OptArgs o) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < o.n; e += gridDim.x * 256L) {
+        const float p0 = o.p[e];
+        float g = o.g[e];
+        // penalties enter through the loss (wgan.py:144-151): d/dp (l2 * p^2) = 2 l2 p, d/dp (l1 |p|) = l1 sgn p
+        g += 2.f * o.l2_penalty * p0 + o.l1_penalty * ((p0 > 0.f) - (p0 < 0.f));
+        float pn;
+        if (o.kind == 1) {
+            const float m = o.beta1 * o.s1[e] + (1.f - o.beta1) * g;
+            const float v = o.beta2 * o.s2[e] + (1.f - o.beta2) * g * g;
+            o.s1[e] = m; o.s2[e] = v;
+            pn = p0 - o.a_t * m / (sqrtf(v) + o.eps);
+        } else if (o.kind == 2) {
+            const float acc = o.rho * o.s1[e] + (1.f - o.rho) * g * g;
+            o.s1[e] = acc;
+            pn = p0 - o.lr * g / sqrtf(acc + o.eps);
+        } else {
+            pn = p0 - o.lr * g;
+        }
+        // decoupled decay on the OLD value (wgan.py:158-163, apply_l2_decay / apply_l1_decay)
+        pn -= o.lr * o.l2_decay * p0 + o.lr * o.l1_decay * ((p0 > 0.f) - (p0 < 0.f));
+        if (o.clip) pn = fminf(fmaxf(pn, o.clip_lo), o.clip_hi);       // wgan.py:244-251
+        o.p[e] = pn;
+    }
+}
+hipError_t optimizer_step(const OptArgs& o, hipStream_t st) {
+    if (o.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(optimizer_kernel, dim3(blocks_for(o.n)), dim3(256), 0, st, o);
+    return hipGetLastError();
+}
+
+}  // namespace ssn

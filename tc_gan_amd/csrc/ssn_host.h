@@ -61,6 +61,25 @@ template <typename T> hipError_t launch_gen_forward(const GenFwdArgs<T>& a, hipS
 template <typename T> hipError_t launch_gen_backward(const GenBwdArgs<T>& a, hipStream_t st);
 template <typename T> hipError_t launch_jds_grad(const T* gW, const T* z, const T* jds12, double* out, int B, int N, hipStream_t st);
 
+// ssn_critic.hip
+struct OptArgs {
+    float* p; const float* g; float* s1; float* s2; long n;
+    float lr, a_t, beta1, beta2, eps, rho;
+    float l2_penalty, l1_penalty, l2_decay, l1_decay;
+    float clip_lo, clip_hi; int clip;
+    int kind;    // 0 sgd, 1 adam, 2 rmsprop
+};
+size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);
+hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                          int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st);
+hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
+                            const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
+                            float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* ws, bool bf16,
+                            hipStream_t st);
+hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                             int hide_cell_type, float scale, float* gx, float* stats, float* ws, bool bf16, hipStream_t st);
+hipError_t optimizer_step(const OptArgs& o, hipStream_t st);
+
 // ssn_aux.hip
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, T* ext, int B, int NB, int N, hipStream_t st);

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_in_header():
     text = open(os.path.join(ROOT, 'include', 'ssnode_mi355x.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    names = re.findall(r'^\s*(?:int|double|const char \*|const char\*)\s*\*?\s*([a-z_0-9]+)\s*\(', text, flags=re.M)
+    names = re.findall(r'^\s*(?:int|long|size_t|double|const char \*|const char\*)\s*\*?\s*([a-z_0-9]+)\s*\(', text, flags=re.M)
     return sorted(set(names))
 
 
