@@ -1,0 +1,435 @@
+"""Conditional BPTT Wasserstein GAN on the GPU -- host-side mirror of ``tc_gan/networks/cwgan.py``.
+
+Same components, names and schedule as the reference:
+
+* `ConditionalMinibatch`, `RandomChoiceSampler` (cwgan.py:217-391) -- host index selection with the
+  reference's RandomState consumption order (SURVEY.md section 8a gotcha 1);
+* `ConditionalBPTTWassersteinGAN` (cwgan.py:410-552) -- ``learning()`` is a Python generator yielding a
+  `Namespace` per critic step (``is_discriminator=True``) and per generator step, with the fields the
+  driver/recorders read;
+* `make_gan(config) -> (gan, rest)` (cwgan.py:555-614).
+
+What differs is where the arithmetic runs: generator forward / BPTT in ``csrc/ssn_gen.hip``, critic
+passes and optimizers in ``csrc/ssn_critic.hip``; tuning curves stay on the device between the
+generator and the critic (the reference round-trips them through numpy, cwgan.py:478-505).
+
+Data parallelism (new; the reference is single device): with ``torch.distributed`` initialised every
+rank keeps a replica of the critic and of (J, D, S), works on its contiguous slice of the
+``num_models`` weight draws, and ONE all-reduce per update (flat buffer: critic grads | 12 generator
+grads | loss scalars) makes the replicas take identical optimizer steps.
+"""
+from logging import getLogger
+
+import numpy as np
+import torch
+
+from .. import clib
+from ..critic import Critic, Updater
+from ..gradient_expressions.utils import sample_sites_from_stim_space
+from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product
+from .ssn import TuningCurveGenerator
+from .utils import gridify_tc_samples
+from .wgan import DEFAULT_PARAMS as _WGAN_DEFAULTS
+
+logger = getLogger(__name__)
+
+# cwgan.py:24-32
+DEFAULT_PARAMS = dict(
+    _WGAN_DEFAULTS,
+    num_models=1,
+    probes_per_model=1,
+    e_ratio=0.8,
+    hide_cell_type=False,
+)
+del DEFAULT_PARAMS['batchsize']
+del DEFAULT_PARAMS['sample_sites']
+
+
+class ConditionalMinibatch(object):
+    """cwgan.py:217-274."""
+
+    def __init__(self, tc_md, conditions_md, bandwidths, contrasts):
+        self.tc_md = tc_md
+        self.conditions_md = np.asarray(conditions_md)
+        self.bandwidths = bandwidths
+        self.contrasts = contrasts
+        assert self.tc_md.shape[:-1] == self.conditions_md.shape[1:]
+        assert self.tc_md.shape[-1] == len(bandwidths)
+
+    num_models = property(lambda self: self.tc_md.shape[0])
+    probes_per_model = property(lambda self: self.tc_md.shape[1])
+    num_bandwidths = property(lambda self: self.tc_md.shape[2])
+
+    @property
+    def batchsize(self):
+        return self.num_models * self.probes_per_model
+
+    @property
+    def gen_kwargs(self):
+        contrasts, bandwidths = np.broadcast_arrays(self.contrasts.reshape((-1, 1)),
+                                                    self.bandwidths.reshape((1, -1)))
+        _, norm_probes, cell_types = self._conditions_T
+        return dict(
+            stimulator_bandwidths=bandwidths.astype('float32'),
+            stimulator_contrasts=contrasts.astype('float32'),
+            prober_norm_probes=norm_probes.astype('float32'),
+            prober_cell_types=cell_types.astype('uint16'),
+            prober_model_ids=self.model_ids.astype('uint16'))
+
+    @property
+    def tuning_curves(self):
+        return self.tc_md.reshape((self.batchsize, self.num_bandwidths))
+
+    @property
+    def conditions(self):
+        return self._conditions_T.T
+
+    @property
+    def _conditions_T(self):
+        return self.conditions_md.reshape((-1, self.batchsize))
+
+    @property
+    def model_ids(self):
+        ids = np.arange(self.num_models, dtype='uint16').reshape((-1, 1))
+        return np.broadcast_to(ids, self.conditions_md.shape[1:]).flatten()
+
+    def shard(self, rank, world):
+        """The contiguous block of models of one data-parallel rank (same arrays, fewer rows)."""
+        per = self.num_models // world
+        sl = slice(rank * per, (rank + 1) * per)
+        return ConditionalMinibatch(self.tc_md[sl], self.conditions_md[:, sl], self.bandwidths, self.contrasts[sl])
+
+
+class RandomChoiceSampler(object):
+    """Minibatch sampler based on random choice (cwgan.py:277-391)."""
+
+    @classmethod
+    def from_grid_data(cls, data, bandwidths, contrasts, norm_probes, include_inhibitory_neurons, **kwargs):
+        cell_types = [0, 1] if include_inhibitory_neurons else [0]
+        nested = gridify_tc_samples(data, num_contrasts=len(contrasts), num_bandwidths=len(bandwidths),
+                                    num_cell_types=len(cell_types), num_probes=len(norm_probes))
+        cond_values = [cell_types, norm_probes, contrasts, bandwidths]
+        assert nested.shape == (len(data),) + tuple(map(len, cond_values))
+        return cls(nested, cond_values, **kwargs)
+
+    def __init__(self, nested, cond_values, e_ratio, seed=0):
+        self.nested = np.asarray(nested)
+        self.cond_values = cond_values = list(map(np.asarray, cond_values))
+        self.e_ratio = e_ratio
+        self.cell_types, self.norm_probes, self.contrasts, self.bandwidths = cond_values
+        self.rng = as_randomstate(seed)
+        assert tuple(self.cell_types) in [(0,), (0, 1)]
+
+    def random_cells(self, num_models, probes_per_model):
+        """Every (cell type, probe) pair at most once per model (cwgan.py:328-355)."""
+        cellids = cartesian_product(np.arange(len(self.cell_types)), np.arange(len(self.norm_probes)), dtype=int).T
+        if len(self.cell_types) == 2:
+            probs = np.zeros(len(cellids))
+            probs[:len(self.norm_probes)] = self.e_ratio
+            probs[len(self.norm_probes):] = 1 - self.e_ratio
+            probs /= probs.sum()
+        else:
+            probs = None
+        ids = np.asarray([cellids[self.rng.choice(len(cellids), probes_per_model, replace=False, p=probs)]
+                          for _ in range(num_models)])
+        ids_cell_type, ids_norm_probes = ids.transpose((2, 0, 1))
+        return ids_cell_type, ids_norm_probes
+
+    def select_minibatch(self, num_models, probes_per_model):
+        """RandomState consumption order: samples, cells (per model), contrasts (cwgan.py:362-367)."""
+        shape = (num_models, probes_per_model)
+        ids_sample = self.rng.choice(len(self.nested), shape)
+        ids_cell_type, ids_norm_probes = self.random_cells(*shape)
+        ids_flat_contrast = self.rng.choice(len(self.contrasts), num_models)
+        ids_contrast = np.broadcast_to(ids_flat_contrast.reshape((-1, 1)), shape)
+        tc_md = self.nested[ids_sample, ids_cell_type, ids_norm_probes, ids_contrast]
+        assert tc_md.shape == (num_models, probes_per_model, len(self.bandwidths))
+        return ConditionalMinibatch(
+            tc_md,
+            [self.contrasts[ids_contrast], self.norm_probes[ids_norm_probes], self.cell_types[ids_cell_type]],
+            self.bandwidths,
+            self.contrasts[ids_flat_contrast])
+
+    def random_minibatches(self, *args, **kwargs):
+        while True:
+            yield self.select_minibatch(*args, **kwargs)
+
+
+class GradientAllReducer(object):
+    """One flat-buffer all-reduce (mean over ranks) per update; identity without torch.distributed."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.on else 1
+        self.rank = dist.get_rank() if self.on else 0
+
+    def mean_(self, *tensors):
+        """In-place mean over ranks of several tensors through ONE collective."""
+        if not self.on:
+            return
+        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+        flat /= self.world
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+            off += n
+
+
+class ConditionalBPTTWassersteinGAN(object):
+    """cwgan.py:410-552."""
+
+    loss_type = 'WD'
+
+    def __init__(self, gen, disc, gen_updaters, disc_updater, bandwidths, contrasts, norm_probes,
+                 e_ratio, include_inhibitory_neurons, rate_penalty_threshold,
+                 num_models, probes_per_model, critic_iters_init, critic_iters, lipschitz_cost,
+                 disc_rate_penalty_bound, dynamics_cost, rate_cost, param_bounds, seed=0):
+        self.gen = gen
+        self.disc = disc
+        self.gen_updaters = gen_updaters          # {'J': Updater, 'D': ..., 'S': ...}
+        self.disc_updater = disc_updater
+        self.bandwidths = np.asarray(bandwidths)
+        self.contrasts = np.asarray(contrasts)
+        self.norm_probes = np.asarray(norm_probes)
+        self.e_ratio = e_ratio
+        self.include_inhibitory_neurons = include_inhibitory_neurons
+        self.rate_penalty_threshold = rate_penalty_threshold
+        self.num_models = num_models
+        self.probes_per_model = probes_per_model
+        self.critic_iters_init = critic_iters_init
+        self.critic_iters = critic_iters
+        self.lipschitz_cost = lipschitz_cost
+        self.disc_rate_penalty_bound = disc_rate_penalty_bound
+        self.dynamics_cost = dynamics_cost
+        self.rate_cost = rate_cost
+        self.param_bounds = param_bounds          # {'J': (min, max), ...}  (wgan.py:244-251)
+        self.rng = as_randomstate(seed)
+        self.reducer = GradientAllReducer()
+        assert self.probes_per_model < gen.num_neurons
+        assert num_models % self.reducer.world == 0, 'num_models must be divisible by the number of ranks'
+        self._gparams = {k: torch.zeros(4, device='cuda', dtype=torch.float32) for k in 'JDS'}
+
+    batchsize = property(lambda self: self.num_models * self.probes_per_model)
+    num_sites = property(lambda self: self.gen.num_sites)
+    num_neurons = property(lambda self: self.gen.num_neurons)
+    NZ = property(lambda self: self.batchsize)
+    discriminator = property(lambda self: self.disc)
+
+    @property
+    def sample_sites(self):
+        return sample_sites_from_stim_space(self.norm_probes, self.num_sites)
+
+    def get_gen_param(self):
+        return [self.gen.J.copy(), self.gen.D.copy(), self.gen.S.copy()]
+
+    def set_dataset(self, data, **kwargs):
+        kwargs.setdefault('seed', self.rng)       # the sampler SHARES the GAN's RandomState (cwgan.py:452)
+        self.sampler = RandomChoiceSampler.from_grid_data(
+            data, bandwidths=self.bandwidths, contrasts=self.contrasts, norm_probes=self.norm_probes,
+            e_ratio=self.e_ratio, include_inhibitory_neurons=self.include_inhibitory_neurons, **kwargs)
+        self.dataset = self.sampler.random_minibatches(self.num_models, self.probes_per_model)
+
+    def next_minibatch(self):
+        return next(self.dataset)
+
+    def prepare(self):
+        """Nothing to compile."""
+
+    # ---------------------------------------------------------------------------------------
+    def _local(self, batch):
+        return batch.shard(self.reducer.rank, self.reducer.world) if self.reducer.on else batch
+
+    def _draw_zs(self, batch):
+        """Host noise in the reference's stream order (ssn.py:434-439): the GLOBAL draw, then this
+        rank's rows -- so a data-parallel run consumes the RandomState exactly like a single-GPU run."""
+        if self.gen._zgen is not None:
+            return None                            # device Philox stream (perf mode)
+        zs = self.rng.rand(batch.num_models, self.gen.num_neurons, self.gen.num_neurons)
+        if self.reducer.on:
+            per = batch.num_models // self.reducer.world
+            zs = zs[self.reducer.rank * per:(self.reducer.rank + 1) * per]
+        return zs
+
+    def gen_forward(self, batch, zs=None, save=False):
+        local = self._local(batch)
+        kw = local.gen_kwargs
+        if zs is not None:
+            kw['model_zs'] = zs
+        return self.gen.forward(rng=self.rng, save=save, model_rate_penalty_threshold=self.rate_penalty_threshold,
+                                **kw), local
+
+    def train_discriminator(self, info):
+        batch = self.next_minibatch()
+        eps_full = self.rng.rand(batch.batchsize, 1)
+        zs = self._draw_zs(batch)
+        with self.gen_forward_watch:
+            gen_out, local = self.gen_forward(batch, zs)
+            xg = gen_out.prober_tuning_curve
+            rate_penalty = self._mean_scalar(gen_out.model_rate_penalty)
+            dynamics_penalty = self._mean_scalar(gen_out.model_dynamics_penalty)
+        xd = torch.as_tensor(local.tuning_curves, device='cuda', dtype=torch.float32)
+        cd = torch.as_tensor(np.ascontiguousarray(local.conditions), device='cuda', dtype=torch.float32)
+        per = local.batchsize
+        r0 = self.reducer.rank * per if self.reducer.on else 0
+        eps = torch.as_tensor(eps_full[r0:r0 + per], device='cuda', dtype=torch.float32)
+        xp = eps * xd + (1 - eps) * xg.to(torch.float32)                      # cwgan.py:481
+        info.gen_out = gen_out
+        info.dynamics_penalty = dynamics_penalty
+        info.rate_penalty = rate_penalty
+        info.xd, info.xg, info.xp = xd, xg, xp
+        info.cd = info.cg = info.cp = cd
+        info.batch = batch
+        info.gen_time = self.gen_forward_watch.times[-1]
+
+        bound = self.disc_rate_penalty_bound
+        if bound > 0 and rate_penalty > bound:                                   # cwgan.py:493-498
+            info.disc_loss = np.nan
+            info.accuracy = np.nan
+            info.disc_time = np.nan
+            return info
+
+        with self.disc_train_watch:
+            stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
+            self.reducer.mean_(self.disc.grads, stats)
+            self.disc_updater(self.disc.params, self.disc.grads)
+            info.disc_loss = float(stats[3])
+        acc = torch.stack([self.disc.forward(xg, cd).mean() - self.disc.forward(xd, cd).mean()])
+        self.reducer.mean_(acc)
+        info.accuracy = float(acc[0])
+        info.disc_time = self.disc_train_watch.times[-1]
+        return info
+
+    def _mean_scalar(self, t):
+        t = t.reshape(1).to(torch.float32).clone()
+        self.reducer.mean_(t)
+        return float(t[0])
+
+    def train_generator(self, info, batch):
+        zs = self._draw_zs(batch)
+        with self.gen_train_watch:
+            gen_out, local = self.gen_forward(batch, zs, save=True)
+            cd = torch.as_tensor(np.ascontiguousarray(local.conditions), device='cuda', dtype=torch.float32)
+            xg = gen_out.prober_tuning_curve.to(torch.float32)
+            nb = xg.shape[0]
+            gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
+            gJ, gD, gS = self.gen.backward(gx, self.dynamics_cost, self.rate_cost)
+            loss = (-dmean.to(torch.float64) + self.dynamics_cost * gen_out.model_dynamics_penalty
+                    + self.rate_cost * gen_out.model_rate_penalty).reshape(1).to(torch.float32)
+            grads = torch.as_tensor(np.concatenate([gJ.ravel(), gD.ravel(), gS.ravel()]), device='cuda',
+                                    dtype=torch.float32)
+            self.reducer.mean_(grads, loss)
+            for i, name in enumerate('JDS'):                                     # wgan.py:218-260
+                p = self._gparams[name]
+                p.copy_(torch.as_tensor(getattr(self.gen, name).ravel(), dtype=torch.float32))
+                self.gen_updaters[name](p, grads[4 * i:4 * i + 4], clip=self.param_bounds[name])
+                setattr(self.gen, name, p.cpu().numpy().astype('float64').reshape(2, 2))
+            info.gen_loss = float(loss[0])
+        info.gen_forward_time = self.gen_forward_watch.sum()
+        info.gen_train_time = self.gen_train_watch.sum()
+        info.gen_time = info.gen_train_time + info.gen_forward_time
+        info.disc_time = self.disc_train_watch.sum()
+        return info
+
+    def _single_gen_step(self, gen_step, critic_iters):
+        self.gen_forward_watch = StopWatch()
+        self.gen_train_watch = StopWatch()
+        self.disc_train_watch = StopWatch()
+        for disc_step in range(critic_iters):
+            info = Namespace(is_discriminator=True, gen_step=gen_step, disc_step=disc_step)
+            info = self.train_discriminator(info)
+            yield info
+        disc_info = info
+        batch = info.batch
+        info = Namespace(is_discriminator=False, gen_step=gen_step)
+        info = self.train_generator(info, batch)       # reuses the LAST critic batch's conditions (cwgan.py:535-539)
+        logger.debug('[Loss] Acc: %-9.3g D: %-9.3g G: %-9.3g [Time] Fwd: %.3g D: %.3g G: %.3g',
+                     disc_info.accuracy, disc_info.disc_loss, info.gen_loss, self.gen_forward_watch.mean(),
+                     self.disc_train_watch.mean(), self.gen_train_watch.mean())
+        yield info
+
+    def learning(self):
+        """wgan.py:439-444: `critic_iters_init` critic steps before generator step 0, then `critic_iters`."""
+        import itertools
+        for info in self._single_gen_step(0, self.critic_iters_init):
+            yield info
+        for gen_step in itertools.count(1):
+            for info in self._single_gen_step(gen_step, self.critic_iters):
+                yield info
+
+
+def make_gan(config):
+    """make_gan(config: dict) -> (GAN, dict): build the GAN and return the unconsumed part of `config`
+    (cwgan.py:555-614).  ``config['gen']`` / ``config['disc']`` hold the trainer options with the reference's
+    names (learning_rate, update_name, dynamics_cost, rate_cost, J_min..S_max, rate_penalty_threshold;
+    layers, normalization, nonlinearity, rate_penalty_bound, ...)."""
+    kwargs = dict(DEFAULT_PARAMS, **config)
+    gen_cfg = dict(DEFAULT_PARAMS['gen'], **config.get('gen', {}))
+    disc_cfg = dict(DEFAULT_PARAMS['disc'], **config.get('disc', {}))
+    kwargs.pop('gen', None)
+    kwargs.pop('disc', None)
+    take = kwargs.pop
+
+    num_models = take('num_models')
+    probes_per_model = take('probes_per_model')
+    bandwidths = take('bandwidths')
+    contrasts = take('contrasts')
+    num_sites = take('num_sites')
+    ssn_type = take('ssn_type', 'default')
+    ssn_impl = take('ssn_impl', 'default')
+    if ssn_type != 'default' or ssn_impl != 'default':
+        raise NotImplementedError("ssn_type={!r} / ssn_impl={!r}: only the default SSN is built on the GPU path"
+                                  .format(ssn_type, ssn_impl))
+    for key in ('V0', 'V', 'dist_in', 'V_min', 'V_max'):
+        kwargs.pop(key, None)
+    reducer = GradientAllReducer()
+    local_models = num_models // reducer.world
+    gen = TuningCurveGenerator(
+        num_sites=num_sites, num_tcdom=len(bandwidths), smoothness=take('smoothness'),
+        J=take('J0'), D=take('D0'), S=take('S0'), k=take('k'), n=take('n'),
+        tau_E=take('tau_E'), tau_I=take('tau_I'), dt=take('dt'), io_type=take('io_type'),
+        seqlen=take('seqlen'), skip_steps=take('skip_steps'),
+        batchsize=local_models * probes_per_model,
+        include_rate_penalty=take('include_rate_penalty', True),
+        include_time_avg=take('include_time_avg', False),
+        unroll_scan=take('unroll_scan', False),
+        dtype=take('gen_dtype', 'float32'),
+        z_device_seed=take('z_device_seed', None))
+    rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
+    disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
+    seed = take('seed', 0)
+    disc = Critic(nx=len(bandwidths), layers=disc_cfg.pop('layers', []),
+                  normalization=disc_cfg.pop('normalization', 'none'),
+                  nonlinearity=disc_cfg.pop('nonlinearity', 'rectify'),
+                  hide_cell_type=take('hide_cell_type'),
+                  precision=disc_cfg.pop('precision', 'bf16'),
+                  seed=disc_cfg.pop('init_seed', seed))
+    disc_cfg.pop('net_options', None)
+
+    def updater_from(cfg):
+        return Updater(**{k: cfg.pop(k) for k in ('learning_rate', 'update_name', 'update_config', 'reg_l2_penalty',
+                                                   'reg_l2_decay', 'reg_l1_penalty', 'reg_l1_decay') if k in cfg})
+
+    dynamics_cost = gen_cfg.pop('dynamics_cost', 1.0)
+    rate_cost = gen_cfg.pop('rate_cost')
+    bounds = {name: (gen_cfg.pop(name + '_min', 1e-3), gen_cfg.pop(name + '_max', 10.0)) for name in 'JDS'}
+    gen_upd_cfg = {k: gen_cfg.pop(k) for k in list(gen_cfg) if k in ('learning_rate', 'update_name', 'update_config',
+                                                                     'reg_l2_penalty', 'reg_l2_decay',
+                                                                     'reg_l1_penalty', 'reg_l1_decay')}
+    gen_updaters = {name: Updater(**gen_upd_cfg) for name in 'JDS'}
+    disc_updater = updater_from(disc_cfg)
+    if gen_cfg or disc_cfg:
+        raise ValueError('Unknown trainer options: gen={} disc={}'.format(sorted(gen_cfg), sorted(disc_cfg)))
+    gan = ConditionalBPTTWassersteinGAN(
+        gen, disc, gen_updaters, disc_updater, bandwidths, contrasts,
+        norm_probes=take('norm_probes'), e_ratio=take('e_ratio'),
+        include_inhibitory_neurons=take('include_inhibitory_neurons'),
+        rate_penalty_threshold=rate_penalty_threshold,
+        num_models=num_models, probes_per_model=probes_per_model,
+        critic_iters_init=take('critic_iters_init'), critic_iters=take('critic_iters'),
+        lipschitz_cost=take('lipschitz_cost'), disc_rate_penalty_bound=disc_rate_penalty_bound,
+        dynamics_cost=dynamics_cost, rate_cost=rate_cost, param_bounds=bounds, seed=seed)
+    return gan, kwargs

@@ -1,0 +1,231 @@
+"""Tuning-curve generator based on the SSN, on the GPU.
+
+Host-side mirror of ``tc_gan/networks/ssn.py`` for the default (``ssn_type='default'``,
+``ssn_impl='default'``) generator: `BandwidthContrastStimulator` -> `EulerSSNModel` ->
+prober, bundled by `TuningCurveGenerator` / `ConditionalTuningCurveGenerator`
+(networks/cwgan.py:107-120).  The reference compiles a Theano graph
+(``forward_impl``, ssn.py:906-914); here `forward` launches the HIP kernels of
+``csrc/ssn_aux.hip`` (stimulus, W from z) and ``csrc/ssn_gen.hip`` (Euler recurrence with
+fused reductions), and `forward_backward` adds the BPTT adjoint sweep.
+
+Input and output names follow the reference (``stimulator_bandwidths``, ``model_zs``,
+``prober_model_ids`` ...; outputs ``model_dynamics_penalty``, ``model_rate_penalty``,
+[``model_time_avg``,] ``prober_tuning_curve``).
+"""
+import collections
+
+import numpy as np
+import torch
+
+from .. import clib, genops
+from ..gradient_expressions.utils import sample_sites_from_stim_space_impl
+from ..stimuli import stimulus_batch
+from ..weight_gen import generate_weight_batch
+
+ssn_impl_choices = ('default',)
+ssn_type_choices = ('default',)
+
+
+def neu_array(pop_array, num_sites, pops=None):
+    """ssn.py:60-83.
+
+    >>> neu_array([0, 1], 2)
+    array([0, 0, 1, 1])
+    """
+    pop_array = np.asarray(pop_array)
+    return np.concatenate([np.tile(pop_array[i], num_sites) for i in range(pop_array.shape[0])])
+
+
+def concat_flat(arrays):
+    flat = []
+    for a in arrays:
+        flat.extend(np.asarray(a).flat)
+    return flat
+
+
+def make_flat_param_names(named_params):
+    """ssn.py:105-123: ('J_EE', 'J_EI', 'J_IE', 'J_II', 'D_EE', ...)."""
+    names = []
+    for name, value in named_params:
+        value = np.asarray(value)
+        if value.ndim == 0:
+            names.append(name)
+        elif value.ndim == 1:
+            names.extend([name + '_E', name + '_I'])
+        elif value.ndim == 2:
+            names.extend([name + '_' + pq for pq in ('EE', 'EI', 'IE', 'II')])
+        else:
+            raise ValueError('Only ndim<=2 is supported.')
+    return tuple(names)
+
+
+class TuningCurveGenerator(object):
+    """Generator with a conditional prober (cwgan.py:72-120) or a fixed prober (ssn.py:779-851).
+
+    Parameters mirror the union of the reference components' constructor arguments
+    (stimulator: num_sites, num_tcdom, smoothness; core: J, D, S, k, n, tau_E, tau_I, dt,
+    io_type; model: seqlen, skip_steps, include_rate_penalty, include_time_avg; prober: probes).
+    """
+
+    def __init__(self, num_sites, num_tcdom, smoothness, J, D, S, k, n, tau_E, tau_I, dt, io_type,
+                 seqlen, skip_steps, batchsize, probes=None, include_rate_penalty=True,
+                 include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None):
+        clib.require_gpu()
+        self.num_sites = int(num_sites)
+        self.num_tcdom = int(num_tcdom)
+        self.smoothness = float(smoothness)
+        self.J = np.array(J, dtype='float64').reshape(2, 2)
+        self.D = np.array(D, dtype='float64').reshape(2, 2)
+        self.S = np.array(S, dtype='float64').reshape(2, 2)
+        self.k, self.n = float(k), float(n)
+        self.tau_E, self.tau_I, self.dt = float(tau_E), float(tau_I), float(dt)
+        self.io_type = io_type
+        self.seqlen, self.skip_steps = int(seqlen), int(skip_steps)
+        self.batchsize = int(batchsize)
+        self.probes = None if probes is None else np.asarray(probes, dtype=np.int64)
+        self.include_rate_penalty = include_rate_penalty
+        self.include_time_avg = include_time_avg
+        self.unroll_scan = unroll_scan            # accepted for config compatibility; no effect
+        self.dtype = dtype
+        self.tdtype = {'float32': torch.float32, 'float64': torch.float64}[dtype]
+        if not clib.libssnode.ssn_gen_supported(2 * self.num_sites, 4 if dtype == 'float32' else 8):
+            raise NotImplementedError('no generator kernel instantiation for num_sites={} ({})'
+                                      .format(num_sites, dtype))
+        names = ['model_dynamics_penalty']
+        if include_rate_penalty:
+            names.append('model_rate_penalty')
+        if include_time_avg:
+            names.append('model_time_avg')
+        names.append('prober_tuning_curve')
+        self.OutType = collections.namedtuple('OutType', names)
+        # device-side noise (perf mode): a per-generator Philox stream instead of host MT19937
+        self._zgen = None
+        if z_device_seed is not None:
+            self._zgen = torch.Generator(device='cuda')
+            self._zgen.manual_seed(int(z_device_seed))
+
+    num_neurons = property(lambda self: 2 * self.num_sites)
+    conditional = property(lambda self: self.probes is None)
+    output_shape = property(lambda self: (self.batchsize, self.num_tcdom if self.conditional
+                                          else self.num_tcdom * len(self.probes)))
+    cond_shape = property(lambda self: (self.batchsize, 3))
+
+    # -- parameters (generator.get_all_params order: J, D, S) -----------------------------
+    def get_all_params(self):
+        return [('J', self.J), ('D', self.D), ('S', self.S)]
+
+    def get_flat_param_names(self):
+        return make_flat_param_names(self.get_all_params())
+
+    def get_flat_param_values(self):
+        return concat_flat(v for _, v in self.get_all_params())
+
+    def set_params(self, params):
+        rest = dict(params)
+        for name in ('J', 'D', 'S'):
+            if name in rest:
+                setattr(self, name, np.array(rest.pop(name), dtype='float64').reshape(2, 2))
+        if rest:
+            raise ValueError('Unknown parameters: {}'.format(rest))
+
+    def gen_params(self, rate_penalty_threshold=200.0):
+        return genops.make_gen_params(io_type=self.io_type, k=self.k, n=self.n, tau_E=self.tau_E, tau_I=self.tau_I,
+                                      dt=self.dt, seqlen=self.seqlen, skip_steps=self.skip_steps,
+                                      rate_penalty_threshold=rate_penalty_threshold)
+
+    # -- noise -----------------------------------------------------------------------------
+    def gen_noise(self, rng, stimulator_bandwidths, **_):
+        """ssn.py:434-439: ``zs = rng.rand(batchsize, 2N, 2N)`` from the HOST RandomState (parity mode),
+        or a device Philox draw when the generator was built with `z_device_seed` (perf mode)."""
+        num_models = np.shape(stimulator_bandwidths)[0]
+        M = self.num_neurons
+        if self._zgen is not None:
+            return dict(model_zs=torch.rand((num_models, M, M), device='cuda', dtype=self.tdtype,
+                                            generator=self._zgen))
+        return dict(model_zs=rng.rand(num_models, M, M))
+
+    # -- forward ------------------------------------------------------------------------------
+    def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs):
+        bw = np.asarray(stimulator_bandwidths) if not torch.is_tensor(stimulator_bandwidths) else stimulator_bandwidths
+        con = np.asarray(stimulator_contrasts) if not torch.is_tensor(stimulator_contrasts) else stimulator_contrasts
+        ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
+        if torch.is_tensor(model_zs):
+            z = model_zs.to('cuda', self.tdtype).contiguous()
+        else:
+            z = torch.as_tensor(np.ascontiguousarray(model_zs)).to('cuda', self.tdtype)
+        W = generate_weight_batch(self.num_sites, self.J, self.D, self.S, z, dtype=self.dtype)
+        return ext, z, W
+
+    def _probe(self, time_avg, prober_norm_probes=None, prober_model_ids=None, prober_cell_types=None):
+        if self.conditional:
+            probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
+                                                       self.num_sites, type='uint16').astype(np.int64) \
+                + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
+            ids = torch.as_tensor(np.asarray(prober_model_ids).astype(np.int64), device='cuda')
+            pr = torch.as_tensor(probes, device='cuda')
+            return time_avg[ids, :, pr], ids, pr                                       # cwgan.py:98
+        pr = torch.as_tensor(self.probes, device='cuda')
+        tc = time_avg[:, :, pr].reshape(time_avg.shape[0], -1)                         # ssn.py:846-848
+        return tc, None, pr
+
+    def forward(self, rng=None, save=False, **kwargs):
+        """ssn.py:910-914.  Keyword inputs: stimulator_bandwidths, stimulator_contrasts (num_models, num_tcdom),
+        model_zs (optional when `rng` is given), model_rate_penalty_threshold, and for the conditional prober
+        prober_norm_probes, prober_model_ids, prober_cell_types.  Outputs are torch CUDA tensors."""
+        if rng is not None or self._zgen is not None:
+            if 'model_zs' not in kwargs:
+                kwargs.update(self.gen_noise(rng, **kwargs))
+        theta = kwargs.pop('model_rate_penalty_threshold', 200.0)
+        ext, z, W = self._device_inputs(kwargs.pop('stimulator_bandwidths'), kwargs.pop('stimulator_contrasts'),
+                                        kwargs.pop('model_zs'))
+        probe_kw = {k: kwargs.pop(k) for k in list(kwargs) if k.startswith('prober_')}
+        assert not kwargs, 'unknown inputs: {}'.format(sorted(kwargs))
+        gp = self.gen_params(theta)
+        fwd = genops.gen_forward(W, ext, gp, save=save)
+        tc, ids, pr = self._probe(fwd['time_avg'], **probe_kw)
+        vals = [fwd['dynamics_penalty']]
+        if self.include_rate_penalty:
+            vals.append(fwd['rate_penalty'])
+        if self.include_time_avg:
+            vals.append(fwd['time_avg'])
+        vals.append(tc)
+        out = self.OutType(*vals)
+        if save:
+            self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr)
+        return out
+
+    def backward(self, g_tuning_curve, dynamics_cost, rate_cost):
+        """BPTT: gradient of  sum(g_tuning_curve * tuning_curve) + dynamics_cost * dynamics_penalty
+        + rate_cost * rate_penalty  w.r.t. (J, D, S), for the last ``forward(save=True)`` call."""
+        sv = self._saved
+        fwd = sv['fwd']
+        g_ta = torch.zeros_like(fwd['time_avg'])
+        g = g_tuning_curve.to(g_ta.dtype)
+        if self.conditional:
+            # scatter-add of the probe gather (several samples may probe the same model/neuron):
+            # tuning_curve[n, :] = time_avg[ids[n], :, probes[n]]
+            g_ta.permute(0, 2, 1).index_put_((sv['ids'], sv['probes']), g, accumulate=True)
+        else:
+            g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
+        delta = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
+                                    rate_cost / fwd['n_rate'], sv['gp'])
+        gW = genops.weight_grad(delta, fwd['traj'])
+        gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S)
+        self._saved = None
+        return gJ, gD, gS
+
+    def prepare(self):
+        """Nothing to compile (the reference forces Theano compilation here)."""
+
+    def to_config(self):
+        return dict(num_sites=self.num_sites, num_tcdom=self.num_tcdom, smoothness=self.smoothness,
+                    J=self.J.tolist(), D=self.D.tolist(), S=self.S.tolist(), k=self.k, n=self.n,
+                    tau_E=self.tau_E, tau_I=self.tau_I, dt=self.dt, io_type=self.io_type,
+                    seqlen=self.seqlen, skip_steps=self.skip_steps, batchsize=self.batchsize,
+                    include_rate_penalty=self.include_rate_penalty, include_time_avg=self.include_time_avg,
+                    unroll_scan=self.unroll_scan, ssn_type='default', ssn_impl='default',
+                    **({} if self.probes is None else dict(probes=self.probes.tolist())))
+
+
+def is_heteroin(gen):
+    return False

@@ -1,0 +1,128 @@
+"""GPU tests of the conditional BPTT-WGAN assembly (tc_gan_amd/networks/cwgan.py): schedule and info
+fields (as networks/tests/test_cwgan.py:38-53), and one full critic + generator update against the fp64
+oracle with identical host RNG streams."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_torch as og
+from oracle import ssn_numpy as on
+
+pytestmark = pytest.mark.gpu
+
+JDS = on.new_JDS()
+TEST_PARAMS = dict(            # small version of networks/tests/test_wgan.py TEST_PARAMS
+    num_sites=10, seqlen=40, skip_steps=30, num_models=4, probes_per_model=2, norm_probes=[0, 0.5],
+    include_inhibitory_neurons=True, bandwidths=[0.0625, 0.125, 0.25, 0.75], contrasts=[5., 20.],
+    J0=JDS['J'], D0=JDS['D'], S0=JDS['S'], critic_iters_init=3, critic_iters=2, lipschitz_cost=10.0,
+    gen=dict(learning_rate=0.01, update_name='sgd', dynamics_cost=1.0, rate_cost=0.01,
+             rate_penalty_threshold=5.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
+    disc=dict(learning_rate=0.01, update_name='sgd', layers=[16, 16], normalization='none',
+              nonlinearity='rectify', precision='fp32'),
+)
+
+
+def _fake_data(gan, truth_size, rs):
+    ncols = len(gan.bandwidths) * len(gan.contrasts) * len(gan.norm_probes) * 2
+    return rs.rand(truth_size, ncols) * 10
+
+
+def test_schedule_and_info_fields():
+    from tc_gan_amd.networks.cwgan import make_gan
+    gan, rest = make_gan(dict(TEST_PARAMS, truth_size=7))
+    assert rest == {'truth_size': 7}
+    gan.set_dataset(_fake_data(gan, 7, np.random.RandomState(3)))
+    it = gan.learning()
+    kinds = []
+    for _ in range(3 + 1 + 2 + 1):
+        info = next(it)
+        kinds.append(info.is_discriminator)
+        if info.is_discriminator:
+            for field in ('disc_loss', 'accuracy', 'gen_time', 'disc_time', 'xd', 'xg', 'cd', 'cg',
+                          'dynamics_penalty', 'rate_penalty', 'gen_step', 'disc_step'):
+                assert hasattr(info, field), field
+            assert info.xg.shape == (8, 4) and info.cd.shape == (8, 3)
+            assert np.isfinite(info.disc_loss)
+        else:
+            for field in ('gen_loss', 'gen_forward_time', 'gen_train_time', 'gen_time', 'disc_time', 'gen_step'):
+                assert hasattr(info, field), field
+            assert np.isfinite(info.gen_loss)
+    assert kinds == [True] * 3 + [False] + [True] * 2 + [False]
+    names = gan.gen.get_flat_param_names()
+    assert names[:4] == ('J_EE', 'J_EI', 'J_IE', 'J_II') and len(names) == 12
+    assert len(gan.get_gen_param()) == 3
+    assert all(np.all(p > 0) for p in gan.get_gen_param())
+
+
+def test_one_critic_and_generator_update_vs_oracle():
+    """Same seeds -> same minibatch, eps, zs (host RandomState order of cwgan.py:471-523); compare the
+    critic loss, the post-update critic parameters, the generator loss and the post-update (J, D, S)."""
+    from tc_gan_amd.networks.cwgan import make_gan, RandomChoiceSampler
+    cfg = dict(TEST_PARAMS, critic_iters_init=1, critic_iters=1)
+    gan, _ = make_gan(cfg)
+    data = _fake_data(gan, 9, np.random.RandomState(4))
+    gan.set_dataset(data)
+    p0 = [og.t64(p) for p in gan.disc.get_param_values()]
+    it = gan.learning()
+    dinfo = next(it)
+    ginfo = next(it)
+
+    # ---- oracle replay with an identical RandomState --------------------------------------------------
+    rng = np.random.RandomState(0)
+    sampler = RandomChoiceSampler.from_grid_data(data, bandwidths=gan.bandwidths, contrasts=gan.contrasts,
+                                                 norm_probes=gan.norm_probes, e_ratio=gan.e_ratio,
+                                                 include_inhibitory_neurons=True, seed=rng)
+    batch = sampler.select_minibatch(4, 2)
+    eps = og.t64(rng.rand(batch.batchsize, 1))
+    N = 10
+    kw = batch.gen_kwargs
+    zs = og.t64(rng.rand(4, 2 * N, 2 * N))
+    gen_common = dict(num_sites=N, smoothness=on.DEFAULT_PARAMS['smoothness'], io_type='asym_tanh', k=0.01, n=2.2,
+                      tau_E=10., tau_I=1., dt=0.1, seqlen=40, skip_steps=30, rate_penalty_threshold=5.0,
+                      dynamics_cost=1.0, rate_cost=0.01)
+    J, D, S = (og.t64(JDS[k]) for k in 'JDS')
+    _, aux = og.generator_loss(J, D, S, zs, kw['stimulator_bandwidths'], kw['stimulator_contrasts'],
+                               kw['prober_model_ids'], kw['prober_norm_probes'], kw['prober_cell_types'], p0,
+                               **gen_common)
+    xg = aux['tuning_curve'].detach()
+    xd = og.t64(batch.tuning_curves)
+    cd = og.t64(batch.conditions)
+    np.testing.assert_allclose(dinfo.xg.cpu().numpy(), xg.numpy(), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(dinfo.xd.cpu().numpy(), xd.numpy(), rtol=1e-6)
+    xp = eps * xd + (1 - eps) * xg
+    ps = [p.clone().requires_grad_(True) for p in p0]
+    dloss = og.critic_loss(ps, xg, xd, xp, cd, cd, cd, 10.0)
+    dgr = torch.autograd.grad(dloss, ps)
+    np.testing.assert_allclose(dinfo.disc_loss, float(dloss), rtol=1e-3, atol=1e-4)
+    p1 = [p - 0.01 * g for p, g in zip(p0, dgr)]                 # sgd
+    got1 = gan.disc.get_param_values()
+    # (the generator step below does not change the critic)
+    for a, b in zip(got1, p1):
+        np.testing.assert_allclose(a, b.numpy(), rtol=2e-3, atol=2e-5)
+    acc = og.critic_forward(p1, xg, cd).mean() - og.critic_forward(p1, xd, cd).mean()
+    np.testing.assert_allclose(dinfo.accuracy, float(acc), rtol=1e-3, atol=1e-4)
+
+    # generator step: new zs, same batch conditions, updated critic
+    zs2 = og.t64(rng.rand(4, 2 * N, 2 * N))
+    Jg, Dg, Sg = (og.t64(JDS[k]).clone().requires_grad_(True) for k in 'JDS')
+    gloss, _ = og.generator_loss(Jg, Dg, Sg, zs2, kw['stimulator_bandwidths'], kw['stimulator_contrasts'],
+                                 kw['prober_model_ids'], kw['prober_norm_probes'], kw['prober_cell_types'], p1,
+                                 **gen_common)
+    gJ, gD, gS = torch.autograd.grad(gloss, [Jg, Dg, Sg])
+    np.testing.assert_allclose(ginfo.gen_loss, float(gloss), rtol=1e-3, atol=1e-4)
+    for name, g in (('J', gJ), ('D', gD), ('S', gS)):
+        want = np.clip(JDS[name] - 0.01 * g.numpy(), 1e-3, 10)
+        got = getattr(gan.gen, name)
+        np.testing.assert_allclose(got - JDS[name], want - JDS[name], rtol=5e-3, atol=5e-3 * np.abs(want - JDS[name]).max())
+
+
+def test_device_noise_mode_runs_and_rate_bound_skips_critic():
+    from tc_gan_amd.networks.cwgan import make_gan
+    cfg = dict(TEST_PARAMS, z_device_seed=123)
+    cfg['disc'] = dict(cfg['disc'], rate_penalty_bound=1e-9)     # any positive rate penalty skips the update
+    gan, _ = make_gan(cfg)
+    gan.set_dataset(_fake_data(gan, 5, np.random.RandomState(1)))
+    before = gan.disc.get_flat().copy()
+    info = next(gan.learning())
+    assert info.is_discriminator and np.isnan(info.disc_loss) and np.isnan(info.accuracy)
+    np.testing.assert_array_equal(gan.disc.get_flat(), before)
