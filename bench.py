@@ -93,12 +93,108 @@ def cpu_baseline(N, NB, T, sample_B, threads):
                        (sample_B, NB, T, M, threads, best))
 
 
+def run_c3(args, rank, world, local_rank):
+    """BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
+    updates (each with a fresh generator forward) + one generator BPTT update; 1024 weight draws x 8
+    bandwidths per GPU, 2N=200, seqlen 1200 / skip 1000, 3x512 critic on bf16 MFMA, adam-wgan.
+    N>1: num_models = 1024*N sharded 1024 per rank, one RCCL all-reduce per update (weak scaling);
+    value = N x iterations/s, i.e. 1024-model GAN iterations per second over the whole job."""
+    import torch
+    import torch.distributed as dist
+    from tc_gan_amd.networks.cwgan import make_gan
+    J, D, S = new_jds()
+    N, models, NB, T, skip = 100, 1024, 8, 1200, 1000
+    bandwidths = [0, 0.0625, 0.125, 0.1875, 0.25, 0.5, 0.75, 1]
+    cfg = dict(num_sites=N, num_models=models * world, probes_per_model=1, norm_probes=[0.0],
+               include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
+               seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=5, critic_iters=5,
+               lipschitz_cost=10.0, z_device_seed=4321 + rank,
+               gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
+                        rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
+               disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
+                         nonlinearity='rectify', precision='bf16'))
+    gan, _ = make_gan(cfg)
+    # truth: 2048 curves from the generator itself at the true parameters (dataset_by_fixedtime), seed 42
+    rs = np.random.RandomState(42)
+    truth = []
+    for _ in range(2):
+        bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
+        out = gan.gen.forward(rng=rs, stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0),
+                              prober_norm_probes=np.zeros(models), prober_model_ids=np.arange(models),
+                              prober_cell_types=np.zeros(models))
+        truth.append(out.prober_tuning_curve.cpu().numpy())
+    gan.set_dataset(np.concatenate(truth))
+    it = gan.learning()
+
+    def one_iter():
+        while True:
+            info = next(it)
+            if not info.is_discriminator:
+                return info
+
+    for _ in range(args.warmup):
+        one_iter()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = one_iter()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.isfinite(info.gen_loss)
+    # dominant kernel: gen_forward_kernel, timed alone with HIP events on the launch stream
+    bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
+    kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
+              prober_model_ids=np.arange(models), prober_cell_types=np.zeros(models))
+    from tc_gan_amd import genops
+    ext, z, W = gan.gen._device_inputs(bw, kw['stimulator_contrasts'], gan.gen.gen_noise(None, bw)['model_zs'])
+    gp = gan.gen.gen_params(200.0)
+    genops.gen_forward(W, ext, gp)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        genops.gen_forward(W, ext, gp)
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms = e0.elapsed_time(e1) / 3
+    M = 2 * N
+    units = float(M) * models * NB * T                     # neuron-steps of one generator forward (per rank)
+    achieved = units * (2 * M + 8) / (kernel_ms * 1e-3) * 1e-12
+    iters_per_s = args.steps / elapsed
+    out = {
+        'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '1024-model GAN iterations/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (critic GEMMs bf16)',
+        'data': 'synthetic',
+        'config': {'workload': 'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
+                               '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
+                               'device-side z (Philox)', 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
+        'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': None, 'kernel': 'gen_forward_kernel',
+                     'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8,
+                     'ssn_steps_per_s_in_loop': 7 * units * iters_per_s * world},
+        'last_gen_loss': info.gen_loss,
+    }
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3'])
     ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 register-stationary tile')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
@@ -121,6 +217,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
+    if args.workload == 'c3':
+        return run_c3(args, rank, world, local_rank)
     N, B, NB, T, desc = WORKLOADS[args.workload]
     M = 2 * N
     J, D, S = new_jds()

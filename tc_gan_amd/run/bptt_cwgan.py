@@ -1,0 +1,57 @@
+"""
+Run SSN-BPTT conditional Wasserstein GAN learning on MI355X.
+
+Mirror of ``tc_gan/run/bptt_cwgan.py``: same options, same config flow
+(argparse -> run_config -> preprocess -> info.json -> init_driver -> learn), same outputs.
+"""
+from logging import getLogger
+
+from . import bptt_wgan
+from .. import utils
+from ..drivers import BPTTcWGANDriver
+from ..networks.cwgan import make_gan
+from .bptt_wgan import learn, do_learning
+
+logger = getLogger(__name__)
+
+
+def make_parser():
+    import argparse
+
+    class CustomFormatter(argparse.RawDescriptionHelpFormatter, argparse.ArgumentDefaultsHelpFormatter):
+        pass
+
+    parser = argparse.ArgumentParser(formatter_class=CustomFormatter, description=__doc__)
+    parser.add_argument('--num-models', default=15, type=int, help='Number of SSN to be instantiated (aka NZ).')
+    parser.add_argument('--probes-per-model', default=1, type=int)
+    parser.add_argument('--norm-probes', '--sample-sites', default=[0], type=utils.csv_line(float),
+                        help='Probe offsets in [-1, 1] "bandwidth coordinate".')
+    parser.add_argument('--tc-stats-record-interval', default=100, type=int)
+    bptt_wgan.add_bptt_common_options(parser)
+    bptt_wgan.add_learning_options(parser)
+    parser.set_defaults(datastore_template='logfiles/BPTT_CWGAN_{layers_str}')
+    return parser
+
+
+def init_driver(datastore, iterations, quit_JDS_threshold, quiet, tc_stats_record_interval,
+                disc_param_save_interval, disc_param_template, disc_param_save_on_error, layers, **run_config):
+    del layers                       # only used for the datastore name (execution.format_datastore)
+    run_config = utils.subdict_by_prefix(run_config, 'disc_')
+    run_config = utils.subdict_by_prefix(run_config, 'gen_')
+    gan, rest = make_gan(run_config)
+    driver = BPTTcWGANDriver(
+        gan, datastore, iterations=iterations, quiet=quiet, tc_stats_record_interval=tc_stats_record_interval,
+        disc_param_save_interval=disc_param_save_interval, disc_param_template=disc_param_template,
+        disc_param_save_on_error=disc_param_save_on_error, quit_JDS_threshold=quit_JDS_threshold)
+    return dict(driver=driver, **rest)
+
+
+def main(args=None):
+    parser = make_parser()
+    ns = parser.parse_args(args)
+    ns.layers = ns.disc_layers
+    do_learning(learn, vars(ns), init_driver=init_driver, script_file=__file__)
+
+
+if __name__ == '__main__':
+    main()

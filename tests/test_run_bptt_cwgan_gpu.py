@@ -1,0 +1,70 @@
+"""CLI integration on the GPU, after run/tests/test_bptt_cwgan.py:7-51 + test_bptt_wgan.py:12-105: one
+generator step through ``main([...])`` in a scratch directory; checks info.json, exit.json, truth.npy, the typed
+tables and their column names."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _load_tables(directory, store):
+    path_h5 = os.path.join(directory, store + '.hdf5')
+    if os.path.exists(path_h5):
+        import h5py
+        with h5py.File(path_h5, 'r') as f:
+            return {k: f[k][...] for k in f}
+    return dict(np.load(os.path.join(directory, store + '.npz')))
+
+
+@pytest.mark.parametrize('args', [
+    [],
+    ['--num-models', '1'],
+    ['--sample-sites', '0, 0.5', '--probes-per-model', '2'],
+    ['--contrasts', '5, 20'],
+    ['--include-inhibitory-neurons', '--dataset-provider', 'fixedtime'],
+])
+def test_single_g_step(args, tmp_path, monkeypatch):
+    from tc_gan_amd.run import bptt_cwgan
+    monkeypatch.chdir(tmp_path)
+    bptt_cwgan.main(['--iterations', '1', '--truth_size', '1', '--num-models', '2', '--n_bandwidths', '1',
+                     '--WGAN_n_critic0', '1', '--seqlen', '4', '--skip-steps', '2',
+                     '--tc-stats-record-interval', '1', '--datastore', 'results', '--disc-layers', '[8]',
+                     '--J0', '0.1', '--D0', '0.05', '--S0', '0.1', '--quiet'] + args)
+    out = tmp_path / 'results'
+    info = json.load(open(out / 'info.json'))
+    assert info['extra_info']['script_file'] == bptt_cwgan.__file__
+    assert info['run_config']['bandwidths'] == [0.0625]
+    assert 'true_ssn_options' in info['run_config']
+    assert json.load(open(out / 'exit.json')) == dict(reason='end_of_iteration', good=True)
+    assert np.load(out / 'truth.npy').shape[0] == 1
+    tables = _load_tables(str(out), 'store')
+    assert set(tables) == {'learning', 'disc_learning', 'generator', 'disc_param_stats'}
+    assert tables['learning'].dtype.names == ('gen_step', 'Gloss', 'Dloss', 'Daccuracy', 'gen_forward_time',
+                                              'gen_train_time', 'disc_time', 'rate_penalty', 'dynamics_penalty')
+    assert tables['generator'].dtype.names == ('gen_step', 'J_EE', 'J_EI', 'J_IE', 'J_II', 'D_EE', 'D_EI', 'D_IE',
+                                               'D_II', 'S_EE', 'S_EI', 'S_IE', 'S_II')
+    assert len(tables['learning']) == 1 and len(tables['disc_learning']) == 1
+    assert np.isfinite(tables['learning']['Gloss']).all()
+    tc = _load_tables(str(out), 'tc_stats')['tc_stats']
+    assert tc.dtype.names[:6] == ('gen_step', 'is_fake', 'contrast', 'norm_probe', 'cell_type', 'count')
+    assert set(tc['is_fake']) == {0, 1}
+    assert os.path.exists(out / 'TC_mean.csv')
+    assert os.path.exists(out / 'disc_param' / 'last.npz')
+    npz = np.load(out / 'disc_param' / 'last.npz')
+    assert int(npz['version']) == 1 and list(npz['param_names']) == ['W', 'b', 'W']
+
+
+def test_known_error_exit_code(tmp_path, monkeypatch):
+    """--quit-JDS-threshold tiny -> KnownError(exit_code=4) and exit.json with reason JDS_distance
+    (drivers.py:183-198), surfaced as the process exit code by run.py."""
+    import run as run_script
+    monkeypatch.chdir(tmp_path)
+    code = run_script.main(['tc_gan.run.bptt_cwgan', '--', '--iterations', '2', '--truth_size', '1', '--num-models', '1',
+                            '--n_bandwidths', '1', '--WGAN_n_critic0', '1', '--seqlen', '4', '--skip-steps', '2',
+                            '--datastore', 'results', '--quit-JDS-threshold', '1e-9', '--quiet',
+                            '--dataset-provider', 'fixedtime'])
+    assert code == 4
+    assert json.load(open(tmp_path / 'results' / 'exit.json'))['reason'] == 'JDS_distance'
