@@ -211,11 +211,14 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+    # BENCH_DIST_BACKEND=gloo lets several ranks share ONE card to rehearse the N>1 code path (never a result)
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+    local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_rank)
     clib.require_gpu()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.workload == 'c3':
         return run_c3(args, rank, world, local_rank)

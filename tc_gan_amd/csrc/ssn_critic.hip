@@ -48,6 +48,7 @@ struct GemmArgs {
     const float* bias;                 // [N]          (BIAS_RELU)
     const float* mask; long ldm;       // [M][ldm] > 0 (MASK): C = acc * (mask > 0)
     int epilogue;
+    int kchunk;                        // K range per blockIdx.z (split-K; PLAIN with beta == 1 only)
 };
 
 template <bool BF16>
@@ -66,21 +67,23 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         // ---- stage op(A)[m0:m0+64][k0:k0+BK] and op(B)[k0:k0+BK][n0:n0+64] ----------------
         for (int e = tid; e < BM * BK; e += 256) {
             // make the index that is contiguous in memory the fastest-varying one
             int mi, ki;
             if (g.sak == 1) { ki = e % BK; mi = e / BK; } else { mi = e % BM; ki = e / BM; }
             const int m = m0 + mi, k = k0 + ki;
-            const float v = (m < g.M && k < g.K) ? g.A[m * g.sam + k * g.sak] : 0.f;
+            const float v = (m < g.M && k < kend) ? g.A[m * g.sam + k * g.sak] : 0.f;
             if constexpr (BF16) As16[mi][ki] = to_bf16(v); else As32[mi][ki] = v;
         }
         for (int e = tid; e < BN * BK; e += 256) {
             int ni, ki;
             if (g.sbk == 1) { ki = e % BK; ni = e / BK; } else { ni = e % BN; ki = e / BN; }
             const int n = n0 + ni, k = k0 + ki;
-            const float v = (n < g.N && k < g.K) ? g.B[k * g.sbk + n * g.sbn] : 0.f;
+            const float v = (n < g.N && k < kend) ? g.B[k * g.sbk + n * g.sbn] : 0.f;
             if constexpr (BF16) Bs16[ni][ki] = to_bf16(v); else Bs32[ni][ki] = v;
         }
         __syncthreads();
@@ -113,15 +116,29 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
             float* c = g.C + m * g.ldc + n;
             if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : 0.f; }
             else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : 0.f; }
+            else if (gridDim.z > 1) { atomicAdd(c, g.alpha * v); continue; }      // split-K partial (beta == 1)
             else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
             *c = v;
         }
     }
 }
 
-static hipError_t gemm(const GemmArgs& g, bool bf16, hipStream_t st) {
+static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    dim3 grid((g.N + 63) / 64, (g.M + 63) / 64);
+    // Weight-gradient GEMMs contract over the batch (K = 1024..2048) into a small M x N: few output tiles,
+    // long K loop.  Split K over blockIdx.z (fp32 atomics into the accumulating gradient) to fill the chip.
+    int splits = 1;
+    const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
+    if (g.epilogue == EPI_PLAIN && g.beta == 1.f && g.K >= 512 && tiles < 256) {
+        splits = (512 + tiles - 1) / tiles;
+        const int maxs = g.K / 128;
+        if (splits > maxs) splits = maxs;
+        if (splits < 1) splits = 1;
+    }
+    const int bk = bf16 ? 32 : 16;
+    g.kchunk = ((g.K + splits - 1) / splits + bk - 1) / bk * bk;
+    splits = (g.K + g.kchunk - 1) / g.kchunk;
+    dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
     if (bf16) hipLaunchKernelGGL((gemm_mfma_kernel<true>), grid, dim3(256), 0, st, g);
     else      hipLaunchKernelGGL((gemm_mfma_kernel<false>), grid, dim3(256), 0, st, g);
     return hipGetLastError();
