@@ -1,0 +1,79 @@
+"""Data-parallel equivalence on the GPU: two ranks (gloo, sharing the one card of the test box) training
+with host-side noise must follow the single-process run -- same minibatches, same z rows per model, one
+averaged gradient per update."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _config():
+    sys.path.insert(0, ROOT)
+    from oracle import ssn_numpy as on          # parameters only
+    jds = on.new_JDS()
+    return dict(
+        num_sites=10, seqlen=40, skip_steps=30, num_models=4, probes_per_model=2, norm_probes=[0, 0.5],
+        include_inhibitory_neurons=True, bandwidths=[0.0625, 0.125, 0.25, 0.75], contrasts=[5., 20.],
+        J0=jds['J'], D0=jds['D'], S0=jds['S'], critic_iters_init=2, critic_iters=2, lipschitz_cost=10.0,
+        gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
+                 rate_penalty_threshold=5.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
+        disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[16, 16], normalization='none',
+                  nonlinearity='rectify', precision='fp32'))
+
+
+def _train(n_gen_steps=2):
+    from tc_gan_amd.networks.cwgan import make_gan
+    gan, _ = make_gan(_config())
+    data = np.random.RandomState(4).rand(9, 4 * 2 * 2 * 2) * 10
+    gan.set_dataset(data)
+    it = gan.learning()
+    losses = []
+    done = 0
+    while done < n_gen_steps:
+        info = next(it)
+        if info.is_discriminator:
+            losses.append(info.disc_loss)
+        else:
+            losses.append(info.gen_loss)
+            done += 1
+    return np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses)
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    res = _train()
+    out.put((rank,) + res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_follow_the_single_process_run():
+    sys.path.insert(0, ROOT)
+    jds1, critic1, losses1 = _train()
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 29700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(res[r][3], losses1, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
+    np.testing.assert_array_equal(res[0][2], res[1][2])          # replicas stay bit-identical
+    np.testing.assert_array_equal(res[0][1], res[1][1])
