@@ -189,12 +189,66 @@ def run_c3(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def run_c5(args, rank, world, local_rank):
+    """BASELINE config 5: the FF_lalazar feed-forward generator (get_FF_output), box_width 40 (64000 grid
+    points), 27 stimuli, 1 hidden unit, 16384 samples per GPU; synthetic inputs as generate_samples draws them
+    (uniform widths / strengths, 1 % connectivity).  One step = one forward over the batch.  HBM-bound:
+    12 B per (sample, grid point)."""
+    import torch
+    import torch.distributed as dist
+    from tc_gan_amd import ff_model
+    nsam, box, nhid = 16384, 40, 1
+    G = box ** 3
+    gen = torch.Generator(device='cuda'); gen.manual_seed(99 + rank)
+    wid = torch.rand((nsam, G), device='cuda', generator=gen)
+    con = (torch.rand((nsam, nhid, G), device='cuda', generator=gen) < 0.01).float()
+    strn = torch.rand((nsam, nhid, G), device='cuda', generator=gen)
+    ths = torch.rand((nsam, nhid), device='cuda', generator=gen) * 2 - 1
+    stim = ff_model.default_stimuli()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(args.warmup):
+        out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
+        ev[k][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out).all())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    bytes_alg = float(nsam) * nhid * G * 12
+    achieved = bytes_alg / (kernel_ms * 1e-3) * 1e-9
+    res = {'metric': 'FF tuning curves/sec', 'value': nsam * args.steps * world / elapsed, 'unit': 'samples (27-point curves)/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'C5: FF_lalazar get_FF_output, box_width 40 (64000 points), 27 stimuli, 1 hidden unit, '
+                                  '16384 samples per GPU', 'parallelism': 'samples sharded over %d GPU(s)' % world},
+           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                        'traffic': None, 'kernel': 'ff_forward_kernel', 'kernel_ms': kernel_ms,
+                        'algorithmic_hbm_bytes': bytes_alg}}
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3'])
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c5'])
     ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 register-stationary tile')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
@@ -222,6 +276,8 @@ def main():
 
     if args.workload == 'c3':
         return run_c3(args, rank, world, local_rank)
+    if args.workload == 'c5':
+        return run_c5(args, rank, world, local_rank)
     N, B, NB, T, desc = WORKLOADS[args.workload]
     M = 2 * N
     J, D, S = new_jds()

@@ -247,6 +247,26 @@ typedef struct ssn_opt_params {
 /* In-place update of p[n] from g[n]; s1, s2 optimizer state (adam: m, v; rmsprop: s1 only; sgd: unused). */
 int ssn_optimizer_step(float *p, const float *g, float *s1, float *s2, long n, const ssn_opt_params *o, void *stream);
 
+/* ------------------------------------------------------------------------
+ * 5. Feed-forward tuning-curve generator (FF_lalazar model; BASELINE config 5): replaces the Theano
+ *    graph of FF_functions/lalazar_func.py:16-45 (get_FF_output) compiled at
+ *    FF_lalazar_model.py:175-179.  Grid = box^3 points of linspace(-3, 3, box)^3, z fastest.
+ * ------------------------------------------------------------------------ */
+typedef struct ssn_ff_params {
+    int nsam, nhid, ni, box;
+    double RF_l, RF_d, TH, TH_d, J, a;   /* already exponentiated where the model script does (FF_lalazar_model.py:175) */
+} ssn_ff_params;
+/* out[nsam][ni][nhid] = relu(sum_g e w / sum_g e - thr).  RF_w [nsam][G], FF_con/FF_str [nsam][nhid][G],
+ * TH_sam [nsam][nhid], stim [ni][3] (ni <= 32), all device fp32.  q, den [nsam][ni][nhid] optional (NULL):
+ * pre-threshold drive and sum_g e, kept for the backward. */
+int ssn_ff_forward_f32(const float *RF_w, const float *FF_con, const float *FF_str, const float *TH_sam,
+                       const float *stim, float *out, float *q, float *den, const ssn_ff_params *p, void *stream);
+/* dsig[nsam][nhid][2] = per-sample partial derivatives of L w.r.t. RF_l and RF_d, given gq[nsam][ni][nhid] =
+ * dL/d(drive) (upstream gradient times [out > 0]) and the forward's q, den. */
+int ssn_ff_backward_f32(const float *RF_w, const float *FF_con, const float *FF_str, const float *stim,
+                        const float *q, const float *den, const float *gq, float *dsig,
+                        const ssn_ff_params *p, void *stream);
+
 /* I/O nonlinearity on arrays (device pointers), the device function the solver
  * kernels use: out[i] = io(v[i]).  p->k, n, rate_soft_bound, rate_hard_bound,
  * io_type are read; for SSN_IO_* semantics see ssnode.c:25-53. */

@@ -164,6 +164,18 @@ libssnode.ssn_optimizer_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p,
 for _name in ('ssn_critic_forward', 'ssn_critic_loss_grad', 'ssn_critic_input_grad', 'ssn_optimizer_step'):
     getattr(libssnode, _name).restype = c_int
 
+class FFParams(Structure):
+    """``ssn_ff_params`` of include/ssnode_mi355x.h."""
+    _fields_ = [('nsam', c_int), ('nhid', c_int), ('ni', c_int), ('box', c_int),
+                ('RF_l', c_double), ('RF_d', c_double), ('TH', c_double), ('TH_d', c_double),
+                ('J', c_double), ('a', c_double)]
+
+
+libssnode.ssn_ff_forward_f32.argtypes = [c_void_p] * 8 + [POINTER(FFParams), c_void_p]
+libssnode.ssn_ff_forward_f32.restype = c_int
+libssnode.ssn_ff_backward_f32.argtypes = [c_void_p] * 8 + [POINTER(FFParams), c_void_p]
+libssnode.ssn_ff_backward_f32.restype = c_int
+
 #: every symbol include/ssnode_mi355x.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = (
     'solve_dynamics_asym_power_euler', 'solve_dynamics_asym_linear_euler', 'solve_dynamics_asym_tanh_euler',
@@ -177,6 +189,7 @@ DECLARED_SYMBOLS = (
     'ssn_gen_backward_f32', 'ssn_gen_backward_f64', 'ssn_jds_grad_f32', 'ssn_jds_grad_f64',
     'ssn_critic_num_params', 'ssn_critic_workspace_floats', 'ssn_critic_forward', 'ssn_critic_loss_grad',
     'ssn_critic_input_grad', 'ssn_optimizer_step',
+    'ssn_ff_forward_f32', 'ssn_ff_backward_f32',
 )
 
 

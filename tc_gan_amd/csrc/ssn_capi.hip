@@ -243,6 +243,50 @@ int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, c
     return 0;
 }
 
+static ssn::FFArgs ff_args(const ssn_ff_params& p) {
+    ssn::FFArgs a{};
+    a.nsam = p.nsam; a.nhid = p.nhid; a.ni = p.ni; a.box = p.box;
+    a.RF_l = (float)p.RF_l; a.RF_d = (float)p.RF_d; a.TH = (float)p.TH; a.TH_d = (float)p.TH_d;
+    a.J = (float)p.J; a.a = (float)p.a;
+    return a;
+}
+int ssn_ff_forward_f32(const float* RF_w, const float* FF_con, const float* FF_str, const float* TH_sam,
+                       const float* stim, float* out, float* q, float* den, const ssn_ff_params* p, void* stream) {
+    if (!p || p->nsam < 0 || p->nhid < 1 || p->ni < 1 || p->ni > 32 || p->box < 1 || (q == nullptr) != (den == nullptr)) {
+        g_last_error = "ssn_ff_forward: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::FFArgs a = ff_args(*p);
+    a.RF_w = RF_w; a.FF_con = FF_con; a.FF_str = FF_str; a.TH_sam = TH_sam; a.stim = stim; a.out = out; a.q = q; a.den = den;
+    // Is the stimulus set a 3 x 3 x 3 product lattice in the model script's order?  (27 x 3 floats: read back once.)
+    ssn::FFLattice lat;
+    bool lattice = false;
+    if (p->ni == 27) {
+        float hs[27][3];
+        if (hipMemcpyAsync(hs, stim, sizeof(hs), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
+            hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
+            for (int k = 0; k < 3; ++k) { lat.x[k] = hs[9 * k][0]; lat.y[k] = hs[3 * k][1]; lat.z[k] = hs[k][2]; }
+            lattice = true;
+            for (int i = 0; i < 27 && lattice; ++i)
+                lattice = hs[i][0] == lat.x[i / 9] && hs[i][1] == lat.y[(i / 3) % 3] && hs[i][2] == lat.z[i % 3];
+        }
+    }
+    SSN_TRY(ssn::launch_ff_forward(a, lattice ? &lat : nullptr, (hipStream_t)stream));
+    return 0;
+}
+int ssn_ff_backward_f32(const float* RF_w, const float* FF_con, const float* FF_str, const float* stim, const float* q,
+                        const float* den, const float* gq, float* dsig, const ssn_ff_params* p, void* stream) {
+    if (!p || p->nsam < 0 || p->nhid < 1 || p->ni < 1 || p->ni > 32 || p->box < 1 || !q || !den || !gq || !dsig) {
+        g_last_error = "ssn_ff_backward: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::FFArgs a = ff_args(*p);
+    a.RF_w = RF_w; a.FF_con = FF_con; a.FF_str = FF_str; a.stim = stim;
+    a.q = const_cast<float*>(q); a.den = const_cast<float*>(den);
+    SSN_TRY(ssn::launch_ff_backward(a, gq, dsig, (hipStream_t)stream));
+    return 0;
+}
+
 int ssn_gen_supported(int M, int dtype_bytes) {
     if (M <= 0 || (M & 1)) return 0;
     return dtype_bytes == 8 ? ssn::gen_supported<double>(M) : ssn::gen_supported<float>(M);

@@ -80,6 +80,23 @@ hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, 
                              int hide_cell_type, float scale, float* gx, float* stats, float* ws, bool bf16, hipStream_t st);
 hipError_t optimizer_step(const OptArgs& o, hipStream_t st);
 
+// ssn_ff.hip
+struct FFArgs {
+    const float* RF_w;     // [nsam][G]
+    const float* FF_con;   // [nsam][nhid][G]
+    const float* FF_str;   // [nsam][nhid][G]
+    const float* TH_sam;   // [nsam][nhid]
+    const float* stim;     // [ni][3]
+    float* out;            // [nsam][ni][nhid]
+    float* q;              // [nsam][ni][nhid] or nullptr: pre-threshold drive
+    float* den;            // [nsam][ni][nhid] or nullptr: sum_g e
+    int nsam, nhid, ni, box;
+    float RF_l, RF_d, TH, TH_d, J, a;
+};
+struct FFLattice { float x[3], y[3], z[3]; };      // stimuli = {x} x {y} x {z}, i = (a*3 + b)*3 + c
+hipError_t launch_ff_forward(const FFArgs& a, const FFLattice* lat, hipStream_t st);
+hipError_t launch_ff_backward(const FFArgs& a, const float* gq, float* dsig, hipStream_t st);
+
 // ssn_aux.hip
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, T* ext, int B, int NB, int N, hipStream_t st);
