@@ -196,6 +196,12 @@ int ssn_gen_backward_f32(const float *W, const float *traj, float *df_delta, con
                          double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
 int ssn_gen_backward_f64(const double *W, const double *traj, double *df_delta, const double *g_time_avg,
                          double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
+/* Same sweep, additionally writing g_ext[B][NB][M] = dL/d ext = sum_t delta_t (gradient path of the
+ * input-variability parameter V of the heterogeneous-input SSN). */
+int ssn_gen_backward_ext_f32(const float *W, const float *traj, float *df_delta, const float *g_time_avg, float *g_ext,
+                             double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
+int ssn_gen_backward_ext_f64(const double *W, const double *traj, double *df_delta, const double *g_time_avg, double *g_ext,
+                             double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
 /*
  * Chain rule W -> (J, D, S) of make_W_with_x (make_w_batch.py:19-34): out[b][pq][0..2] =
  * partial dL/dJ_pq, dL/dD_pq, dL/dS_pq of draw b (device fp64 [B][4][3]; sum over b on the caller's
@@ -266,6 +272,13 @@ int ssn_ff_forward_f32(const float *RF_w, const float *FF_con, const float *FF_s
 int ssn_ff_backward_f32(const float *RF_w, const float *FF_con, const float *FF_str, const float *stim,
                         const float *q, const float *den, const float *gq, float *dsig,
                         const ssn_ff_params *p, void *stream);
+
+/* Heterogeneous-input variant (networks/ssn.py:645-772): ext *= amp[b][m], amp = 1 + v_pop * z_in,
+ * device [B][2N] (NULL = homogeneous). */
+int ssn_stimulus_amp_f32(const float *bandwidths, const float *contrasts, float smoothness, const float *amp,
+                         float *ext, int B, int NB, int N, void *stream);
+int ssn_stimulus_amp_f64(const double *bandwidths, const double *contrasts, double smoothness, const double *amp,
+                         double *ext, int B, int NB, int N, void *stream);
 
 /* I/O nonlinearity on arrays (device pointers), the device function the solver
  * kernels use: out[i] = io(v[i]).  p->k, n, rate_soft_bound, rate_hard_bound,

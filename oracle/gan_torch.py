@@ -162,11 +162,16 @@ def glorot_uniform(rng, fan_in, fan_out):
 # ------------------------------------------------------------------ generator loss
 def generator_loss(J, D, S, z, bandwidths, contrasts, model_ids, norm_probes, cell_types, critic_params,
                    num_sites, smoothness, io_type, k, n, tau_E, tau_I, dt, seqlen, skip_steps,
-                   rate_penalty_threshold, dynamics_cost, rate_cost, critic_kw=None):
+                   rate_penalty_threshold, dynamics_cost, rate_cost, critic_kw=None, V=None, zs_in=None):
     """wgan.py:236-241: -mean D(G(z)) + dynamics_cost * dyn_pen + rate_cost * rate_pen, with the
     conditional generator output of cwgan.py:107-120 (conditions = contrast, norm_probe, cell_type)."""
     critic_kw = critic_kw or {}
     ext = stimulus(bandwidths, contrasts, smoothness, num_sites)
+    if V is not None:
+        # networks/ssn.py:679-686: stimulus * (1 + v_pop z_in); V of shape (2,) ('heteroin') or () ('deg-heteroin')
+        vpop = V if V.dim() == 1 else torch.stack([V, V])
+        vs = torch.cat([vpop[0].expand(num_sites), vpop[1].expand(num_sites)])
+        ext = (1 + vs.reshape(1, 1, -1) * t64(zs_in)[:, None, :]) * ext
     W = make_W(z, J, D, S, num_sites)
     ta, dyn, rate = euler_ssn(W, ext, io_type, k, n, tau_E, tau_I, dt, seqlen, skip_steps, rate_penalty_threshold)
     probes = probes_from_norm(norm_probes, cell_types, num_sites)

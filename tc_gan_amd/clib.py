@@ -104,6 +104,10 @@ libssnode.ssn_build_w_f64.argtypes = [c_void_p, POINTER(c_double), POINTER(c_dou
                                       c_void_p, c_int, c_int, c_void_p]
 libssnode.ssn_stimulus_f32.argtypes = [c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_void_p]
 libssnode.ssn_stimulus_f64.argtypes = [c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_amp_f32.argtypes = [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_amp_f64.argtypes = [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_amp_f32.restype = c_int
+libssnode.ssn_stimulus_amp_f64.restype = c_int
 libssnode.ssn_io_eval_f32.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
 libssnode.ssn_io_eval_f64.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
 for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
@@ -129,6 +133,9 @@ for _name in ('ssn_gen_forward_f32', 'ssn_gen_forward_f64'):
     getattr(libssnode, _name).restype = c_int
 for _name in ('ssn_gen_backward_f32', 'ssn_gen_backward_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p] * 4 + [c_double, c_double, c_int, c_int, c_int, _gp, c_void_p]
+    getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p] * 5 + [c_double, c_double, c_int, c_int, c_int, _gp, c_void_p]
     getattr(libssnode, _name).restype = c_int
 libssnode.ssn_jds_grad_f32.argtypes = [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float),
                                        c_void_p, c_int, c_int, c_void_p]
@@ -190,6 +197,7 @@ DECLARED_SYMBOLS = (
     'ssn_critic_num_params', 'ssn_critic_workspace_floats', 'ssn_critic_forward', 'ssn_critic_loss_grad',
     'ssn_critic_input_grad', 'ssn_optimizer_step',
     'ssn_ff_forward_f32', 'ssn_ff_backward_f32',
+    'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
 )
 
 

@@ -75,6 +75,7 @@ template hipError_t launch_build_w<double>(const double*, const double*, double*
 // ext[b][s][pN+i] = c * sig((x_i + bw/2)/l) * sig((bw/2 - x_i)/l)   (stimuli.py:3-10)
 template <typename T>
 __global__ void __launch_bounds__(256) stimulus_kernel(const T* __restrict__ bw, const T* __restrict__ con, T inv_l,
+                                                       const T* __restrict__ amp, int NB,
                                                        T* __restrict__ ext, int N, long total) {
     const int M = 2 * N;
     const T step = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
@@ -86,19 +87,21 @@ __global__ void __launch_bounds__(256) stimulus_kernel(const T* __restrict__ bw,
         const T hb = bw[bs] * (T)0.5;
         const T s1 = (T)1 / ((T)1 + exp(-(x + hb) * inv_l));
         const T s2 = (T)1 / ((T)1 + exp(-(hb - x) * inv_l));
-        ext[e] = con[bs] * s1 * s2;
+        // heterogeneous input (networks/ssn.py:645-700): stimulus * (1 + v_pop * z_in), amp[b][m] given per draw
+        const T gain = amp ? amp[(bs / NB) * M + m] : (T)1;
+        ext[e] = gain * con[bs] * s1 * s2;
     }
 }
 template <typename T>
-hipError_t launch_stimulus(const T* bw, const T* con, T smooth, T* ext, int B, int NB, int N, hipStream_t st) {
+hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st) {
     const long total = (long)B * NB * 2 * N;
     if (total == 0) return hipSuccess;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL((stimulus_kernel<T>), dim3(blocks), dim3(256), 0, st, bw, con, (T)1 / smooth, ext, N, total);
+    hipLaunchKernelGGL((stimulus_kernel<T>), dim3(blocks), dim3(256), 0, st, bw, con, (T)1 / smooth, amp, NB, ext, N, total);
     return hipGetLastError();
 }
-template hipError_t launch_stimulus<float>(const float*, const float*, float, float*, int, int, int, hipStream_t);
-template hipError_t launch_stimulus<double>(const double*, const double*, double, double*, int, int, int, hipStream_t);
+template hipError_t launch_stimulus<float>(const float*, const float*, float, const float*, float*, int, int, int, hipStream_t);
+template hipError_t launch_stimulus<double>(const double*, const double*, double, const double*, double*, int, int, int, hipStream_t);
 
 template <typename T>
 __global__ void __launch_bounds__(256) io_eval_kernel(const T* __restrict__ v, T* __restrict__ out, long count, IoConsts<T> io) {

@@ -173,8 +173,8 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
 }
 
 template <typename T>
-int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, double c_dyn, double c_rate, int B, int NB,
-                      int M, const ssn_gen_params* g, void* stream) {
+int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ext, double c_dyn, double c_rate, int B,
+                      int NB, int M, const ssn_gen_params* g, void* stream) {
     if (B == 0 || NB == 0) return 0;
     if (!g || !W || !traj || !delta || !gta || M <= 0 || (M & 1) || g->seqlen < 1 || g->skip_steps < 0 ||
         g->skip_steps >= g->seqlen || !ssn::gen_supported<T>(M)) {
@@ -182,7 +182,7 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, double 
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
     ssn::GenBwdArgs<T> a;
-    a.W = W; a.traj = traj; a.delta = delta; a.g_time_avg = gta;
+    a.W = W; a.traj = traj; a.delta = delta; a.g_time_avg = gta; a.g_ext = g_ext;
     a.B = B; a.NB = NB; a.M = M; a.seqlen = g->seqlen; a.skip = g->skip_steps;
     a.eps_E = (T)(g->dt / g->tau_E); a.eps_I = (T)(g->dt / g->tau_I); a.theta = (T)g->rate_penalty_threshold;
     a.c_dyn = (T)c_dyn; a.c_rate = (T)c_rate;
@@ -301,11 +301,20 @@ int ssn_gen_forward_f64(const double* W, const double* ext, double* time_avg, do
 }
 int ssn_gen_backward_f32(const float* W, const float* traj, float* df_delta, const float* g_time_avg, double c_dyn,
                          double c_rate, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
-    return gen_backward_impl<float>(W, traj, df_delta, g_time_avg, c_dyn, c_rate, B, NB, M, p, stream);
+    return gen_backward_impl<float>(W, traj, df_delta, g_time_avg, nullptr, c_dyn, c_rate, B, NB, M, p, stream);
 }
 int ssn_gen_backward_f64(const double* W, const double* traj, double* df_delta, const double* g_time_avg, double c_dyn,
                          double c_rate, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
-    return gen_backward_impl<double>(W, traj, df_delta, g_time_avg, c_dyn, c_rate, B, NB, M, p, stream);
+    return gen_backward_impl<double>(W, traj, df_delta, g_time_avg, nullptr, c_dyn, c_rate, B, NB, M, p, stream);
+}
+int ssn_gen_backward_ext_f32(const float* W, const float* traj, float* df_delta, const float* g_time_avg, float* g_ext,
+                             double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params* p, void* stream) {
+    return gen_backward_impl<float>(W, traj, df_delta, g_time_avg, g_ext, c_dyn, c_rate, B, NB, M, p, stream);
+}
+int ssn_gen_backward_ext_f64(const double* W, const double* traj, double* df_delta, const double* g_time_avg,
+                             double* g_ext, double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params* p,
+                             void* stream) {
+    return gen_backward_impl<double>(W, traj, df_delta, g_time_avg, g_ext, c_dyn, c_rate, B, NB, M, p, stream);
 }
 int ssn_jds_grad_f32(const float* gW, const float* z, const float* J, const float* D, const float* S, double* out,
                      int B, int N, void* stream) {
@@ -380,11 +389,21 @@ int ssn_build_w_f64(const double* z, const double* J, const double* D, const dou
     return 0;
 }
 int ssn_stimulus_f32(const float* bw, const float* con, float smoothness, float* ext, int B, int NB, int N, void* stream) {
-    SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, ext, B, NB, N, (hipStream_t)stream));
+    SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, nullptr, ext, B, NB, N, (hipStream_t)stream));
     return 0;
 }
 int ssn_stimulus_f64(const double* bw, const double* con, double smoothness, double* ext, int B, int NB, int N, void* stream) {
-    SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, ext, B, NB, N, (hipStream_t)stream));
+    SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, nullptr, ext, B, NB, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_stimulus_amp_f32(const float* bw, const float* con, float smoothness, const float* amp, float* ext, int B, int NB,
+                         int N, void* stream) {
+    SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_stimulus_amp_f64(const double* bw, const double* con, double smoothness, const double* amp, double* ext, int B,
+                         int NB, int N, void* stream) {
+    SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));
     return 0;
 }
 int ssn_io_eval_f32(const float* v, float* out, long count, const ssn_solver_params* p, void* stream) {

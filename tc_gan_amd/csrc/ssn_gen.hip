@@ -133,13 +133,14 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
     const T inv = (T)1 / (T)(T_ - a.skip);
     bool live[NB];
     size_t base[NB];
-    T gta[NB], carry[NB], xn[NB], xc[NB], xm[NB], dfc[NB];
+    T gta[NB], carry[NB], xn[NB], xc[NB], xm[NB], dfc[NB], dsum[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         live[s] = fin && (s0 + s) < a.NB;
         base[s] = (((size_t)b * a.NB + (live[s] ? s0 + s : 0)) * T_) * M + (fin ? myrow : 0);
         gta[s] = live[s] ? a.g_time_avg[((size_t)b * a.NB + s0 + s) * M + myrow] * inv : (T)0;
         carry[s] = (T)0;
+        dsum[s] = (T)0;
         xn[s] = (T)0;
         xc[s] = live[s] ? a.traj[base[s] + (size_t)(T_ - 1) * M] : (T)0;              // x_T
         xm[s] = (live[s] && T_ >= 2) ? a.traj[base[s] + (size_t)(T_ - 2) * M] : (T)0;  // x_{T-1}
@@ -170,6 +171,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
             const T at = g + carry[s];
             const T delta = eps * dfc[s] * at;
             carry[s] = oneme * at;                     // + (W^T delta)[j] below
+            dsum[s] += delta;                          // dL/d ext = sum_t delta_t  (u_t = W x_{t-1} + ext)
             if (live[s]) {
                 dbuf[cur][s][myslot] = delta;
                 if (tau >= 2) a.delta[base[s] + (size_t)(tau - 2) * M] = delta;   // shifted: pairs with x_{tau-1}
@@ -184,6 +186,11 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
             xn[s] = xc[s]; xc[s] = xm[s]; xm[s] = xmm[s]; dfc[s] = dfn[s];
         }
         cur ^= 1;
+    }
+    if (a.g_ext) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s)
+            if (live[s]) a.g_ext[((size_t)b * a.NB + s0 + s) * M + myrow] = dsum[s];
     }
 }
 

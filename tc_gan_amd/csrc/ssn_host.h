@@ -40,6 +40,7 @@ struct GenBwdArgs {
     const T* traj;         // [B][NB][T][M]
     T* delta;              // in: f'(u_t) (the forward's df); out: delta_t at index t-2, slot T-1 zero
     const T* g_time_avg;   // [B][NB][M]  dL/d time_avg
+    T* g_ext;              // [B][NB][M] or nullptr: dL/d ext = sum_t delta_t
     int B, NB, M, seqlen, skip;
     T eps_E, eps_I, theta, c_dyn, c_rate;
 };
@@ -99,7 +100,7 @@ hipError_t launch_ff_backward(const FFArgs& a, const float* gq, float* dsig, hip
 
 // ssn_aux.hip
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
-template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, T* ext, int B, int NB, int N, hipStream_t st);
+template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st);
 template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st);
 template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st);
 

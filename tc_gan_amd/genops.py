@@ -62,18 +62,20 @@ def gen_forward(W, ext, gp, save=False):
     return out
 
 
-def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp):
-    """Adjoint sweep; `df` is overwritten by the shifted delta and returned.
+def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp, want_g_ext=False):
+    """Adjoint sweep; `df` is overwritten by the shifted delta and returned (with dL/d ext when asked).
     c_dyn / c_rate multiply SUM(dyn_row) / SUM(rate_row) in the loss."""
     clib.require_gpu()
     B, NB, T, M = traj.shape
     suffix, _ = _DT[W.dtype]
     g_time_avg = g_time_avg.to(W.dtype).contiguous()
-    rc = getattr(libssnode, 'ssn_gen_backward_' + suffix)(
-        W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(), float(c_dyn), float(c_rate),
+    g_ext = torch.empty((B, NB, M), device=W.device, dtype=W.dtype) if want_g_ext else None
+    rc = getattr(libssnode, 'ssn_gen_backward_ext_' + suffix)(
+        W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(),
+        g_ext.data_ptr() if want_g_ext else None, float(c_dyn), float(c_rate),
         B, NB, M, ctypes.byref(gp), _stream())
-    clib.check(rc, 'ssn_gen_backward_' + suffix)
-    return df
+    clib.check(rc, 'ssn_gen_backward_ext_' + suffix)
+    return (df, g_ext) if want_g_ext else df
 
 
 def weight_grad(delta, traj):

@@ -211,7 +211,9 @@ class ConditionalBPTTWassersteinGAN(object):
         self.reducer = GradientAllReducer()
         assert self.probes_per_model < gen.num_neurons
         assert num_models % self.reducer.world == 0, 'num_models must be divisible by the number of ranks'
-        self._gparams = {k: torch.zeros(4, device='cuda', dtype=torch.float32) for k in 'JDS'}
+        self._pnames = [name for name, _ in gen.get_all_params()]        # ['V',] 'J', 'D', 'S'
+        self._gparams = {name: torch.zeros(int(np.size(value)), device='cuda', dtype=torch.float32)
+                         for name, value in gen.get_all_params()}
 
     batchsize = property(lambda self: self.num_models * self.probes_per_model)
     num_sites = property(lambda self: self.gen.num_sites)
@@ -225,6 +227,9 @@ class ConditionalBPTTWassersteinGAN(object):
 
     def get_gen_param(self):
         return [self.gen.J.copy(), self.gen.D.copy(), self.gen.S.copy()]
+
+    def set_gen_param(self, **params):
+        self.gen.set_params(params)
 
     def set_dataset(self, data, **kwargs):
         kwargs.setdefault('seed', self.rng)       # the sampler SHARES the GAN's RandomState (cwgan.py:452)
@@ -243,31 +248,31 @@ class ConditionalBPTTWassersteinGAN(object):
     def _local(self, batch):
         return batch.shard(self.reducer.rank, self.reducer.world) if self.reducer.on else batch
 
-    def _draw_zs(self, batch):
-        """Host noise in the reference's stream order (ssn.py:434-439): the GLOBAL draw, then this
-        rank's rows -- so a data-parallel run consumes the RandomState exactly like a single-GPU run."""
+    def _draw_noise(self, batch):
+        """Host noise in the reference's stream order (ssn.py:434-439, 764-767: zs, then zs_in): the GLOBAL
+        draw, then this rank's rows -- a data-parallel run consumes the RandomState exactly like a
+        single-GPU run.  Empty in device-noise mode (the generator draws from its Philox stream)."""
         if self.gen._zgen is not None:
-            return None                            # device Philox stream (perf mode)
-        zs = self.rng.rand(batch.num_models, self.gen.num_neurons, self.gen.num_neurons)
+            return {}
+        noise = self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((batch.num_models, 1)))
         if self.reducer.on:
             per = batch.num_models // self.reducer.world
-            zs = zs[self.reducer.rank * per:(self.reducer.rank + 1) * per]
-        return zs
+            noise = {k: v[self.reducer.rank * per:(self.reducer.rank + 1) * per] for k, v in noise.items()}
+        return noise
 
-    def gen_forward(self, batch, zs=None, save=False):
+    def gen_forward(self, batch, noise=None, save=False):
         local = self._local(batch)
         kw = local.gen_kwargs
-        if zs is not None:
-            kw['model_zs'] = zs
+        kw.update(noise or {})
         return self.gen.forward(rng=self.rng, save=save, model_rate_penalty_threshold=self.rate_penalty_threshold,
                                 **kw), local
 
     def train_discriminator(self, info):
         batch = self.next_minibatch()
         eps_full = self.rng.rand(batch.batchsize, 1)
-        zs = self._draw_zs(batch)
+        noise = self._draw_noise(batch)
         with self.gen_forward_watch:
-            gen_out, local = self.gen_forward(batch, zs)
+            gen_out, local = self.gen_forward(batch, noise)
             xg = gen_out.prober_tuning_curve
             rate_penalty = self._mean_scalar(gen_out.model_rate_penalty)
             dynamics_penalty = self._mean_scalar(gen_out.model_dynamics_penalty)
@@ -309,24 +314,27 @@ class ConditionalBPTTWassersteinGAN(object):
         return float(t[0])
 
     def train_generator(self, info, batch):
-        zs = self._draw_zs(batch)
+        noise = self._draw_noise(batch)
         with self.gen_train_watch:
-            gen_out, local = self.gen_forward(batch, zs, save=True)
+            gen_out, local = self.gen_forward(batch, noise, save=True)
             cd = torch.as_tensor(np.ascontiguousarray(local.conditions), device='cuda', dtype=torch.float32)
             xg = gen_out.prober_tuning_curve.to(torch.float32)
             nb = xg.shape[0]
             gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
-            gJ, gD, gS = self.gen.backward(gx, self.dynamics_cost, self.rate_cost)
+            gdict = self.gen.backward(gx, self.dynamics_cost, self.rate_cost)
             loss = (-dmean.to(torch.float64) + self.dynamics_cost * gen_out.model_dynamics_penalty
                     + self.rate_cost * gen_out.model_rate_penalty).reshape(1).to(torch.float32)
-            grads = torch.as_tensor(np.concatenate([gJ.ravel(), gD.ravel(), gS.ravel()]), device='cuda',
+            grads = torch.as_tensor(np.concatenate([np.ravel(gdict[name]) for name in self._pnames]), device='cuda',
                                     dtype=torch.float32)
             self.reducer.mean_(grads, loss)
-            for i, name in enumerate('JDS'):                                     # wgan.py:218-260
+            off = 0
+            for name in self._pnames:                                            # wgan.py:218-260
+                value = np.asarray(getattr(self.gen, name))
                 p = self._gparams[name]
-                p.copy_(torch.as_tensor(getattr(self.gen, name).ravel(), dtype=torch.float32))
-                self.gen_updaters[name](p, grads[4 * i:4 * i + 4], clip=self.param_bounds[name])
-                setattr(self.gen, name, p.cpu().numpy().astype('float64').reshape(2, 2))
+                p.copy_(torch.as_tensor(value.ravel(), dtype=torch.float32))
+                self.gen_updaters[name](p, grads[off:off + p.numel()], clip=self.param_bounds[name])
+                off += p.numel()
+                setattr(self.gen, name, p.cpu().numpy().astype('float64').reshape(value.shape))
             info.gen_loss = float(loss[0])
         info.gen_forward_time = self.gen_forward_watch.sum()
         info.gen_train_time = self.gen_train_watch.sum()
@@ -380,10 +388,13 @@ def make_gan(config):
     num_sites = take('num_sites')
     ssn_type = take('ssn_type', 'default')
     ssn_impl = take('ssn_impl', 'default')
-    if ssn_type != 'default' or ssn_impl != 'default':
-        raise NotImplementedError("ssn_type={!r} / ssn_impl={!r}: only the default SSN is built on the GPU path"
-                                  .format(ssn_type, ssn_impl))
-    for key in ('V0', 'V', 'dist_in', 'V_min', 'V_max'):
+    if ssn_impl not in ('default', 'mapclone'):     # 'mapclone' is the same arithmetic organised differently (ssn.py:25-30)
+        raise ValueError('Unknown ssn_impl: {}'.format(ssn_impl))
+    if 'V0' in kwargs:                              # cwgan.py:570-571
+        kwargs['V'] = kwargs.pop('V0')
+    V = kwargs.pop('V', 0)
+    dist_in = kwargs.pop('dist_in', 'bernoulli')
+    for key in ('V_min', 'V_max'):
         kwargs.pop(key, None)
     reducer = GradientAllReducer()
     local_models = num_models // reducer.world
@@ -397,7 +408,8 @@ def make_gan(config):
         include_time_avg=take('include_time_avg', False),
         unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'),
-        z_device_seed=take('z_device_seed', None))
+        z_device_seed=take('z_device_seed', None),
+        ssn_type=ssn_type, V=V, dist_in=dist_in)
     rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
     disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
     seed = take('seed', 0)
@@ -416,10 +428,11 @@ def make_gan(config):
     dynamics_cost = gen_cfg.pop('dynamics_cost', 1.0)
     rate_cost = gen_cfg.pop('rate_cost')
     bounds = {name: (gen_cfg.pop(name + '_min', 1e-3), gen_cfg.pop(name + '_max', 10.0)) for name in 'JDS'}
+    bounds['V'] = (float(np.min(gen_cfg.pop('V_min', 0))), float(np.max(gen_cfg.pop('V_max', 1))))   # wgan.py:263-283
     gen_upd_cfg = {k: gen_cfg.pop(k) for k in list(gen_cfg) if k in ('learning_rate', 'update_name', 'update_config',
                                                                      'reg_l2_penalty', 'reg_l2_decay',
                                                                      'reg_l1_penalty', 'reg_l1_decay')}
-    gen_updaters = {name: Updater(**gen_upd_cfg) for name in 'JDS'}
+    gen_updaters = {name: Updater(**gen_upd_cfg) for name in 'VJDS'}
     disc_updater = updater_from(disc_cfg)
     if gen_cfg or disc_cfg:
         raise ValueError('Unknown trainer options: gen={} disc={}'.format(sorted(gen_cfg), sorted(disc_cfg)))

@@ -34,7 +34,7 @@ def dataset_by_fixedtime(learner, truth_size, truth_seed, truth_batchsize=50, tr
             repeat += 1
             logger.warning('truth_size=%d is not divisible by truth_batchsize=%d.', truth_size, truth_batchsize)
     options = dict(true_ssn_options)
-    for name in ('J', 'D', 'S'):
+    for name, _ in learner.gen.get_all_params():
         options.setdefault(name, DEFAULT_PARAMS[name])
     sampler = FixedTimeTuningCurveSampler.from_learner(learner, batchsize=truth_batchsize, seed=truth_seed, **options)
     data = np.concatenate([sampler.forward().prober_tuning_curve.cpu().numpy() for _ in range(repeat)])
@@ -43,6 +43,8 @@ def dataset_by_fixedtime(learner, truth_size, truth_seed, truth_batchsize=50, tr
 
 def generate_dataset(learner, dataset_provider='ssnode', **kwargs):
     """dataset.py:133-185."""
+    if dataset_provider == 'ssnode' and learner.gen.heteroin:
+        raise NotImplementedError("ssnode does not support SSN with heterogeneous input (yet).")   # dataset.py:163-166
     logger.info('Generating the truth...')
     if dataset_provider == 'ssnode':
         return dataset_by_ssnode(num_sites=learner.gen.num_sites, bandwidths=learner.bandwidths,

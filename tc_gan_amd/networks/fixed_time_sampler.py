@@ -31,8 +31,10 @@ class FixedTimeTuningCurveSampler(object):
     @classmethod
     def from_dict(cls, dct):
         cfg = dict(DEFAULT_PARAMS, **dct)
-        for key in ('V', 'dist_in', 'ssn_type', 'ssn_impl'):
-            cfg.pop(key, None)
+        cfg.pop('ssn_impl', None)
+        if cfg.get('ssn_type', 'default') == 'default':
+            for key in ('V', 'dist_in'):
+                cfg.pop(key, None)
         bandwidths, contrasts = cfg.pop('bandwidths'), cfg.pop('contrasts')
         num_sites = cfg.pop('num_sites')
         probes = probes_from_stim_space(cfg.pop('norm_probes'), num_sites, cfg.pop('include_inhibitory_neurons'))
@@ -80,7 +82,7 @@ class FixedTimeTuningCurveSampler(object):
     def from_learner(cls, learner, batchsize, seed, **override):
         """fixed_time_sampler.py:208-246: copy the learner's generator settings, override parameters."""
         cfg = learner.gen.to_config()
-        for key in ('probes', 'include_rate_penalty', 'ssn_type', 'ssn_impl', 'num_tcdom', 'batchsize'):
+        for key in ('probes', 'include_rate_penalty', 'ssn_impl', 'num_tcdom', 'batchsize'):
             cfg.pop(key, None)
         cfg.update(override)
         bandwidths, contrasts = learner.bandwidths, learner.contrasts

@@ -23,7 +23,8 @@ from ..stimuli import stimulus_batch
 from ..weight_gen import generate_weight_batch
 
 ssn_impl_choices = ('default',)
-ssn_type_choices = ('default',)
+ssn_type_choices = ('default', 'heteroin', 'deg-heteroin')
+dist_in_choices = ('bernoulli', 'uniform')
 
 
 def neu_array(pop_array, num_sites, pops=None):
@@ -69,8 +70,21 @@ class TuningCurveGenerator(object):
 
     def __init__(self, num_sites, num_tcdom, smoothness, J, D, S, k, n, tau_E, tau_I, dt, io_type,
                  seqlen, skip_steps, batchsize, probes=None, include_rate_penalty=True,
-                 include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None):
+                 include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None,
+                 ssn_type='default', V=0, dist_in='bernoulli'):
         clib.require_gpu()
+        if ssn_type not in ssn_type_choices:
+            raise ValueError('Unknown ssn_type: {}'.format(ssn_type))
+        assert dist_in in dist_in_choices
+        self.ssn_type = ssn_type
+        self.dist_in = dist_in
+        # ssn.py:688-740: 'heteroin' has V = (V_E, V_I); 'deg-heteroin' one scalar V used for both populations
+        if ssn_type == 'heteroin':
+            self.V = np.ascontiguousarray(np.broadcast_to(np.asarray(V, dtype='float64'), 2))
+        elif ssn_type == 'deg-heteroin':
+            self.V = np.asarray(V, dtype='float64').reshape(())
+        else:
+            self.V = None
         self.num_sites = int(num_sites)
         self.num_tcdom = int(num_tcdom)
         self.smoothness = float(smoothness)
@@ -111,8 +125,16 @@ class TuningCurveGenerator(object):
     cond_shape = property(lambda self: (self.batchsize, 3))
 
     # -- parameters (generator.get_all_params order: J, D, S) -----------------------------
+    heteroin = property(lambda self: self.V is not None)
+
+    @property
+    def vpop(self):
+        return np.broadcast_to(self.V, 2).astype('float64')
+
     def get_all_params(self):
-        return [('J', self.J), ('D', self.D), ('S', self.S)]
+        """Order of the reference's ``get_all_params`` (stimulator parameters first: ssn.py:255-259, 703-705)."""
+        params = [('V', self.V)] if self.heteroin else []
+        return params + [('J', self.J), ('D', self.D), ('S', self.S)]
 
     def get_flat_param_names(self):
         return make_flat_param_names(self.get_all_params())
@@ -125,6 +147,8 @@ class TuningCurveGenerator(object):
         for name in ('J', 'D', 'S'):
             if name in rest:
                 setattr(self, name, np.array(rest.pop(name), dtype='float64').reshape(2, 2))
+        if 'V' in rest and self.heteroin:
+            self.V = np.array(rest.pop('V'), dtype='float64').reshape(self.V.shape)
         if rest:
             raise ValueError('Unknown parameters: {}'.format(rest))
 
@@ -140,15 +164,33 @@ class TuningCurveGenerator(object):
         num_models = np.shape(stimulator_bandwidths)[0]
         M = self.num_neurons
         if self._zgen is not None:
-            return dict(model_zs=torch.rand((num_models, M, M), device='cuda', dtype=self.tdtype,
-                                            generator=self._zgen))
-        return dict(model_zs=rng.rand(num_models, M, M))
+            noise = dict(model_zs=torch.rand((num_models, M, M), device='cuda', dtype=self.tdtype,
+                                             generator=self._zgen))
+            if self.heteroin:
+                u = torch.rand((num_models, M), device='cuda', dtype=self.tdtype, generator=self._zgen)
+                noise['model_zs_in'] = (u < 0.5).to(self.tdtype) * 2 - 1 if self.dist_in == 'bernoulli' else u * 2 - 1
+            return noise
+        noise = dict(model_zs=rng.rand(num_models, M, M))
+        if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720
+            shape = (num_models, M)
+            noise['model_zs_in'] = (rng.choice(2, shape) * 2 - 1 if self.dist_in == 'bernoulli'
+                                    else rng.rand(*shape) * 2 - 1)
+        return noise
 
     # -- forward ------------------------------------------------------------------------------
-    def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs):
+    def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs, model_zs_in=None):
         bw = np.asarray(stimulator_bandwidths) if not torch.is_tensor(stimulator_bandwidths) else stimulator_bandwidths
         con = np.asarray(stimulator_contrasts) if not torch.is_tensor(stimulator_contrasts) else stimulator_contrasts
-        ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
+        amp = None
+        self._zin = None
+        if self.heteroin:
+            zin = torch.as_tensor(model_zs_in).to('cuda', self.tdtype)
+            vs = torch.as_tensor(neu_array(self.vpop, self.num_sites), device='cuda', dtype=self.tdtype)
+            amp = 1 + vs[None, :] * zin                                   # ssn.py:679-684
+            self._zin = zin
+        ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)
+        self._ext_base = (stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
+                          if self.heteroin else None)
         if torch.is_tensor(model_zs):
             z = model_zs.to('cuda', self.tdtype).contiguous()
         else:
@@ -177,7 +219,7 @@ class TuningCurveGenerator(object):
                 kwargs.update(self.gen_noise(rng, **kwargs))
         theta = kwargs.pop('model_rate_penalty_threshold', 200.0)
         ext, z, W = self._device_inputs(kwargs.pop('stimulator_bandwidths'), kwargs.pop('stimulator_contrasts'),
-                                        kwargs.pop('model_zs'))
+                                        kwargs.pop('model_zs'), kwargs.pop('model_zs_in', None))
         probe_kw = {k: kwargs.pop(k) for k in list(kwargs) if k.startswith('prober_')}
         assert not kwargs, 'unknown inputs: {}'.format(sorted(kwargs))
         gp = self.gen_params(theta)
@@ -191,12 +233,13 @@ class TuningCurveGenerator(object):
         vals.append(tc)
         out = self.OutType(*vals)
         if save:
-            self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr)
+            self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr, zin=self._zin, ext_base=self._ext_base)
         return out
 
     def backward(self, g_tuning_curve, dynamics_cost, rate_cost):
         """BPTT: gradient of  sum(g_tuning_curve * tuning_curve) + dynamics_cost * dynamics_penalty
-        + rate_cost * rate_penalty  w.r.t. (J, D, S), for the last ``forward(save=True)`` call."""
+        + rate_cost * rate_penalty  w.r.t. the generator parameters (dict: J, D, S[, V]), for the last
+        ``forward(save=True)`` call."""
         sv = self._saved
         fwd = sv['fwd']
         g_ta = torch.zeros_like(fwd['time_avg'])
@@ -207,12 +250,20 @@ class TuningCurveGenerator(object):
             g_ta.permute(0, 2, 1).index_put_((sv['ids'], sv['probes']), g, accumulate=True)
         else:
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
-        delta = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
-                                    rate_cost / fwd['n_rate'], sv['gp'])
+        res = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
+                                  rate_cost / fwd['n_rate'], sv['gp'], want_g_ext=self.heteroin)
+        delta, g_ext = res if self.heteroin else (res, None)
         gW = genops.weight_grad(delta, fwd['traj'])
         gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S)
+        grads = dict(J=gJ, D=gD, S=gS)
+        if self.heteroin:
+            # ext = (1 + v_pop z_in) ext_base  ->  dL/dv_pop = sum over the population of g_ext * ext_base * z_in
+            B, NB, M = g_ext.shape
+            per = (g_ext.to(torch.float64) * sv['ext_base'].to(torch.float64) * sv['zin'].to(torch.float64)[:, None, :])
+            gv = per.reshape(B, NB, 2, M // 2).sum(dim=(0, 1, 3)).cpu().numpy()
+            grads['V'] = gv if self.ssn_type == 'heteroin' else np.asarray(gv.sum())
         self._saved = None
-        return gJ, gD, gS
+        return grads
 
     def prepare(self):
         """Nothing to compile (the reference forces Theano compilation here)."""
@@ -223,9 +274,10 @@ class TuningCurveGenerator(object):
                     tau_E=self.tau_E, tau_I=self.tau_I, dt=self.dt, io_type=self.io_type,
                     seqlen=self.seqlen, skip_steps=self.skip_steps, batchsize=self.batchsize,
                     include_rate_penalty=self.include_rate_penalty, include_time_avg=self.include_time_avg,
-                    unroll_scan=self.unroll_scan, ssn_type='default', ssn_impl='default',
+                    unroll_scan=self.unroll_scan, ssn_type=self.ssn_type, ssn_impl='default',
+                    **({} if not self.heteroin else dict(V=np.asarray(self.V).tolist(), dist_in=self.dist_in)),
                     **({} if self.probes is None else dict(probes=self.probes.tolist())))
 
 
 def is_heteroin(gen):
-    return False
+    return gen.heteroin

@@ -60,6 +60,8 @@ def add_bptt_common_options(parser):
     parser.add_argument('--lipschitz-cost', '--WGAN_lambda', default=10.0, type=float)
     parser.add_argument('--critic-iters-init', '--WGAN_n_critic0', default=50, type=int)
     parser.add_argument('--critic-iters', '--WGAN_n_critic', default=5, type=int)
+    parser.add_argument('--ssn-type', default='default', choices=('default', 'heteroin', 'deg-heteroin'),
+                        help='SSN variant (the reference sets it through --load-config)')
     parser.add_argument('--z-device-seed', default=None, type=int,
                         help='Draw z on the device (Philox) instead of the host RandomState (new; fast mode)')
 
@@ -99,6 +101,10 @@ def preprocess(run_config):
     true_ssn_options = run_config.setdefault('true_ssn_options', {})
     for key in ['J', 'D', 'S']:
         true_ssn_options.setdefault(key, new_JDS[key].tolist())
+    if run_config.get('ssn_type') == 'heteroin':                  # bptt_wgan.py:211-214
+        true_ssn_options.setdefault('V', [0.3, 0])
+    elif run_config.get('ssn_type') == 'deg-heteroin':
+        true_ssn_options.setdefault('V', 0.5)
 
 
 def do_learning(learn, run_config, script_file, init_driver, preprocess=preprocess, **kwargs):

@@ -14,9 +14,10 @@ from . import clib
 from .clib import libssnode
 
 
-def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32'):
+def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32', amp=None):
     """Device form: `bandwidths`, `contrasts` of shape (B, NB) -> CUDA tensor (B, NB, 2*num_sites)
-    (networks/ssn.py:177-188)."""
+    (networks/ssn.py:177-188).  `amp` (B, 2*num_sites): per-draw input amplification of the
+    heterogeneous-input SSN (ssn.py:679-686)."""
     import torch
     clib.require_gpu()
     td = {'float32': torch.float32, 'float64': torch.float64}[str(np.dtype(dtype))]
@@ -25,10 +26,14 @@ def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32'
     assert bw.shape == con.shape and bw.dim() == 2
     B, NB = bw.shape
     ext = torch.empty((B, NB, 2 * num_sites), device='cuda', dtype=td)
-    fn, ct = ((libssnode.ssn_stimulus_f32, ctypes.c_float) if td == torch.float32
-              else (libssnode.ssn_stimulus_f64, ctypes.c_double))
-    clib.check(fn(bw.data_ptr(), con.data_ptr(), ct(smoothness), ext.data_ptr(), int(B), int(NB),
-                  int(num_sites), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_stimulus')
+    fn, ct = ((libssnode.ssn_stimulus_amp_f32, ctypes.c_float) if td == torch.float32
+              else (libssnode.ssn_stimulus_amp_f64, ctypes.c_double))
+    if amp is not None:
+        amp = torch.as_tensor(amp).to('cuda', td).contiguous()
+        assert amp.shape == (B, 2 * num_sites)
+    clib.check(fn(bw.data_ptr(), con.data_ptr(), ct(smoothness), amp.data_ptr() if amp is not None else None,
+                  ext.data_ptr(), int(B), int(NB), int(num_sites),
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_stimulus')
     return ext
 
 

@@ -126,3 +126,49 @@ def test_device_noise_mode_runs_and_rate_bound_skips_critic():
     info = next(gan.learning())
     assert info.is_discriminator and np.isnan(info.disc_loss) and np.isnan(info.accuracy)
     np.testing.assert_array_equal(gan.disc.get_flat(), before)
+
+
+@pytest.mark.parametrize('ssn_type,V0', [('heteroin', [0.3, 0.1]), ('deg-heteroin', 0.4)])
+def test_heteroin_generator_update_vs_oracle(ssn_type, V0):
+    """Heterogeneous-input SSNs (networks/ssn.py:645-772): parameter order [V, J, D, S], noise order
+    zs then zs_in, and the V gradient through dL/d ext, against the oracle with the same host RNG stream."""
+    from tc_gan_amd.networks.cwgan import make_gan, RandomChoiceSampler
+    cfg = dict(TEST_PARAMS, critic_iters_init=1, critic_iters=1, ssn_type=ssn_type, V0=V0)
+    cfg['gen'] = dict(cfg['gen'], V_min=0, V_max=1)
+    gan, _ = make_gan(cfg)
+    names = gan.gen.get_flat_param_names()
+    assert names[:2] == ('V_E', 'V_I') if ssn_type == 'heteroin' else names[0] == 'V'
+    assert names[-4:] == ('S_EE', 'S_EI', 'S_IE', 'S_II')
+    data = _fake_data(gan, 9, np.random.RandomState(4))
+    gan.set_dataset(data)
+    p0 = [og.t64(p) for p in gan.disc.get_param_values()]
+    it = gan.learning()
+    dinfo = next(it)
+    p1 = [og.t64(p) for p in gan.disc.get_param_values()]
+    ginfo = next(it)
+    # oracle replay
+    rng = np.random.RandomState(0)
+    sampler = RandomChoiceSampler.from_grid_data(data, bandwidths=gan.bandwidths, contrasts=gan.contrasts,
+                                                 norm_probes=gan.norm_probes, e_ratio=gan.e_ratio,
+                                                 include_inhibitory_neurons=True, seed=rng)
+    batch = sampler.select_minibatch(4, 2)
+    rng.rand(batch.batchsize, 1)                       # eps
+    N = 10
+    rng.rand(4, 2 * N, 2 * N); rng.choice(2, (4, 2 * N))      # critic step noise: zs, zs_in
+    zs = og.t64(rng.rand(4, 2 * N, 2 * N))
+    zs_in = rng.choice(2, (4, 2 * N)) * 2 - 1
+    kw = batch.gen_kwargs
+    Jg, Dg, Sg = (og.t64(JDS[k]).clone().requires_grad_(True) for k in 'JDS')
+    Vg = og.t64(V0).clone().requires_grad_(True)
+    gloss, _ = og.generator_loss(Jg, Dg, Sg, zs, kw['stimulator_bandwidths'], kw['stimulator_contrasts'],
+                                 kw['prober_model_ids'], kw['prober_norm_probes'], kw['prober_cell_types'], p1,
+                                 num_sites=N, smoothness=on.DEFAULT_PARAMS['smoothness'], io_type='asym_tanh', k=0.01,
+                                 n=2.2, tau_E=10., tau_I=1., dt=0.1, seqlen=40, skip_steps=30,
+                                 rate_penalty_threshold=5.0, dynamics_cost=1.0, rate_cost=0.01, V=Vg, zs_in=zs_in)
+    gJ, gD, gS, gV = torch.autograd.grad(gloss, [Jg, Dg, Sg, Vg])
+    np.testing.assert_allclose(ginfo.gen_loss, float(gloss), rtol=1e-3, atol=1e-4)
+    want_V = np.clip(np.asarray(V0, dtype=float) - 0.01 * gV.numpy(), 0, 1)
+    np.testing.assert_allclose(np.asarray(gan.gen.V) - np.asarray(V0), want_V - np.asarray(V0), rtol=1e-2,
+                               atol=1e-2 * np.abs(want_V - np.asarray(V0)).max() + 1e-9)
+    want_J = np.clip(JDS['J'] - 0.01 * gJ.numpy(), 1e-3, 10)
+    np.testing.assert_allclose(gan.gen.J - JDS['J'], want_J - JDS['J'], rtol=1e-2, atol=1e-2 * np.abs(want_J - JDS['J']).max())

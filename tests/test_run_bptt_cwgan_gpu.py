@@ -25,6 +25,8 @@ def _load_tables(directory, store):
     ['--sample-sites', '0, 0.5', '--probes-per-model', '2'],
     ['--contrasts', '5, 20'],
     ['--include-inhibitory-neurons', '--dataset-provider', 'fixedtime'],
+    ['--ssn-type', 'heteroin', '--dataset-provider', 'fixedtime'],
+    ['--ssn-type', 'deg-heteroin', '--dataset-provider', 'fixedtime', '--include-inhibitory-neurons'],
 ])
 def test_single_g_step(args, tmp_path, monkeypatch):
     from tc_gan_amd.run import bptt_cwgan
@@ -44,8 +46,10 @@ def test_single_g_step(args, tmp_path, monkeypatch):
     assert set(tables) == {'learning', 'disc_learning', 'generator', 'disc_param_stats'}
     assert tables['learning'].dtype.names == ('gen_step', 'Gloss', 'Dloss', 'Daccuracy', 'gen_forward_time',
                                               'gen_train_time', 'disc_time', 'rate_penalty', 'dynamics_penalty')
-    assert tables['generator'].dtype.names == ('gen_step', 'J_EE', 'J_EI', 'J_IE', 'J_II', 'D_EE', 'D_EI', 'D_IE',
-                                               'D_II', 'S_EE', 'S_EI', 'S_IE', 'S_II')
+    vnames = {'heteroin': ('V_E', 'V_I'), 'deg-heteroin': ('V',)}.get(
+        args[args.index('--ssn-type') + 1] if '--ssn-type' in args else 'default', ())
+    assert tables['generator'].dtype.names == ('gen_step',) + vnames + (
+        'J_EE', 'J_EI', 'J_IE', 'J_II', 'D_EE', 'D_EI', 'D_IE', 'D_II', 'S_EE', 'S_EI', 'S_IE', 'S_II')
     assert len(tables['learning']) == 1 and len(tables['disc_learning']) == 1
     assert np.isfinite(tables['learning']['Gloss']).all()
     tc = _load_tables(str(out), 'tc_stats')['tc_stats']
