@@ -241,6 +241,23 @@ int ssn_critic_input_grad(const float *params, const int *dims, int nlayers, con
                           int batch, int hide_cell_type, float scale, float *gx, float *stats,
                           float *workspace, int precision, void *stream);
 
+/* The same three passes for a critic whose hidden layer l is layer-normalised when layer_norm[l] != 0
+ * (simple_discriminator.py:51-75: Dense(no bias) -> LayerNorm (eps 1e-4, no parameters) -> Bias -> ReLU;
+ * same [W_l, b_l] parameter layout).  layer_norm: HOST int[L] or NULL (all plain).  The WGAN-GP double
+ * backward goes through the normalisation. */
+size_t ssn_critic_norm_workspace_floats(const int *dims, int nlayers, int batch_gd, int batch_p);
+int ssn_critic_forward_norm(const float *params, const int *dims, const int *layer_norm, int nlayers,
+                            const float *x, const float *cond, int batch, int hide_cell_type, float *out,
+                            float *workspace, int precision, void *stream);
+int ssn_critic_loss_grad_norm(const float *params, const int *dims, const int *layer_norm, int nlayers,
+                              const float *xg, const float *cg, const float *xd, const float *cd,
+                              const float *xp, const float *cp, int ng, int nd, int np, float lmd,
+                              int hide_cell_type, float *grads, float *stats, float *dvals,
+                              float *workspace, int precision, void *stream);
+int ssn_critic_input_grad_norm(const float *params, const int *dims, const int *layer_norm, int nlayers,
+                               const float *x, const float *cond, int batch, int hide_cell_type, float scale,
+                               float *gx, float *stats, float *workspace, int precision, void *stream);
+
 typedef struct ssn_opt_params {
     int kind;                 /* 0 sgd, 1 adam, 2 rmsprop (lasagne.updates) */
     int step;                 /* 1-based update count (adam bias correction) */

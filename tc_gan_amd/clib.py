@@ -167,6 +167,16 @@ libssnode.ssn_critic_loss_grad.argtypes = [c_void_p, _ip, c_int] + [c_void_p] * 
                                            c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
 libssnode.ssn_critic_input_grad.argtypes = [c_void_p, _ip, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
                                             c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_norm_workspace_floats.argtypes = [_ip, c_int, c_int, c_int]
+libssnode.ssn_critic_norm_workspace_floats.restype = ctypes.c_size_t
+libssnode.ssn_critic_forward_norm.argtypes = [c_void_p, _ip, _ip, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                              c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_loss_grad_norm.argtypes = [c_void_p, _ip, _ip, c_int] + [c_void_p] * 6 + [
+    c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_input_grad_norm.argtypes = [c_void_p, _ip, _ip, c_int, c_void_p, c_void_p, c_int, c_int, c_float,
+                                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+for _name in ('ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm', 'ssn_critic_input_grad_norm'):
+    getattr(libssnode, _name).restype = c_int
 libssnode.ssn_optimizer_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_long, POINTER(OptParams), c_void_p]
 for _name in ('ssn_critic_forward', 'ssn_critic_loss_grad', 'ssn_critic_input_grad', 'ssn_optimizer_step'):
     getattr(libssnode, _name).restype = c_int
@@ -198,6 +208,8 @@ DECLARED_SYMBOLS = (
     'ssn_critic_input_grad', 'ssn_optimizer_step',
     'ssn_ff_forward_f32', 'ssn_ff_backward_f32',
     'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
+    'ssn_critic_norm_workspace_floats', 'ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm',
+    'ssn_critic_input_grad_norm',
 )
 
 

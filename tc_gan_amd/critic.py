@@ -26,8 +26,10 @@ class Critic(object):
 
     def __init__(self, nx, layers, seed=0, hide_cell_type=False, precision='bf16',
                  normalization='none', nonlinearity='rectify', device=None):
-        if normalization not in ('none', ('none',) * len(layers), ['none'] * len(layers)):
-            raise NotImplementedError("only normalization='none' is implemented on the GPU path")
+        norms = list(normalization) if isinstance(normalization, (list, tuple)) else [normalization] * len(layers)
+        if len(norms) != len(layers) or any(n not in ('none', 'layer') for n in norms):
+            raise ValueError('normalization must be none/layer (or one per layer): {!r}'.format(normalization))
+        self.normalization = norms
         if nonlinearity != 'rectify':
             raise NotImplementedError("only nonlinearity='rectify' is implemented on the GPU path")
         clib.require_gpu()
@@ -38,6 +40,8 @@ class Critic(object):
         self.hide_cell_type = int(bool(hide_cell_type))
         self.precision = PRECISION[precision]
         self._dims_c = (ctypes.c_int * len(self.dims))(*self.dims)
+        self.layer_norm = any(n == 'layer' for n in norms)
+        self._norm_c = (ctypes.c_int * max(len(norms), 1))(*[int(n == 'layer') for n in norms])
         self.num_params = int(libssnode.ssn_critic_num_params(self._dims_c, self.nlayers))
         self.device = device or torch.device('cuda', torch.cuda.current_device())
         self.params = torch.empty(self.num_params, device=self.device, dtype=torch.float32)
@@ -57,13 +61,18 @@ class Critic(object):
         return shapes
 
     def init_params(self, rng):
-        """Lasagne defaults: W ~ GlorotUniform, hidden b ~ Normal(std=.01) (simple_discriminator.py:149-150),
-        linear output layer without bias (160-161)."""
+        """Lasagne defaults: W ~ GlorotUniform (plain layers) or Normal(std=1) (layer-normalised layers,
+        simple_discriminator.py:53), hidden b ~ Normal(std=.01) (149-150), linear output layer without bias
+        (160-161)."""
         flat = []
-        for kind, shape in self.param_shapes():
+        for i, (kind, shape) in enumerate(self.param_shapes()):
             if kind == 'W':
-                a = np.sqrt(6.0 / (shape[0] + shape[1]))
-                flat.append(rng.uniform(-a, a, size=shape).ravel())
+                layer = i // 2
+                if layer < self.nlayers and self.normalization[layer] == 'layer':
+                    flat.append(rng.normal(0.0, 1.0, size=shape).ravel())
+                else:
+                    a = np.sqrt(6.0 / (shape[0] + shape[1]))
+                    flat.append(rng.uniform(-a, a, size=shape).ravel())
             else:
                 flat.append(rng.normal(0.0, 0.01, size=shape).ravel())
         self.set_flat(np.concatenate(flat))
@@ -93,7 +102,8 @@ class Critic(object):
     def _workspace(self, bgd, bp):
         key = (bgd, bp)
         if self._ws_key != key:
-            n = int(libssnode.ssn_critic_workspace_floats(self._dims_c, self.nlayers, int(bgd), int(bp)))
+            fn = libssnode.ssn_critic_norm_workspace_floats if self.layer_norm else libssnode.ssn_critic_workspace_floats
+            n = int(fn(self._dims_c, self.nlayers, int(bgd), int(bp)))
             self._ws = torch.empty(n, device=self.device, dtype=torch.float32)
             self._ws_key = key
         return self._ws
@@ -107,6 +117,11 @@ class Critic(object):
         batch = x.shape[0]
         out = torch.empty(batch, device=self.device, dtype=torch.float32)
         ws = self._workspace(batch, 0)
+        if self.layer_norm:
+            clib.check(libssnode.ssn_critic_forward_norm(
+                self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
+                self.hide_cell_type, out.data_ptr(), ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward_norm')
+            return out
         clib.check(libssnode.ssn_critic_forward(self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(),
                                                 cond.data_ptr(), batch, self.hide_cell_type, out.data_ptr(),
                                                 ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward')
@@ -118,6 +133,13 @@ class Critic(object):
         ng, nd, npn = xg.shape[0], xd.shape[0], xp.shape[0]
         ws = self._workspace(ng + nd, npn)
         self._dvals = torch.empty(ng + nd, device=self.device, dtype=torch.float32)
+        if self.layer_norm:
+            clib.check(libssnode.ssn_critic_loss_grad_norm(
+                self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, xg.data_ptr(), cg.data_ptr(),
+                xd.data_ptr(), cd.data_ptr(), xp.data_ptr(), cp.data_ptr(), ng, nd, npn, float(lmd), self.hide_cell_type,
+                self.grads.data_ptr(), self.stats.data_ptr(), self._dvals.data_ptr(), ws.data_ptr(), self.precision,
+                _stream()), 'ssn_critic_loss_grad_norm')
+            return self.stats
         clib.check(libssnode.ssn_critic_loss_grad(
             self.params.data_ptr(), self._dims_c, self.nlayers, xg.data_ptr(), cg.data_ptr(), xd.data_ptr(),
             cd.data_ptr(), xp.data_ptr(), cp.data_ptr(), ng, nd, npn, float(lmd), self.hide_cell_type,
@@ -131,6 +153,12 @@ class Critic(object):
         batch = x.shape[0]
         gx = torch.empty((batch, self.nx), device=self.device, dtype=torch.float32)
         ws = self._workspace(batch, batch)
+        if self.layer_norm:
+            clib.check(libssnode.ssn_critic_input_grad_norm(
+                self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
+                self.hide_cell_type, float(scale), gx.data_ptr(), self.stats.data_ptr(), ws.data_ptr(), self.precision,
+                _stream()), 'ssn_critic_input_grad_norm')
+            return gx, self.stats[0]
         clib.check(libssnode.ssn_critic_input_grad(
             self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
             self.hide_cell_type, float(scale), gx.data_ptr(), self.stats.data_ptr(), ws.data_ptr(), self.precision,

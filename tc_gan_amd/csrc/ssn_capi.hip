@@ -225,6 +225,33 @@ int ssn_critic_input_grad(const float* params, const int* dims, int nlayers, con
                                    precision == 0, (hipStream_t)stream));
     return 0;
 }
+size_t ssn_critic_norm_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p) {
+    return ssn::critic_norm_workspace_floats(dims, nlayers, batch_gd, batch_p);
+}
+int ssn_critic_forward_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* x,
+                            const float* cond, int batch, int hide_cell_type, float* out, float* workspace, int precision,
+                            void* stream) {
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_norm_forward(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, out, workspace,
+                                     precision == 0, (hipStream_t)stream));
+    return 0;
+}
+int ssn_critic_loss_grad_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* xg,
+                              const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
+                              int nd, int np, float lmd, int hide_cell_type, float* grads, float* stats, float* dvals,
+                              float* workspace, int precision, void* stream) {
+    SSN_TRY(ssn::critic_norm_loss_grad(params, dims, layer_norm, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd,
+                                       hide_cell_type, grads, stats, dvals, workspace, precision == 0, (hipStream_t)stream));
+    return 0;
+}
+int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* x,
+                               const float* cond, int batch, int hide_cell_type, float scale, float* gx, float* stats,
+                               float* workspace, int precision, void* stream) {
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_norm_input_grad(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
+                                        workspace, precision == 0, (hipStream_t)stream));
+    return 0;
+}
 int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, void* stream) {
     if (!o || n < 0 || o->kind < 0 || o->kind > 2) {
         g_last_error = "ssn_optimizer_step: invalid argument";

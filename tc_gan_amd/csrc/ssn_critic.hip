@@ -456,6 +456,42 @@ hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, 
 }
 
 // ---------------------------------------------------------------------------------
+// building blocks exported to ssn_critic_ln.hip
+// ---------------------------------------------------------------------------------
+hipError_t critic_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                       int M, int N, int K, float alpha, float beta, bool bf16, hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.sam = sam; g.sak = sak; g.B = B; g.sbk = sbk; g.sbn = sbn; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta; g.epilogue = EPI_PLAIN;
+    return gemm(g, bf16, st);
+}
+hipError_t critic_colsum(const float* X, float* out, int batch, int n, float beta, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64), dim3(256), 0, st, X, out, batch, n, beta);
+    return hipGetLastError();
+}
+hipError_t critic_make_input(const float* x, const float* cond, float* h0, int batch, int nx, int hide, hipStream_t st) {
+    if (batch == 0) return hipSuccess;
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * (nx + 3))), dim3(256), 0, st, x, cond, h0, batch, nx, hide);
+    return hipGetLastError();
+}
+hipError_t critic_gp_head(const float* g, float* ghat, float* pen, int batch, int n0, int nx, hipStream_t st) {
+    hipLaunchKernelGGL(gp_head_kernel, dim3(1), dim3(256), 0, st, g, ghat, pen, batch, n0, nx);
+    return hipGetLastError();
+}
+hipError_t critic_two_means(const float* d, float* out, int ng, int nd, hipStream_t st) {
+    hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, d, out, ng, nd);
+    return hipGetLastError();
+}
+hipError_t critic_loss_combine(float* stats, float lmd, hipStream_t st) {
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
+    return hipGetLastError();
+}
+hipError_t critic_gather_scale(const float* v0, float* gx, int batch, int n0, int nx, float s, hipStream_t st) {
+    hipLaunchKernelGGL(gather_scale_kernel, dim3(blocks_for((long)batch * nx)), dim3(256), 0, st, v0, gx, batch, n0, nx, s);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------
 // optimizers (wgan.py:111-165 on top of lasagne.updates.{adam,rmsprop,sgd})
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) optimizer_kernel(OptArgs o) {

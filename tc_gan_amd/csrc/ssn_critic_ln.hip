@@ -1,0 +1,321 @@
+// Critic with per-layer Layer Normalization (networks/simple_discriminator.py:6-75:
+// Dense(no bias) -> LayerNorm (no parameters, biased variance, eps = 1e-4 of Lasagne's
+// BatchNormLayer) -> Bias -> ReLU), including the WGAN-GP double backward through the
+// normalisation.  Layers flagged 0 are the plain Dense+bias+ReLU layers of ssn_critic.hip.
+//
+// Per layer l (a = h_{l-1} W_l; y = LN(a) or a; h_l = relu(y + b_l)):
+//   LNback(x; y, 1/s) = (x - mean(x) - y mean(x.y)) / s          (row-wise, symmetric operator)
+//   input-gradient chain   p_l = m_l u_l,  c_l = LNback(p_l),  u_{l-1} = c_l W_l^T,  g = u_0
+//   penalty backward, sweep 1 (l = 1..L, du_0 = dP/dg):
+//       dW_l += du_{l-1}^T c_l;  dc_l = du_{l-1} W_l;  dp_l = LNback(dc_l);
+//       dyA_l = -(dc_l q + p_l r)/s  with q = mean(p.y), r = mean(dc.y);   dsA_l = -sum(dc.c)/s;
+//       du_l = m_l dp_l;                                   dw_out += colsum(du_L)
+//   sweep 2 (l = L..1, dh_L = 0): ordinary backprop of the a_l-dependence:
+//       dpre = m_l dh_l;  db_l += colsum(dpre);  dy = dyA_l + dpre;
+//       da = LNback(dy) + dsA_l y / n;  dW_l += h_{l-1}^T da;  dh_{l-1} = da W_l^T
+// (derivation in DESIGN.md section 3.8; checked against torch autograd of oracle/gan_torch.py).
+#include <hip/hip_runtime.h>
+#include "ssn_host.h"
+
+namespace ssn {
+
+// from ssn_critic.hip
+hipError_t critic_gemm(const float* A, long sam, long sak, const float* B, long sbk, long sbn, float* C, long ldc,
+                       int M, int N, int K, float alpha, float beta, bool bf16, hipStream_t st);
+hipError_t critic_colsum(const float* X, float* out, int batch, int n, float beta, hipStream_t st);
+hipError_t critic_make_input(const float* x, const float* cond, float* h0, int batch, int nx, int hide, hipStream_t st);
+hipError_t critic_gp_head(const float* g, float* ghat, float* pen, int batch, int n0, int nx, hipStream_t st);
+hipError_t critic_two_means(const float* d, float* out, int ng, int nd, hipStream_t st);
+hipError_t critic_loss_combine(float* stats, float lmd, hipStream_t st);
+hipError_t critic_gather_scale(const float* v0, float* gx, int batch, int n0, int nx, float s, hipStream_t st);
+
+constexpr float LN_EPS = 1e-4f;
+
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// One wave per row.  mode 0: forward  a -> (y, invs, h = relu(y + b));  ln = 0: y = a.
+__global__ void __launch_bounds__(64) ln_forward_kernel(const float* __restrict__ a, const float* __restrict__ bias,
+                                                        float* __restrict__ y, float* __restrict__ invs,
+                                                        float* __restrict__ h, int n, int ln) {
+    const long row = blockIdx.x;
+    const float* ar = a + row * n;
+    float mu = 0.f, is = 1.f;
+    if (ln) {
+        float s = 0.f;
+        for (int j = threadIdx.x; j < n; j += 64) s += ar[j];
+        mu = wave_sum_f(s) / n;
+        float v = 0.f;
+        for (int j = threadIdx.x; j < n; j += 64) { const float d = ar[j] - mu; v += d * d; }
+        is = rsqrtf(wave_sum_f(v) / n + LN_EPS);
+    }
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const float yy = (ar[j] - mu) * is;
+        y[row * n + j] = yy;
+        const float pre = yy + bias[j];
+        h[row * n + j] = pre > 0.f ? pre : 0.f;
+    }
+    if (threadIdx.x == 0) invs[row] = is;
+}
+
+// out = LNback(x [* (mask > 0)]; y, invs)   (ln = 0: out = masked x).  `rowscale` (optional) multiplies x per row.
+__global__ void __launch_bounds__(64) ln_back_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                     const float* __restrict__ y, const float* __restrict__ invs,
+                                                     float* __restrict__ out, float* __restrict__ xmasked, int n, int ln) {
+    const long row = blockIdx.x;
+    float sx = 0.f, sxy = 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const long o = row * n + j;
+        const float v = (!mask || mask[o] > 0.f) ? x[o] : 0.f;
+        sx += v; sxy += v * y[o];
+    }
+    const float mx = wave_sum_f(sx) / n, mxy = wave_sum_f(sxy) / n, is = invs[row];
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const long o = row * n + j;
+        const float v = (!mask || mask[o] > 0.f) ? x[o] : 0.f;
+        if (xmasked) xmasked[o] = v;
+        out[o] = ln ? (v - mx - y[o] * mxy) * is : v;
+    }
+}
+
+// Sweep-1 row op: given dc, p, c, y, invs, mask(h):  du = m * LNback(dc);  dyA = -(dc q + p r) invs;  dsA = -sum(dc c) invs
+__global__ void __launch_bounds__(64) ln_sweep1_kernel(const float* __restrict__ dc, const float* __restrict__ p,
+                                                       const float* __restrict__ c, const float* __restrict__ y,
+                                                       const float* __restrict__ invs, const float* __restrict__ hmask,
+                                                       float* __restrict__ du, float* __restrict__ dyA,
+                                                       float* __restrict__ dsA, int n, int ln) {
+    const long row = blockIdx.x;
+    float sdc = 0.f, sdcy = 0.f, spy = 0.f, sdcc = 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const long o = row * n + j;
+        sdc += dc[o]; sdcy += dc[o] * y[o]; spy += p[o] * y[o]; sdcc += dc[o] * c[o];
+    }
+    const float mdc = wave_sum_f(sdc) / n, r = wave_sum_f(sdcy) / n, q = wave_sum_f(spy) / n, is = invs[row];
+    const float tot = wave_sum_f(sdcc);
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const long o = row * n + j;
+        const float dp = ln ? (dc[o] - mdc - y[o] * r) * is : dc[o];
+        du[o] = (hmask[o] > 0.f) ? dp : 0.f;
+        dyA[o] = ln ? -(dc[o] * q + p[o] * r) * is : 0.f;
+    }
+    if (threadIdx.x == 0) dsA[row] = ln ? -tot * is : 0.f;
+}
+
+// Sweep-2 row op: dpre = m * dh (dh may be null = 0);  dy = dyA + dpre;  da = LNback(dy) + dsA y / n   (ln = 0: da = dy)
+__global__ void __launch_bounds__(64) ln_sweep2_kernel(const float* __restrict__ dh, const float* __restrict__ hmask,
+                                                       const float* __restrict__ dyA, const float* __restrict__ dsA,
+                                                       const float* __restrict__ y, const float* __restrict__ invs,
+                                                       float* __restrict__ dpre, float* __restrict__ da, int n, int ln) {
+    const long row = blockIdx.x;
+    float sd = 0.f, sdy = 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const long o = row * n + j;
+        const float dp = (dh && hmask[o] > 0.f) ? dh[o] : 0.f;
+        dpre[o] = dp;
+        const float d = (dyA ? dyA[o] : 0.f) + dp;
+        sd += d; sdy += d * y[o];
+    }
+    const float md = wave_sum_f(sd) / n, mdy = wave_sum_f(sdy) / n, is = invs[row];
+    const float ds = dsA ? dsA[row] : 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) {
+        const long o = row * n + j;
+        const float d = (dyA ? dyA[o] : 0.f) + dpre[o];
+        da[o] = ln ? (d - md - y[o] * mdy) * is + ds * y[o] / n : d;
+    }
+}
+
+// p_L[b][k] = (h_L > 0) * w_out[k] * up[b]
+__global__ void __launch_bounds__(256) top_seed_kernel(const float* __restrict__ wout, const float* __restrict__ up,
+                                                       float* __restrict__ uL, int batch, int nL) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)batch * nL; e += gridDim.x * 256L)
+        uL[e] = wout[e % nL] * (up ? up[e / nL] : 1.f);
+}
+__global__ void __launch_bounds__(256) fill_updown2_kernel(float* up, int ng, int nd) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ng + nd; i += gridDim.x * 256)
+        up[i] = (i < ng) ? 1.f / (float)ng : -1.f / (float)nd;
+}
+__global__ void __launch_bounds__(256) scale_kernel(float* x, float a, long n) {
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += gridDim.x * 256L) x[e] *= a;
+}
+
+static int nblk(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+
+struct NormNet {
+    int L; int dims[10]; int ln[9];
+    const float* W[9]; const float* b[9]; const float* wout; long offW[9], offb[9], offout, nparams;
+};
+static bool parse_norm_net(const float* params, const int* dims, const int* norm, int nlayers, NormNet& net) {
+    if (nlayers < 0 || nlayers > 8) return false;
+    net.L = nlayers;
+    long off = 0;
+    for (int l = 0; l <= nlayers; ++l) net.dims[l] = dims[l];
+    for (int l = 0; l < nlayers; ++l) {
+        net.ln[l] = norm ? norm[l] : 0;
+        net.offW[l] = off; net.W[l] = params + off; off += (long)dims[l] * dims[l + 1];
+        net.offb[l] = off; net.b[l] = params + off; off += dims[l + 1];
+    }
+    net.offout = off; net.wout = params + off; off += dims[nlayers];
+    net.nparams = off;
+    return true;
+}
+
+struct Acts {            // per batch of rows
+    float *h[10], *y[10], *invs[10], *u[10], *p[10], *c[10];
+};
+static float* carve(float*& p, long n) { float* r = p; p += n; return r; }
+static void carve_acts(float*& p, const NormNet& net, int rows, Acts& A) {
+    for (int l = 0; l <= net.L; ++l) {
+        A.h[l] = carve(p, (long)rows * net.dims[l]);
+        A.y[l] = carve(p, (long)rows * net.dims[l]);
+        A.invs[l] = carve(p, rows);
+        A.u[l] = carve(p, (long)rows * net.dims[l]);
+        A.p[l] = carve(p, (long)rows * net.dims[l]);
+        A.c[l] = carve(p, (long)rows * net.dims[l]);
+    }
+}
+
+static hipError_t norm_forward(const NormNet& net, const Acts& A, float* dout, int rows, bool bf16, hipStream_t st) {
+    hipError_t e;
+    for (int l = 0; l < net.L; ++l) {
+        const int nin = net.dims[l], nout = net.dims[l + 1];
+        // a -> stored temporarily in u[l+1]
+        if ((e = critic_gemm(A.h[l], nin, 1, net.W[l], nout, 1, A.u[l + 1], nout, rows, nout, nin, 1.f, 0.f, bf16, st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(ln_forward_kernel, dim3(rows), dim3(64), 0, st, A.u[l + 1], net.b[l], A.y[l + 1], A.invs[l + 1],
+                           A.h[l + 1], nout, net.ln[l]);
+    }
+    return critic_gemm(A.h[net.L], net.dims[net.L], 1, net.wout, 1, 1, dout, 1, rows, 1, net.dims[net.L], 1.f, 0.f, bf16, st);
+}
+
+// input-gradient chain given per-row upstream `up` of D: fills p, c, u; u[0] = dD/dh0 (times up)
+static hipError_t norm_chain(const NormNet& net, const Acts& A, const float* up, int rows, bool bf16, hipStream_t st) {
+    hipError_t e;
+    const int L = net.L;
+    hipLaunchKernelGGL(top_seed_kernel, dim3(nblk((long)rows * net.dims[L])), dim3(256), 0, st, net.wout, up, A.u[L], rows, net.dims[L]);
+    for (int l = L; l >= 1; --l) {
+        const int nin = net.dims[l - 1], nout = net.dims[l];
+        // p_l = m_l u_l ; c_l = LNback(p_l)
+        hipLaunchKernelGGL(ln_back_kernel, dim3(rows), dim3(64), 0, st, A.u[l], A.h[l], A.y[l], A.invs[l], A.c[l], A.p[l], nout, net.ln[l - 1]);
+        // u_{l-1} = c_l W_l^T
+        if ((e = critic_gemm(A.c[l], nout, 1, net.W[l - 1], 1, nout, A.u[l - 1], nin, rows, nin, nout, 1.f, 0.f, bf16, st)) != hipSuccess) return e;
+    }
+    return hipGetLastError();
+}
+
+// standard parameter gradient of sum_b up_b D_b given the chain results (c_l = dL/da_l, p_l = dL/dpre_l)
+static hipError_t norm_param_grads(const NormNet& net, const Acts& A, const float* up, float* grads, int rows, bool bf16, hipStream_t st) {
+    hipError_t e;
+    const int L = net.L;
+    // w_out: sum_b up_b h_L
+    if ((e = critic_gemm(A.h[L], 1, net.dims[L], up, 1, 1, grads + net.offout, 1, net.dims[L], 1, rows, 1.f, 1.f, bf16, st)) != hipSuccess) return e;
+    for (int l = 1; l <= L; ++l) {
+        const int nin = net.dims[l - 1], nout = net.dims[l];
+        if ((e = critic_gemm(A.h[l - 1], 1, nin, A.c[l], nout, 1, grads + net.offW[l - 1], nout, nin, nout, rows, 1.f, 1.f, bf16, st)) != hipSuccess) return e;
+        if ((e = critic_colsum(A.p[l], grads + net.offb[l - 1], rows, nout, 1.f, st)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+size_t critic_norm_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p) {
+    long per_row = 0, maxd = 0;
+    for (int l = 0; l <= nlayers; ++l) { per_row += dims[l]; if (dims[l] > maxd) maxd = dims[l]; }
+    const long acts = 5 * per_row + (nlayers + 1);
+    return (size_t)((long)batch_gd * (acts + 1) + (long)batch_p * (acts + 6 * per_row + (nlayers + 1) + 1) + 2 * maxd + 64);
+}
+
+hipError_t critic_norm_forward(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
+                               const float* cond, int batch, int hide, float* out, float* ws, bool bf16, hipStream_t st) {
+    NormNet net;
+    if (!parse_norm_net(params, dims, norm, nlayers, net)) return hipErrorInvalidValue;
+    hipError_t e;
+    float* p = ws;
+    Acts A;
+    carve_acts(p, net, batch, A);
+    if ((e = critic_make_input(x, cond, A.h[0], batch, dims[0] - 3, hide, st)) != hipSuccess) return e;
+    return norm_forward(net, A, out, batch, bf16, st);
+}
+
+hipError_t critic_norm_input_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
+                                  const float* cond, int batch, int hide, float scale, float* gx, float* stats, float* ws,
+                                  bool bf16, hipStream_t st) {
+    NormNet net;
+    if (!parse_norm_net(params, dims, norm, nlayers, net)) return hipErrorInvalidValue;
+    hipError_t e;
+    float* p = ws;
+    Acts A;
+    carve_acts(p, net, batch, A);
+    float* dv = carve(p, batch);
+    if ((e = critic_make_input(x, cond, A.h[0], batch, dims[0] - 3, hide, st)) != hipSuccess) return e;
+    if ((e = norm_forward(net, A, dv, batch, bf16, st)) != hipSuccess) return e;
+    if ((e = critic_two_means(dv, stats, batch, 0, st)) != hipSuccess) return e;
+    if ((e = norm_chain(net, A, nullptr, batch, bf16, st)) != hipSuccess) return e;
+    return critic_gather_scale(A.u[0], gx, batch, dims[0], dims[0] - 3, scale, st);
+}
+
+hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* xg,
+                                 const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
+                                 int nd, int np, float lmd, int hide, float* grads, float* stats, float* dvals, float* ws,
+                                 bool bf16, hipStream_t st) {
+    NormNet net;
+    if (!parse_norm_net(params, dims, norm, nlayers, net)) return hipErrorInvalidValue;
+    hipError_t e;
+    const int L = nlayers, nx = dims[0] - 3, bgd = ng + nd;
+    if ((e = hipMemsetAsync(grads, 0, net.nparams * sizeof(float), st)) != hipSuccess) return e;
+    float* p = ws;
+    // ---- (1) mean D(xg) - mean D(xd) -----------------------------------------------------------------
+    Acts A;
+    carve_acts(p, net, bgd, A);
+    float* up = carve(p, bgd);
+    if ((e = critic_make_input(xg, cg, A.h[0], ng, nx, hide, st)) != hipSuccess) return e;
+    if ((e = critic_make_input(xd, cd, A.h[0] + (long)ng * dims[0], nd, nx, hide, st)) != hipSuccess) return e;
+    if ((e = norm_forward(net, A, dvals, bgd, bf16, st)) != hipSuccess) return e;
+    if ((e = critic_two_means(dvals, stats, ng, nd, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(fill_updown2_kernel, dim3(nblk(bgd)), dim3(256), 0, st, up, ng, nd);
+    if ((e = norm_chain(net, A, up, bgd, bf16, st)) != hipSuccess) return e;
+    if ((e = norm_param_grads(net, A, up, grads, bgd, bf16, st)) != hipSuccess) return e;
+
+    // ---- (2) gradient penalty ------------------------------------------------------------------------
+    Acts P;
+    carve_acts(p, net, np, P);
+    float* dp = carve(p, np);
+    float *du[10], *dc[10], *dyA[10], *dsA[10], *dpre[10], *da[10];
+    for (int l = 0; l <= L; ++l) {
+        du[l] = carve(p, (long)np * dims[l]); dc[l] = carve(p, (long)np * dims[l]); dyA[l] = carve(p, (long)np * dims[l]);
+        dpre[l] = carve(p, (long)np * dims[l]); da[l] = carve(p, (long)np * dims[l]); dsA[l] = carve(p, np);
+    }
+    // (dh_{l-1} of sweep 2 is written into dc[l-1], which is free by then)
+    if ((e = critic_make_input(xp, cp, P.h[0], np, nx, hide, st)) != hipSuccess) return e;
+    if ((e = norm_forward(net, P, dp, np, bf16, st)) != hipSuccess) return e;
+    if ((e = norm_chain(net, P, nullptr, np, bf16, st)) != hipSuccess) return e;
+    // du_0 = lmd * dP/dg
+    if ((e = critic_gp_head(P.u[0], du[0], stats + 2, np, dims[0], nx, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(scale_kernel, dim3(nblk((long)np * dims[0])), dim3(256), 0, st, du[0], lmd, (long)np * dims[0]);
+    // sweep 1
+    for (int l = 1; l <= L; ++l) {
+        const int nin = dims[l - 1], nout = dims[l];
+        if ((e = critic_gemm(du[l - 1], 1, nin, P.c[l], nout, 1, grads + net.offW[l - 1], nout, nin, nout, np, 1.f, 1.f, bf16, st)) != hipSuccess) return e;
+        if ((e = critic_gemm(du[l - 1], nin, 1, net.W[l - 1], nout, 1, dc[l], nout, np, nout, nin, 1.f, 0.f, bf16, st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(ln_sweep1_kernel, dim3(np), dim3(64), 0, st, dc[l], P.p[l], P.c[l], P.y[l], P.invs[l], P.h[l],
+                           du[l], dyA[l], dsA[l], nout, net.ln[l - 1]);
+    }
+    // u_L = w_out (the same row for every sample): dw_out += colsum(du_L)
+    if ((e = critic_colsum(du[L], grads + net.offout, np, dims[L], 1.f, st)) != hipSuccess) return e;
+    // sweep 2
+    const float* dh_cur = nullptr;
+    for (int l = L; l >= 1; --l) {
+        const int nin = dims[l - 1], nout = dims[l];
+        hipLaunchKernelGGL(ln_sweep2_kernel, dim3(np), dim3(64), 0, st, dh_cur, P.h[l], dyA[l], dsA[l], P.y[l], P.invs[l],
+                           dpre[l], da[l], nout, net.ln[l - 1]);
+        if ((e = critic_colsum(dpre[l], grads + net.offb[l - 1], np, nout, 1.f, st)) != hipSuccess) return e;
+        if ((e = critic_gemm(P.h[l - 1], 1, nin, da[l], nout, 1, grads + net.offW[l - 1], nout, nin, nout, np, 1.f, 1.f, bf16, st)) != hipSuccess) return e;
+        if (l > 1) {
+            if ((e = critic_gemm(da[l], nout, 1, net.W[l - 1], 1, nout, dc[l - 1], nin, np, nin, nout, 1.f, 0.f, bf16, st)) != hipSuccess) return e;
+            dh_cur = dc[l - 1];
+        }
+    }
+    return critic_loss_combine(stats, lmd, st);
+}
+
+}  // namespace ssn

@@ -102,3 +102,36 @@ def test_optimizer_steps_vs_oracle(name, cfg):
         pn = pn - 0.01 * 1e-2 * po - 0.01 * 3e-3 * np.sign(po)       # wgan.py:158-163 (decay on the old value)
         po = np.clip(pn, -2.5, 2.5)
         np.testing.assert_allclose(pd.cpu().numpy(), po, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('batch,nx,layers,norm', [
+    (9, 4, [12], 'layer'), (64, 8, [32, 32], 'layer'), (130, 8, [128, 128, 128, 128], ['none', 'layer', 'layer', 'layer']),
+    (48, 8, [24, 24], ['layer', 'none']), (40, 6, [16, 16], 'none')])
+def test_layer_normalised_critic_loss_gradient_and_input_gradient(batch, nx, layers, norm):
+    """Layer-normalised critic (simple_discriminator.py:6-75; the paper's 4x128 critic normalises layers 2-4):
+    loss, parameter gradient INCLUDING the WGAN-GP double backward through the normalisation, and the
+    generator-side input gradient, against torch autograd on the fp64 restatement."""
+    from tc_gan_amd.critic import Critic
+    rs = np.random.RandomState(batch + len(layers))
+    c = Critic(nx, layers, seed=batch, precision='fp32', normalization=norm)
+    if norm != 'none':
+        c.layer_norm = True          # also drive all-plain nets through the general path
+    params_o = [og.t64(p) for p in c.get_param_values()]
+    xg, xd = rs.rand(batch, nx) * 5, rs.rand(batch, nx) * 5
+    eps = rs.rand(batch, 1)
+    xp = eps * xd + (1 - eps) * xg
+    cond = np.stack([np.full(batch, 20.), rs.rand(batch) * 2 - 1, rs.randint(0, 2, batch)], axis=1)
+    tg, td, tp, tc = (og.t64(a) for a in (xg, xd, xp, cond))
+    ps = [p.clone().requires_grad_(True) for p in params_o]
+    loss_o = og.critic_loss(ps, tg, td, tp, tc, tc, tc, 10.0, normalization=norm)
+    flat_o = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(loss_o, ps)])
+    stats = c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(loss_o.detach()), rtol=5e-5, atol=5e-5)
+    got = c.grads.cpu().numpy()
+    np.testing.assert_allclose(got, flat_o, rtol=2e-3, atol=1e-4 * np.abs(flat_o).max())
+    np.testing.assert_allclose(c.forward(xg, cond).cpu().numpy(),
+                               og.critic_forward(params_o, tg, tc, normalization=norm)[:, 0].numpy(), rtol=2e-4, atol=2e-5)
+    x = tg.clone().requires_grad_(True)
+    gx_o, = torch.autograd.grad(-og.critic_forward(params_o, x, tc, normalization=norm).mean(), x)
+    gx, _ = c.input_grad(xg, cond, scale=-1.0 / batch)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_o.numpy(), rtol=2e-3, atol=1e-6)

@@ -25,6 +25,7 @@ def _load_tables(directory, store):
     ['--sample-sites', '0, 0.5', '--probes-per-model', '2'],
     ['--contrasts', '5, 20'],
     ['--include-inhibitory-neurons', '--dataset-provider', 'fixedtime'],
+    ['--disc-normalization', 'layer'],
     ['--ssn-type', 'heteroin', '--dataset-provider', 'fixedtime'],
     ['--ssn-type', 'deg-heteroin', '--dataset-provider', 'fixedtime', '--include-inhibitory-neurons'],
 ])
