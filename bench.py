@@ -34,6 +34,7 @@ WORKLOADS = {
     # name: (N, B, NB, T, description)
     'c2': (100, 4096, 1, 2000, 'C2: SSN fixed-point forward, 2N=200, batch 4096, NB=1 stimulus, 2000 Euler steps'),
     'c2nb8': (100, 4096, 8, 2000, 'C2/NB=8: 2N=200, batch 4096, 8 stimuli per draw, 2000 Euler steps'),
+    'm152': (76, 4096, 1, 2000, 'probe: 2N=152, batch 4096, NB=1, 2000 Euler steps'),
     'c1': (50, 64, 1, 500, 'C1: 2N=100, batch 64, NB=1, 500 Euler steps'),
 }
 
@@ -249,7 +250,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c5'])
-    ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 register-stationary tile')
+    ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 tile (library picks the shape), '
+                    '3 tile with 5 rows per lane, 4 tile with 7 rows per lane')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
     args = ap.parse_args()
@@ -362,7 +364,7 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': desc + ', asym_tanh, atol=0, fp32, W rebuilt from resident z each step',
                    'neurons': M, 'batch_per_gpu': B, 'stimuli_per_draw': NB, 'euler_steps': T,
-                   'kernel': {2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
+                   'kernel': {5: 'probe', 4: 'solve_tile_kernel (7 rows per lane)', 3: 'solve_tile_kernel (5 rows per lane)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
                    'parallelism': 'draws sharded over %d GPU(s), no data-path collective' % world},
         'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,

@@ -37,15 +37,18 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     a.io = ssn::make_io_consts<T>(*p);
     a.st = ssn::make_step_consts<T>(*p);
     hipStream_t st = (hipStream_t)stream;
-    // variant: -1 auto (tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile
+    // variant: -1 auto (tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
+    // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs
     const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
-    if ((variant == 1 && !regw_ok) || (variant == 2 && !tile_ok) || variant > 2) {
+    if ((variant == 1 && !regw_ok) || (variant >= 2 && !tile_ok) || variant > 4) {
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
     if (variant < 0) variant = tile_ok ? 2 : (regw_ok ? 1 : 0);
     switch (variant) {
-        case 2: SSN_TRY(ssn::launch_tile<T>(a, st)); break;
+        case 2: SSN_TRY(ssn::launch_tile<T>(a, st, 0)); break;
+        case 3: SSN_TRY(ssn::launch_tile<T>(a, st, 1)); break;
+        case 4: SSN_TRY(ssn::launch_tile<T>(a, st, 2)); break;
         case 1: SSN_TRY(ssn::launch_regw<T>(a, st)); break;
         default: SSN_TRY(ssn::launch_stream<T>(a, st)); break;
     }
@@ -135,6 +138,8 @@ double legacy_io(int io_type, double v, double r0, double r1, double v0, double 
     c.io_type = io_type; c.k = k; c.n = n; c.v0 = v0; c.soft = r0; c.hard = r1;
     c.lin_slope = k * std::pow(v0, n - 1.0) * n;
     c.tanh_gain = n * r0 / ((r1 - r0) * v0);
+    c.span = r1 - r0;
+    c.span_gain = c.span * c.tanh_gain;
     double *dv = nullptr, out = std::numeric_limits<double>::quiet_NaN();
     if (hipMalloc(&dv, 2 * sizeof(double)) != hipSuccess) return out;
     if (hipMemcpy(dv, &v, sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&

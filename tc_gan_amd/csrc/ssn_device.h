@@ -18,6 +18,8 @@ struct IoConsts {
     T soft, hard;  // rate_soft_bound, rate_hard_bound
     T lin_slope;   // k * v0^(n-1) * n                      ssnode.c:41
     T tanh_gain;   // n * soft / ((hard - soft) * v0)       ssnode.c:51
+    T span;        // hard - soft        (host-side so that it arrives as a kernel argument in an SGPR
+    T span_gain;   // span * tanh_gain    instead of being recomputed into a VGPR by every wave)
 };
 
 template <typename T>
@@ -41,6 +43,8 @@ inline IoConsts<T> make_io_consts(const ssn_solver_params& p) {
     c.hard = (T)p.rate_hard_bound;
     c.lin_slope = (T)(p.k * pow(v0, p.n - 1.0) * p.n);
     c.tanh_gain = (T)(p.n * p.rate_soft_bound / ((p.rate_hard_bound - p.rate_soft_bound) * v0));
+    c.span = c.hard - c.soft;
+    c.span_gain = c.span * c.tanh_gain;
     return c;
 }
 
@@ -76,7 +80,7 @@ __device__ __forceinline__ T io_eval(T v, const IoConsts<T>& c) {
     if (!(v > (T)0)) return (v != v) ? v : (T)0;   // v <= 0 -> 0; NaN propagates like pow(NaN)
     if (c.io_type == SSN_IO_POWER || v <= c.v0) return pow_rate(v, c.k, c.n);
     if (c.io_type == SSN_IO_LINEAR) return c.soft + c.lin_slope * (v - c.v0);
-    return c.soft + (c.hard - c.soft) * tanh_pos(c.tanh_gain * (v - c.v0));
+    return c.soft + c.span * tanh_pos(c.tanh_gain * (v - c.v0));
 }
 
 __device__ __forceinline__ float abs_t(float x) { return __builtin_fabsf(x); }

@@ -35,14 +35,15 @@ __device__ __forceinline__ void io_eval_grad(T v, const IoConsts<T>& c, T& f, T&
     }
     if (c.io_type == SSN_IO_LINEAR) { f = c.soft + c.lin_slope * (v - c.v0); df = c.lin_slope; return; }
     const T th = tanh_pos(c.tanh_gain * (v - c.v0));
-    f = c.soft + (c.hard - c.soft) * th;
-    df = (c.hard - c.soft) * c.tanh_gain * ((T)1 - th * th);
+    f = c.soft + c.span * th;
+    df = c.span_gain * ((T)1 - th * th);
 }
 
-template <typename T, int RA, int C, int NB, int MAXTHREADS, int MINWAVES>
+template <typename T, int RA, int C, int RL, int NB, int MAXTHREADS, int MINWAVES>
 __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFwdArgs<T> a) {
     constexpr int CP = SlabPad<C>::value;
     __shared__ __align__(16) T rbuf[2][NB][8 * CP];
+    __shared__ __align__(16) T wlds[TileSplit<RA, C, RL>::lds_elems(MAXTHREADS)];   // RL > 0: see ssn_tile_core.h
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
     const int ngroups = (a.NB + NB - 1) / NB;
     const int b = blockIdx.x / ngroups;
@@ -51,14 +52,13 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFw
     const int cg = lane & 7, rg = lane >> 3;
     const int rowbase = (8 * wave + rg) * RA;
 
-    T w[RA][C];
-    tile_load<T, RA, C, false>(a.W + (size_t)b * M * M, M, rowbase, cg * C, w);
+    T w[RA - RL][C];
+    tile_load_split<T, RA, C, RL, false>(a.W + (size_t)b * M * M, M, rowbase, cg * C, w, wlds, threadIdx.x);
 
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
     const int myslot = (myrow / C) * CP + (myrow % C);
     const T eps = (myrow < N) ? a.eps_E : a.eps_I;
-    const T oneme = (T)1 - eps;
     T rc[NB], ex[NB], ta[NB], dp[NB], rpn[NB];
     bool live[NB];
 #pragma unroll
@@ -70,16 +70,21 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFw
     for (int c = threadIdx.x; c < 2 * NB * 8 * CP; c += blockDim.x) (&rbuf[0][0][0])[c] = (T)0;
     __syncthreads();
 
+    // trajectory addressing: uniform (SGPR) pointer to row `it` of the block's first stimulus + a 32-bit lane
+    // offset, instead of one 64-bit VGPR address pair per stream
+    const size_t blk = ((size_t)b * a.NB + s0) * T_ * M;
+    const unsigned stim_stride = (unsigned)T_ * (unsigned)M;
     int cur = 0;
     for (int it = 0; it < T_; ++it) {
         T acc[NB][8];
-        tile_matvec<T, RA, C, NB>(w, &rbuf[cur][0][0], cg, acc);
+        if constexpr (RL > 0) tile_matvec_split<T, RA, C, RL, NB>(w, wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
+        else tile_matvec<T, RA, C, NB>(w, &rbuf[cur][0][0], cg, acc);
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
             const T u = reduce8_to_lane(acc[s], cg) + ex[s];
             T f, dfv;
             io_eval_grad(u, a.io, f, dfv);
-            const T r1 = oneme * rc[s] + eps * f;
+            const T r1 = fma(eps, f - rc[s], rc[s]);          // (1 - eps) r + eps f(u)
             if (live[s]) {
                 if (it >= a.skip) {
                     ta[s] += r1;
@@ -87,9 +92,9 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFw
                     if (it > a.skip) { const T d = r1 - rc[s]; dp[s] += d * d; }
                 }
                 if (a.traj) {
-                    const size_t o = (((size_t)b * a.NB + s0 + s) * T_ + it) * M + myrow;
-                    a.traj[o] = r1;
-                    a.df[o] = dfv;
+                    const unsigned lo = (unsigned)s * stim_stride + (unsigned)myrow;
+                    (a.traj + blk + (size_t)it * M)[lo] = r1;
+                    (a.df + blk + (size_t)it * M)[lo] = dfv;
                 }
                 rc[s] = r1;
                 rbuf[cur ^ 1][s][myslot] = r1;
@@ -110,10 +115,11 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFw
 }
 
 // Reverse-time adjoint sweep.  The lane that finishes row j owns a_t[j]; the tile holds W^T.
-template <typename T, int RA, int C, int NB, int MAXTHREADS, int MINWAVES>
+template <typename T, int RA, int C, int RL, int NB, int MAXTHREADS, int MINWAVES>
 __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenBwdArgs<T> a) {
     constexpr int CP = SlabPad<C>::value;
     __shared__ __align__(16) T dbuf[2][NB][8 * CP];
+    __shared__ __align__(16) T wlds[TileSplit<RA, C, RL>::lds_elems(MAXTHREADS)];
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
     const int ngroups = (a.NB + NB - 1) / NB;
     const int b = blockIdx.x / ngroups;
@@ -122,30 +128,33 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
     const int cg = lane & 7, rg = lane >> 3;
     const int rowbase = (8 * wave + rg) * RA;
 
-    T wt[RA][C];   // tile element (row j, col i) = W[i][j]
-    tile_load<T, RA, C, true>(a.W + (size_t)b * M * M, M, rowbase, cg * C, wt);
+    T wt[RA - RL][C];   // tile element (row j, col i) = W[i][j]
+    tile_load_split<T, RA, C, RL, true>(a.W + (size_t)b * M * M, M, rowbase, cg * C, wt, wlds, threadIdx.x);
 
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
     const int myslot = (myrow / C) * CP + (myrow % C);
     const T eps = (myrow < N) ? a.eps_E : a.eps_I;
-    const T oneme = (T)1 - eps;
     const T inv = (T)1 / (T)(T_ - a.skip);
     bool live[NB];
-    size_t base[NB];
+    // uniform (SGPR) block pointers + 32-bit lane offsets (lo[s] = s*T*M + myrow)
+    const size_t blk = ((size_t)b * a.NB + s0) * T_ * M;
+    const T* trj = a.traj + blk;
+    T* dlt = a.delta + blk;
+    unsigned lo[NB];
     T gta[NB], carry[NB], xn[NB], xc[NB], xm[NB], dfc[NB], dsum[NB];
 #pragma unroll
     for (int s = 0; s < NB; ++s) {
         live[s] = fin && (s0 + s) < a.NB;
-        base[s] = (((size_t)b * a.NB + (live[s] ? s0 + s : 0)) * T_) * M + (fin ? myrow : 0);
+        lo[s] = live[s] ? (unsigned)s * (unsigned)T_ * (unsigned)M + (unsigned)myrow : 0u;
         gta[s] = live[s] ? a.g_time_avg[((size_t)b * a.NB + s0 + s) * M + myrow] * inv : (T)0;
         carry[s] = (T)0;
         dsum[s] = (T)0;
         xn[s] = (T)0;
-        xc[s] = live[s] ? a.traj[base[s] + (size_t)(T_ - 1) * M] : (T)0;              // x_T
-        xm[s] = (live[s] && T_ >= 2) ? a.traj[base[s] + (size_t)(T_ - 2) * M] : (T)0;  // x_{T-1}
-        dfc[s] = live[s] ? a.delta[base[s] + (size_t)(T_ - 1) * M] : (T)0;             // f'(u_T)
-        if (live[s]) a.delta[base[s] + (size_t)(T_ - 1) * M] = (T)0;   // slot T-1 of the shifted delta stays zero
+        xc[s] = live[s] ? (trj + (size_t)(T_ - 1) * M)[lo[s]] : (T)0;              // x_T
+        xm[s] = (live[s] && T_ >= 2) ? (trj + (size_t)(T_ - 2) * M)[lo[s]] : (T)0;  // x_{T-1}
+        dfc[s] = live[s] ? (dlt + (size_t)(T_ - 1) * M)[lo[s]] : (T)0;             // f'(u_T)
+        if (live[s]) (dlt + (size_t)(T_ - 1) * M)[lo[s]] = (T)0;   // slot T-1 of the shifted delta stays zero
     }
     for (int c = threadIdx.x; c < 2 * NB * 8 * CP; c += blockDim.x) (&dbuf[0][0][0])[c] = (T)0;
     __syncthreads();
@@ -156,8 +165,11 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
         T xmm[NB], dfn[NB];
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
-            xmm[s] = (live[s] && tau >= 3) ? a.traj[base[s] + (size_t)(tau - 3) * M] : (T)0;
-            dfn[s] = (live[s] && tau >= 2) ? a.delta[base[s] + (size_t)(tau - 2) * M] : (T)0;
+            // opaque per iteration: otherwise trj + lo is hoisted as a loop-invariant 64-bit VGPR pair per stream
+            // (registers this kernel does not have) instead of SGPR base + 32-bit VGPR offset addressing
+            asm volatile("" : "+v"(lo[s]));
+            xmm[s] = (live[s] && tau >= 3) ? (trj + (size_t)(tau - 3) * M)[lo[s]] : (T)0;
+            dfn[s] = (live[s] && tau >= 2) ? (dlt + (size_t)(tau - 2) * M)[lo[s]] : (T)0;
         }
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
@@ -170,16 +182,17 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
             }
             const T at = g + carry[s];
             const T delta = eps * dfc[s] * at;
-            carry[s] = oneme * at;                     // + (W^T delta)[j] below
+            carry[s] = fma(-eps, at, at);              // (1 - eps) a_t, + (W^T delta)[j] below
             dsum[s] += delta;                          // dL/d ext = sum_t delta_t  (u_t = W x_{t-1} + ext)
             if (live[s]) {
                 dbuf[cur][s][myslot] = delta;
-                if (tau >= 2) a.delta[base[s] + (size_t)(tau - 2) * M] = delta;   // shifted: pairs with x_{tau-1}
+                if (tau >= 2) (dlt + (size_t)(tau - 2) * M)[lo[s]] = delta;   // shifted: pairs with x_{tau-1}
             }
         }
         __syncthreads();
         T acc[NB][8];
-        tile_matvec<T, RA, C, NB>(wt, &dbuf[cur][0][0], cg, acc);
+        if constexpr (RL > 0) tile_matvec_split<T, RA, C, RL, NB>(wt, wlds, threadIdx.x, &dbuf[cur][0][0], cg, acc);
+        else tile_matvec<T, RA, C, NB>(wt, &dbuf[cur][0][0], cg, acc);
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
             carry[s] += reduce8_to_lane(acc[s], cg);
@@ -244,17 +257,17 @@ template <typename T> bool gen_supported(int M) { return (M % 2 == 0) && gen_pic
 template bool gen_supported<float>(int);
 template bool gen_supported<double>(int);
 
-template <typename T, int C, int NB, bool FWD, typename Args>
+template <typename T, int C, int RL, int NB, bool FWD, typename Args>
 static hipError_t launch_gen_k(const Args& a, hipStream_t st) {
     constexpr int MAXW = (8 * C + 8 * GEN_RA - 1) / (8 * GEN_RA);
-    constexpr int MINW = (sizeof(T) == 4) ? 2 : 1;
+    constexpr int MINW = (sizeof(T) == 4) ? (RL > 0 ? 3 : 2) : 1;
     const int waves = (a.M + 8 * GEN_RA - 1) / (8 * GEN_RA);
     const int ngroups = (a.NB + NB - 1) / NB;
     if constexpr (FWD)
-        hipLaunchKernelGGL((gen_forward_kernel<T, GEN_RA, C, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
+        hipLaunchKernelGGL((gen_forward_kernel<T, GEN_RA, C, RL, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
                            dim3(64 * waves), 0, st, a);
     else
-        hipLaunchKernelGGL((gen_backward_kernel<T, GEN_RA, C, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
+        hipLaunchKernelGGL((gen_backward_kernel<T, GEN_RA, C, RL, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
                            dim3(64 * waves), 0, st, a);
     return hipGetLastError();
 }
@@ -262,11 +275,14 @@ template <typename T, int C, bool FWD, typename Args>
 static hipError_t launch_gen_nb(const Args& a, hipStream_t st) {
     // stimuli per workgroup chosen so that no instantiation spills (7*C tile + 8*NB accumulators + state)
     if constexpr (sizeof(T) == 4) {
-        if constexpr (C <= 13) { if (a.NB >= 4) return launch_gen_k<T, C, 4, FWD>(a, st); }
+        if constexpr (C <= 13) { if (a.NB >= 4) return launch_gen_k<T, C, 0, 4, FWD>(a, st); }
         // (two stimuli per workgroup at C >= 19 measured no faster at the C3 shape: the loop is VALU-issue bound)
-        if constexpr (C <= 13) { if (a.NB >= 2) return launch_gen_k<T, C, 2, FWD>(a, st); }
+        if constexpr (C <= 13) { if (a.NB >= 2) return launch_gen_k<T, C, 0, 2, FWD>(a, st); }
+        // split VGPR/LDS residency (3 waves/SIMD, three workgroups per CU), as in the solver
+        if constexpr (C == 25) return launch_gen_k<T, C, 2, 1, FWD>(a, st);
+        if constexpr (C == 19) return launch_gen_k<T, C, 1, 1, FWD>(a, st);
     }
-    return launch_gen_k<T, C, 1, FWD>(a, st);
+    return launch_gen_k<T, C, 0, 1, FWD>(a, st);
 }
 template <typename T, bool FWD, typename Args>
 static hipError_t launch_gen_c(const Args& a, hipStream_t st) {

@@ -54,7 +54,7 @@ template <typename T> hipError_t launch_stream(const SolveArgs<T>& a, hipStream_
 
 // ssn_tile.hip
 template <typename T> bool tile_supported(int M, int NB);
-template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st);
+template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st, int shape = 0);   // 0 default, 1 split residency, 2 all-register
 
 // ssn_gen.hip
 template <typename T> bool gen_supported(int M);

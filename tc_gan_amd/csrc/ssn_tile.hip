@@ -35,14 +35,18 @@
 
 namespace ssn {
 
-template <typename T, int RA, int C, int NB, int MAXTHREADS, int MINWAVES>
+template <typename T, int RA, int C, int RL, int NB, int MAXTHREADS, int MINWAVES>
 __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveArgs<T> a) {
     constexpr int CP = SlabPad<C>::value;
+    using Split = TileSplit<RA, C, RL>;       // RL > 0: last RL rows of every lane's tile live in LDS
+    __shared__ __align__(16) T wlds[Split::lds_elems(MAXTHREADS)];
     constexpr int NQ = (C + 3) / 4;              // 16-B reads per lane per stimulus
     static_assert(RA <= 8, "a row group has 8 lanes to finish its rows");
     using V4 = T __attribute__((ext_vector_type(4)));
     __shared__ __align__(16) T rbuf[2][NB][8 * CP];
-    __shared__ int flags[3][2][NB];
+    // per slot and stimulus one 32-bit word: low half = "some row has not converged", high half = "some row hit
+    // the rate bound"; written with 16-bit stores (no race between the two kinds), read and cleared as one word
+    __shared__ int flags[3][NB];
 
     const int M = a.M, N = a.N;
     const int ngroups = (a.NB + NB - 1) / NB;
@@ -53,23 +57,9 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     const int rowbase = (8 * wave + rg) * RA;
     const int colbase = cg * C;
 
-    // ---- prologue: my RA x C tile of W -> registers ---------------------------------
-    T w[RA][C];
-    {
-        const T* Wb = a.W + (size_t)b * M * M;
-#pragma unroll
-        for (int r = 0; r < RA; ++r) {
-            const int row = rowbase + r;
-            const T* wrow = Wb + (size_t)(row < M ? row : M - 1) * M;
-            const T rmask = (row < M) ? (T)1 : (T)0;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int col = colbase + c;
-                const T v = wrow[col < M ? col : M - 1];      // clamped address, masked value
-                w[r][c] = v * ((col < M) ? rmask : (T)0);
-            }
-        }
-    }
+    // ---- prologue: my RA x C tile of W -> registers (and LDS for the last RL rows) -----------------
+    T w[RA - RL][C];
+    tile_load_split<T, RA, C, RL, false>(a.W + (size_t)b * M * M, M, rowbase, colbase, w, wlds, threadIdx.x);
     // the row this lane finishes each step (a = cg), its LDS slot, input and state
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
@@ -85,7 +75,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
         ex[s] = (fin && live[s]) ? a.ext[(a.ext_per_draw ? vec : (size_t)(s0 + s) * M) + myrow] : (T)0;
     }
     for (int c = threadIdx.x; c < 2 * NB * 8 * CP; c += blockDim.x) (&rbuf[0][0][0])[c] = (T)0;
-    if (threadIdx.x < 3 * 2 * NB) (&flags[0][0][0])[threadIdx.x] = 0;
+    if (threadIdx.x < 3 * NB) (&flags[0][0])[threadIdx.x] = 0;
     __syncthreads();
     if (fin) {
 #pragma unroll
@@ -107,10 +97,10 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     int cur = 0;
     int step = 0;
     for (; step < a.st.max_iter; ++step) {
-        int fnc[NB], fhb[NB];
+        int fl[NB];
         if (!(SSN_ABLATE & 4) && step > 0) {
 #pragma unroll
-            for (int s = 0; s < NB; ++s) { fnc[s] = flags[(step + 2) % 3][0][s]; fhb[s] = flags[(step + 2) % 3][1][s]; }
+            for (int s = 0; s < NB; ++s) fl[s] = flags[(step + 2) % 3][s];
         }
         // ---- partial sums over my C columns for my RA rows ---------------------------
         T acc[NB][8];
@@ -118,33 +108,50 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
         for (int s = 0; s < NB; ++s)
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
+        if constexpr (RL > 0) {
+            tile_matvec_split<T, RA, C, RL, NB>(w, wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            V4 rv[NB];
+            for (int q = 0; q < NQ; ++q) {
+                V4 rv[NB];
 #pragma unroll
-            for (int s = 0; s < NB; ++s) {
-                if constexpr (SSN_ABLATE & 8) { rv[s].x = rc[s]; rv[s].y = rc[s] + 1; rv[s].z = rc[s] + 2; rv[s].w = rc[s] + 3; }
-                else rv[s] = *reinterpret_cast<const V4*>(&rbuf[cur][s][cg * CP + 4 * q]);
-            }
+                for (int s = 0; s < NB; ++s) {
+                    if constexpr (SSN_ABLATE & 8) { rv[s].x = rc[s]; rv[s].y = rc[s] + 1; rv[s].z = rc[s] + 2; rv[s].w = rc[s] + 3; }
+                    else rv[s] = *reinterpret_cast<const V4*>(&rbuf[cur][s][cg * CP + 4 * q]);
+                }
 #pragma unroll
-            for (int s = 0; s < NB; ++s) {
-                const T rr[4] = {rv[s].x, rv[s].y, rv[s].z, rv[s].w};
+                for (int s = 0; s < NB; ++s) {
+                    const T rr[4] = {rv[s].x, rv[s].y, rv[s].z, rv[s].w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (4 * q + e < C) {
+                    for (int e = 0; e < 4; ++e) {
+                        if (4 * q + e < C) {
 #pragma unroll
-                        for (int r = 0; r < RA; ++r) acc[s][r] = fma(w[r][4 * q + e], rr[e], acc[s][r]);
+                            for (int r = 0; r < RA; ++r) acc[s][r] = fma(w[r][4 * q + e], rr[e], acc[s][r]);
+                        }
                     }
                 }
             }
         }
         // ---- verdict of the previous iteration (uniform over the workgroup) -----------
         if (!(SSN_ABLATE & 4) && step > 0) {
+            // keep the consumption of the flag loads BELOW the FMA block: without this tie the compiler
+            // hoists the branch to the loop head and waits for the flag read before issuing the r reads
+            // (two exposed LDS latencies per step instead of one)
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                asm volatile("" : "+v"(fl[s]));
+#pragma unroll
+                for (int r = 0; r < RA; ++r) asm volatile("" : "+v"(acc[s][r]));
+            }
             int nfrozen = 0;
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
-                if (!frozen[s] && (!fnc[s] || fhb[s])) {
-                    code[s] = fnc[s] ? 2 : 0;
+                // every lane read the same word: make the verdict (and with it frozen/code/nsteps/cur and the loop
+                // control) scalar
+                const int fu = __builtin_amdgcn_readfirstlane(fl[s]);
+                const bool fnc = fu & 0xffff, fhb = fu >> 16;
+                if (!frozen[s] && (!fnc || fhb)) {
+                    code[s] = fnc ? 2 : 0;
                     nsteps[s] = step;                 // it stopped in iteration step-1
                     frozen[s] = true;
                 }
@@ -162,24 +169,28 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
             const T r1 = rc[s] + (-rc[s] + fu) * eps;
             if (fin && !frozen[s]) {
                 if (!(SSN_ABLATE & 4)) {
-                    if (abs_t(r1 - rc[s]) >= a.st.atol) flags[slot][0][s] = 1;
-                    if (a.st.check_hard && r1 >= a.st.hard_stop) flags[slot][1][s] = 1;
+                    short* fw = reinterpret_cast<short*>(&flags[slot][s]);
+                    if (abs_t(r1 - rc[s]) >= a.st.atol) fw[0] = 1;
+                    if (a.st.check_hard && r1 >= a.st.hard_stop) fw[1] = 1;
                 }
-                rp[s] = rc[s];
+                if constexpr (NB > 1) rp[s] = rc[s];     // NB == 1: x_{k-1} is read back from LDS at the end
                 rc[s] = r1;
             }
             if (fin) rbuf[cur ^ 1][s][myslot] = rc[s];
         }
-        if (!(SSN_ABLATE & 4) && threadIdx.x < 2 * NB) (&flags[(step + 1) % 3][0][0])[threadIdx.x] = 0;
+        if (!(SSN_ABLATE & 4) && threadIdx.x < NB) flags[(step + 1) % 3][threadIdx.x] = 0;
         if constexpr (!(SSN_ABLATE & 16)) __syncthreads();
         cur ^= 1;
     }
+    // NB == 1: nothing runs after the stop, so the buffer that was read in the last update still holds x_{k-1}
+    if constexpr (NB == 1) { if (step > 0 && fin) rp[0] = rbuf[cur ^ 1][0][myslot]; }
     // verdict of the last executed iteration (no extra step was taken, so no roll-back)
     if (!(SSN_ABLATE & 4) && step == a.st.max_iter && step > 0) {
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
             if (!frozen[s]) {
-                const int nc = flags[(step + 2) % 3][0][s], hb = flags[(step + 2) % 3][1][s];
+                const int f = flags[(step + 2) % 3][s];
+                const int nc = f & 0xffff, hb = f >> 16;
                 if (!nc) { code[s] = 0; nsteps[s] = step; }
                 else if (hb) { code[s] = 2; nsteps[s] = step; }
             }
@@ -205,6 +216,12 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
 // dispatch: C = columns per column group (8*C >= M), RA = 7 rows per lane,
 // waves = ceil(M / 56) <= 4.
 // ---------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------
+// dispatch: C = columns per column group (8*C >= M), RA = 7 rows per lane, waves = ceil(M / 56) <= 4.
+// Shapes (fp32): "split" = RL rows of every lane's tile in LDS so that the kernel fits 168 VGPRs and
+// three workgroups share a CU (C = 19: RL = 1, C = 25: RL = 2; C = 26 would need 3 x 55 KB of LDS);
+// "reg" = whole tile in VGPRs (2 waves/SIMD at C >= 19).  fp64: all-register only.
+// ---------------------------------------------------------------------------------
 static constexpr int TILE_RA = 7;
 
 static int tile_pick_c(int M, int elem_bytes) {
@@ -221,45 +238,50 @@ bool tile_supported(int M, int NB) { (void)NB; return (M % 2 == 0) && tile_pick_
 template bool tile_supported<float>(int, int);
 template bool tile_supported<double>(int, int);
 
-template <typename T, int RA, int C, int NB, int MINW>
+template <typename T, int RA, int C, int RL, int NB, int MINW>
 static hipError_t launch_tile_k(const SolveArgs<T>& a, hipStream_t st) {
     constexpr int MAXW = (8 * C + 8 * RA - 1) / (8 * RA);
     const int waves = (a.M + 8 * RA - 1) / (8 * RA);
     const int ngroups = (a.NB + NB - 1) / NB;
-    hipLaunchKernelGGL((solve_tile_kernel<T, RA, C, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
+    hipLaunchKernelGGL((solve_tile_kernel<T, RA, C, RL, NB, 64 * MAXW, MINW>), dim3(a.B * ngroups),
                        dim3(64 * waves), 0, st, a);
     return hipGetLastError();
 }
 
 template <typename T, int C>
-static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st) {
+static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st, bool split) {
     if constexpr (sizeof(T) == 4) {
+        if constexpr (C == 25) { if (split) return launch_tile_k<T, TILE_RA, C, 2, 1, 3>(a, st); }
+        if constexpr (C == 19) { if (split) return launch_tile_k<T, TILE_RA, C, 1, 1, 3>(a, st); }
         // 7*C W registers + 8*NB accumulators + 4*NB states must stay under 256 VGPRs (no spills)
-        if constexpr (C <= 19) { if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 4, 2>(a, st); }
-        if (a.NB >= 2) return launch_tile_k<T, TILE_RA, C, 2, 2>(a, st);
-        return launch_tile_k<T, TILE_RA, C, 1, 2>(a, st);
+        if constexpr (C <= 19) { if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 0, 4, 2>(a, st); }
+        if (a.NB >= 2) return launch_tile_k<T, TILE_RA, C, 0, 2, 2>(a, st);
+        return launch_tile_k<T, TILE_RA, C, 0, 1, 2>(a, st);
     } else {
-        return launch_tile_k<T, TILE_RA, C, 1, 1>(a, st);
+        return launch_tile_k<T, TILE_RA, C, 0, 1, 1>(a, st);
     }
 }
 
-template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st);
-template <> hipError_t launch_tile<float>(const SolveArgs<float>& a, hipStream_t st) {
+// shape: 0 = library default, 1 = split residency where instantiated, 2 = all-register
+template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st, int shape);
+template <> hipError_t launch_tile<float>(const SolveArgs<float>& a, hipStream_t st, int shape) {
+    const bool split = shape != 2;
     switch (tile_pick_c(a.M, 4)) {
-        case 4: return launch_tile_nb<float, 4>(a, st);
-        case 8: return launch_tile_nb<float, 8>(a, st);
-        case 13: return launch_tile_nb<float, 13>(a, st);
-        case 19: return launch_tile_nb<float, 19>(a, st);
-        case 25: return launch_tile_nb<float, 25>(a, st);
-        case 26: return launch_tile_nb<float, 26>(a, st);
+        case 4: return launch_tile_nb<float, 4>(a, st, split);
+        case 8: return launch_tile_nb<float, 8>(a, st, split);
+        case 13: return launch_tile_nb<float, 13>(a, st, split);
+        case 19: return launch_tile_nb<float, 19>(a, st, split);
+        case 25: return launch_tile_nb<float, 25>(a, st, split);
+        case 26: return launch_tile_nb<float, 26>(a, st, split);
         default: return hipErrorInvalidValue;
     }
 }
-template <> hipError_t launch_tile<double>(const SolveArgs<double>& a, hipStream_t st) {
+template <> hipError_t launch_tile<double>(const SolveArgs<double>& a, hipStream_t st, int shape) {
+    (void)shape;
     switch (tile_pick_c(a.M, 8)) {
-        case 4: return launch_tile_nb<double, 4>(a, st);
-        case 8: return launch_tile_nb<double, 8>(a, st);
-        case 13: return launch_tile_nb<double, 13>(a, st);
+        case 4: return launch_tile_nb<double, 4>(a, st, false);
+        case 8: return launch_tile_nb<double, 8>(a, st, false);
+        case 13: return launch_tile_nb<double, 13>(a, st, false);
         default: return hipErrorInvalidValue;
     }
 }

@@ -108,22 +108,165 @@ __device__ __forceinline__ void tile_matvec(const T (&w)[RA][C], const T* xs /* 
     }
 }
 
+// One element of a raw buffer (byte offset = voff + soff); out-of-range offsets return 0 instead of faulting.
+__device__ __forceinline__ float buffer_load_elem(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, float) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+}
+__device__ __forceinline__ double buffer_load_elem(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, double) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
+
 // Load the lane's RA x C tile of a row-major M x M matrix A (TRANSPOSED = false) or of its transpose
 // (TRANSPOSED = true: tile element (row, col) = A[col][row]); entries outside M x M are zero.
-// Unconditional loads from clamped addresses, masked by multiplication (no per-element branches).
+// Buffer loads: one address VGPR per tile row (clamped row), the column as an immediate / scalar offset;
+// out-of-tile columns may read the next row (or past the matrix: the buffer returns 0) and are masked.
+// No per-element 64-bit addresses, no per-element branches.
 template <typename T, int RA, int C, bool TRANSPOSED>
 __device__ __forceinline__ void tile_load(const T* A, int M, int rowbase, int colbase, T (&w)[RA][C]) {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0, M * M * (int)sizeof(T), 0x00020000);
+    const int ncol = M - colbase;                       // columns c < ncol are inside the matrix
 #pragma unroll
     for (int r = 0; r < RA; ++r) {
         const int row = rowbase + r;
         const int rowc = row < M ? row : M - 1;
-        const T rmask = (row < M) ? (T)1 : (T)0;
+        const int voff = (TRANSPOSED ? colbase * M + rowc : rowc * M + colbase) * (int)sizeof(T);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const int col = colbase + c;
-            const int colc = col < M ? col : M - 1;
-            const T v = TRANSPOSED ? A[(size_t)colc * M + rowc] : A[(size_t)rowc * M + colc];
-            w[r][c] = v * ((col < M) ? rmask : (T)0);
+            const T v = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
+            w[r][c] = (row < M && c < ncol) ? v : (T)0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split residency: the first RA-RL rows of a lane's RA x C tile stay in VGPRs, the last RL rows live in
+// LDS.  At 2N = 200 (RA = 7, C = 25) the all-register tile needs 175 + ~70 VGPRs -> 2 waves/SIMD, and a
+// single wave issues only one VALU instruction per ~5 cycles; with RL = 2 the kernel fits 168 VGPRs ->
+// 3 waves/SIMD, three workgroups per CU (3 x 50 KB of LDS), which is what fills the VALU.
+// LDS image per lane: values j = c*RL + rl (column-major over the RL rows), zero-padded to NF4 16-byte
+// units; unit k of lane tid sits at base[(k*WS + tid)*4] (conflict-free, one address VGPR + immediate
+// offsets).  WS = number of lanes whose row group can hold a real row (8*ceil(8C/RA), 232 of 256 at
+// C = 25): the idle lanes of the last wave alias the next unit -- they never write, and what they read
+// only reaches accumulators of row groups that have no rows.
+// ---------------------------------------------------------------------------------------------
+template <int RA, int C, int RL> struct TileSplit {
+    static_assert(RL >= 0 && RL <= 2 && RL < RA, "0, 1 or 2 LDS-resident rows");
+    static constexpr int RR = RA - RL;
+    static constexpr int NL = RL * C;
+    static constexpr int NF4 = (NL + 3) / 4;
+    static constexpr int WS = 8 * ((8 * C + RA - 1) / RA);
+    static constexpr int lds_elems(int wg) { return NF4 > 0 ? ((NF4 - 1) * WS + wg) * 4 : 1; }
+};
+
+template <typename T, int RA, int C, int RL, bool TRANSPOSED>
+__device__ __forceinline__ void tile_load_split(const T* A, int M, int rowbase, int colbase, T (&w)[RA - RL][C],
+                                                T* wl /* LDS, TileSplit::lds_elems(blockDim) */, int tid) {
+    using S = TileSplit<RA, C, RL>;
+    using V4 = T __attribute__((ext_vector_type(4)));
+    // LDS rows first and fenced off from the register rows: loading all RA*C values at once needs more
+    // registers than the split kernels have (the prologue would spill ~20 of them through scratch)
+    if constexpr (RL > 0) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0, M * M * (int)sizeof(T), 0x00020000);
+        const int ncol = M - colbase;
+        int voff[RL];
+#pragma unroll
+        for (int rl = 0; rl < RL; ++rl) {
+            const int row = rowbase + S::RR + rl;
+            const int rowc = row < M ? row : M - 1;
+            voff[rl] = (TRANSPOSED ? colbase * M + rowc : rowc * M + colbase) * (int)sizeof(T);
+        }
+        auto fetch = [&](int j) -> T {
+            const int c = j / RL, rl = j % RL;
+            if (j >= S::NL) return (T)0;
+            const T v = buffer_load_elem(rsrc, voff[rl], (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
+            return (rowbase + S::RR + rl < M && c < ncol) ? v : (T)0;
+        };
+        if (tid < S::WS) {
+#pragma unroll
+            for (int k = 0; k < S::NF4; ++k) {
+                V4 v;
+                v.x = fetch(4 * k); v.y = fetch(4 * k + 1); v.z = fetch(4 * k + 2); v.w = fetch(4 * k + 3);
+                *reinterpret_cast<V4*>(&wl[((size_t)k * S::WS + tid) * 4]) = v;
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    tile_load<T, S::RR, C, TRANSPOSED>(A, M, rowbase, colbase, w);
+}
+
+// acc[s][a] as tile_matvec, rows a < RA-RL from VGPRs and rows a >= RA-RL from the LDS image.  Software
+// pipeline per quad q of columns: issue the r reads of quad q+1 and the W units of quad q, run the
+// register FMAs of quad q (which cover the LDS latency), then the LDS-row FMAs.
+template <typename T, int RA, int C, int RL, int NB>
+__device__ __forceinline__ void tile_matvec_split(const T (&w)[RA - RL][C], const T* wl, int tid,
+                                                  const T* xs /* [NB][8*CP] */, int cg, T (&acc)[NB][8]) {
+    using S = TileSplit<RA, C, RL>;
+    constexpr int CP = SlabPad<C>::value;
+    constexpr int NQ = (C + 3) / 4;
+    constexpr int RR = S::RR;
+    using V4 = T __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int s = 0; s < NB; ++s)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
+    // Stage boundaries are enforced with data dependencies (an empty asm that "redefines" the LDS addresses
+    // and the accumulators): the reads of stage q+1 cannot be hoisted above it, the FMAs of stage q cannot
+    // sink below it.  __builtin_amdgcn_sched_barrier alone is not enough -- instruction selection already
+    // reorders the (side-effect free) FMAs across it and every read ends up at the top (~80 staging VGPRs).
+    // The tied values are 32-bit LDS byte addresses: tying a generic pointer would lose its address space
+    // and turn every ds_read into a flat_load.
+    using LdsV4 = const __attribute__((address_space(3))) V4*;
+    using LdsT = const __attribute__((address_space(3))) T*;
+    unsigned xa = (unsigned)(size_t)(LdsT)(xs + cg * CP);
+    unsigned wa = (unsigned)(size_t)(LdsT)(wl + tid * 4);
+    V4 rv[NQ][NB];
+    V4 wu[S::NF4 > 0 ? S::NF4 : 1];
+    auto load_quad = [&](int q) {
+#pragma unroll
+        for (int s = 0; s < NB; ++s) rv[q][s] = *(LdsV4)(size_t)(xa + (unsigned)sizeof(T) * (s * 8 * CP + 4 * q));
+    };
+    auto load_unit = [&](int k) {
+        if (k < S::NF4) wu[k] = *(LdsV4)(size_t)(wa + (unsigned)sizeof(T) * (k * S::WS * 4));
+    };
+    load_quad(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) load_quad(q + 1);
+#pragma unroll
+        for (int uu = 0; uu < RL; ++uu) load_unit(q * RL + uu);      // values 4*q*RL .. 4*(q+1)*RL - 1
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const T rr[4] = {rv[q][s].x, rv[q][s].y, rv[q][s].z, rv[q][s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * q + e < C) {
+#pragma unroll
+                    for (int r = 0; r < RR; ++r) acc[s][r] = fma(w[r][4 * q + e], rr[e], acc[s][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+            const T rr[4] = {rv[q][s].x, rv[q][s].y, rv[q][s].z, rv[q][s].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * q + e < C) {
+#pragma unroll
+                    for (int rl = 0; rl < RL; ++rl) {
+                        const int j = (4 * q + e) * RL + rl;
+                        acc[s][RR + rl] = fma(wu[j / 4][j % 4], rr[e], acc[s][RR + rl]);
+                    }
+                }
+            }
+        }
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int s = 0; s < NB; ++s)
+#pragma unroll
+                for (int r = 0; r < RA; ++r) asm volatile("" : "+v"(acc[s][r]));
+            asm volatile("" : "+v"(xa), "+v"(wa));
         }
     }
 }

@@ -129,6 +129,9 @@ def test_test_inf_message():
     (50, 1, 2, 'float32'), (50, 8, 2, 'float32'), (100, 1, 2, 'float32'), (100, 8, 2, 'float32'),
     (100, 3, 2, 'float32'), (102, 5, 2, 'float32'), (16, 5, 2, 'float32'), (1, 1, 2, 'float32'),
     (75, 2, 2, 'float32'), (50, 2, 2, 'float64'), (23, 3, 2, 'float64'),
+    # variant 3: tile kernel with 5 rows per lane (5 waves at 2N = 200); variant 4: 7 rows per lane
+    (100, 1, 3, 'float32'), (100, 8, 3, 'float32'), (102, 3, 3, 'float32'), (50, 8, 3, 'float32'),
+    (75, 2, 3, 'float32'), (16, 5, 3, 'float32'), (1, 1, 3, 'float32'), (100, 1, 4, 'float32'), (100, 2, 4, 'float32'),
 ])
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
@@ -146,7 +149,7 @@ def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
 
 
 @pytest.mark.parametrize('dtype,variant', [('float64', 0), ('float64', 1), ('float64', 2), ('float32', 1),
-                                           ('float32', 2), ('float32', 0)])
+                                           ('float32', 2), ('float32', 0), ('float32', 3), ('float32', 4)])
 def test_converging_batch_codes_steps_states(oracle_lib, dtype, variant):
     """Default solver settings (atol 1e-5, dt 8e-4): per-pair convergence step and state."""
     from tc_gan_amd.ssnode import fixed_points_batch
@@ -179,7 +182,8 @@ def test_blowup_codes_match_oracle(oracle_lib):
     exts = np.stack([g['ext_%d' % bad[0]['id']]])
     want, wcodes, wsteps = _oracle_batch(oracle_lib, Ws, exts, 'asym_power', 100000, 1e-5, dt=5e-4, hard=200.)
     assert set(wcodes.flat) >= {2}
-    for dtype, variant in (('float64', 1), ('float64', 0), ('float64', 2), ('float32', 1), ('float32', 2)):
+    for dtype, variant in (('float64', 1), ('float64', 0), ('float64', 2), ('float32', 1), ('float32', 2),
+                           ('float32', 3), ('float32', 4)):
         res = fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=100000, atol=1e-5, dt=5e-4,
                                  io_type='asym_power', rate_stop_at=200., dtype=dtype, variant=variant)
         np.testing.assert_array_equal(res.codes, wcodes)
