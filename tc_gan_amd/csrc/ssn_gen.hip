@@ -52,8 +52,10 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFw
     const int cg = lane & 7, rg = lane >> 3;
     const int rowbase = (8 * wave + rg) * RA;
 
-    T w[RA - RL][C];
-    tile_load_split<T, RA, C, RL, false>(a.W + (size_t)b * M * M, M, rowbase, cg * C, w, wlds, threadIdx.x);
+    T w[RL == 0 ? RA : 1][RL == 0 ? C : 1];     // all-register shape
+    SplitTile<T, RA, C, RL> sw;                 // split shape (RL > 0)
+    if constexpr (RL > 0) sw.template load<false>(a.W + (size_t)b * M * M, M, rowbase, cg * C, wlds, threadIdx.x);
+    else tile_load<T, RA, C, false>(a.W + (size_t)b * M * M, M, rowbase, cg * C, w);
 
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_forward_kernel(GenFw
     int cur = 0;
     for (int it = 0; it < T_; ++it) {
         T acc[NB][8];
-        if constexpr (RL > 0) tile_matvec_split<T, RA, C, RL, NB>(w, wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
+        if constexpr (RL > 0) sw.template matvec<NB>(wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
         else tile_matvec<T, RA, C, NB>(w, &rbuf[cur][0][0], cg, acc);
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
@@ -128,8 +130,10 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
     const int cg = lane & 7, rg = lane >> 3;
     const int rowbase = (8 * wave + rg) * RA;
 
-    T wt[RA - RL][C];   // tile element (row j, col i) = W[i][j]
-    tile_load_split<T, RA, C, RL, true>(a.W + (size_t)b * M * M, M, rowbase, cg * C, wt, wlds, threadIdx.x);
+    T wt[RL == 0 ? RA : 1][RL == 0 ? C : 1];   // tile element (row j, col i) = W[i][j]
+    SplitTile<T, RA, C, RL> sw;
+    if constexpr (RL > 0) sw.template load<true>(a.W + (size_t)b * M * M, M, rowbase, cg * C, wlds, threadIdx.x);
+    else tile_load<T, RA, C, true>(a.W + (size_t)b * M * M, M, rowbase, cg * C, wt);
 
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
@@ -191,7 +195,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
         }
         __syncthreads();
         T acc[NB][8];
-        if constexpr (RL > 0) tile_matvec_split<T, RA, C, RL, NB>(wt, wlds, threadIdx.x, &dbuf[cur][0][0], cg, acc);
+        if constexpr (RL > 0) sw.template matvec<NB>(wlds, threadIdx.x, &dbuf[cur][0][0], cg, acc);
         else tile_matvec<T, RA, C, NB>(wt, &dbuf[cur][0][0], cg, acc);
 #pragma unroll
         for (int s = 0; s < NB; ++s) {

@@ -27,12 +27,6 @@
 #include "ssn_host.h"
 #include "ssn_tile_core.h"
 
-// Diagnostic builds only (tools/microbench/tile_ablate.hip): bit mask of loop phases to stub out
-// so their cost can be measured.  The product library is always built with SSN_ABLATE == 0.
-#ifndef SSN_ABLATE
-#define SSN_ABLATE 0
-#endif
-
 namespace ssn {
 
 template <typename T, int RA, int C, int RL, int NB, int MAXTHREADS, int MINWAVES>
@@ -58,8 +52,11 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     const int colbase = cg * C;
 
     // ---- prologue: my RA x C tile of W -> registers (and LDS for the last RL rows) -----------------
-    T w[RA - RL][C];
-    tile_load_split<T, RA, C, RL, false>(a.W + (size_t)b * M * M, M, rowbase, colbase, w, wlds, threadIdx.x);
+    if constexpr (RL > 0) set_rank_priority((blockIdx.x >> 8) % 3);
+    T w[RL == 0 ? RA : 1][RL == 0 ? C : 1];     // all-register shape
+    SplitTile<T, RA, C, RL> sw;                 // split shape (RL > 0)
+    if constexpr (RL > 0) sw.template load<false>(a.W + (size_t)b * M * M, M, rowbase, colbase, wlds, threadIdx.x);
+    else tile_load<T, RA, C, false>(a.W + (size_t)b * M * M, M, rowbase, colbase, w);
     // the row this lane finishes each step (a = cg), its LDS slot, input and state
     const int myrow = rowbase + cg;
     const bool fin = (cg < RA) && (myrow < M);
@@ -109,7 +106,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
         if constexpr (RL > 0) {
-            tile_matvec_split<T, RA, C, RL, NB>(w, wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
+            sw.template matvec<NB>(wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
@@ -212,10 +209,6 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     }
 }
 
-// ---------------------------------------------------------------------------------
-// dispatch: C = columns per column group (8*C >= M), RA = 7 rows per lane,
-// waves = ceil(M / 56) <= 4.
-// ---------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------
 // dispatch: C = columns per column group (8*C >= M), RA = 7 rows per lane, waves = ceil(M / 56) <= 4.
 // Shapes (fp32): "split" = RL rows of every lane's tile in LDS so that the kernel fits 168 VGPRs and

@@ -4,6 +4,16 @@
 #include <hip/hip_runtime.h>
 #include "ssn_device.h"
 
+// Diagnostic builds only (tools/microbench/tile_ablate.hip): bit mask of loop phases to stub out so that
+// their cost can be measured.  The product library is always built with SSN_ABLATE == 0.
+#ifndef SSN_ABLATE
+#define SSN_ABLATE 0
+#endif
+// diagnostic switch: 0 no wave priorities, 2 static priority per workgroup rank (product setting)
+#ifndef SSN_PRIO_MODE
+#define SSN_PRIO_MODE 2
+#endif
+
 namespace ssn {
 
 // x + (x from the lane selected by a DPP control); folds to v_add_f32_dpp.
@@ -156,119 +166,177 @@ template <int RA, int C, int RL> struct TileSplit {
     static constexpr int NL = RL * C;
     static constexpr int NF4 = (NL + 3) / 4;
     static constexpr int WS = 8 * ((8 * C + RA - 1) / RA);
-    static constexpr int lds_elems(int wg) { return NF4 > 0 ? ((NF4 - 1) * WS + wg) * 4 : 1; }
+    static constexpr int lds_elems(int wg) { return NF4 > 0 ? ((NF4 - 1) * WS + wg) * 4 : 4; }
 };
 
-template <typename T, int RA, int C, int RL, bool TRANSPOSED>
-__device__ __forceinline__ void tile_load_split(const T* A, int M, int rowbase, int colbase, T (&w)[RA - RL][C],
-                                                T* wl /* LDS, TileSplit::lds_elems(blockDim) */, int tid) {
+// The split tile of one lane.  Register rows are stored as PAIRS of rows per column so that one
+// v_pk_fma_f32 (r value broadcast to both halves through op_sel) updates two rows: a lone wave issues a
+// VALU instruction only every ~4 cycles, and the packed form does twice the work per issue slot, so the
+// FMA block keeps the pipe full even while the other waves of the SIMD sit at the barrier.
+// At RA = 7, RL = 2: rows (0,1), (2,3) packed, row 4 plain, LDS rows (5,6) packed -> 4 instead of 7
+// instructions per column.  (fp64 has no packed form; the same code compiles to scalar v_fma_f64.)
+template <typename T, int RA, int C, int RL> struct SplitTile {
     using S = TileSplit<RA, C, RL>;
+    static constexpr int RR = S::RR, NP = RR / 2, ODD = RR % 2;
+    using V2 = T __attribute__((ext_vector_type(2)));
     using V4 = T __attribute__((ext_vector_type(4)));
-    // LDS rows first and fenced off from the register rows: loading all RA*C values at once needs more
-    // registers than the split kernels have (the prologue would spill ~20 of them through scratch)
-    if constexpr (RL > 0) {
+    V2 p[NP > 0 ? NP : 1][C];      // p[k][c] = (W[row 2k][c], W[row 2k+1][c])
+    T o[ODD ? C : 1];              // last register row when RR is odd
+
+    template <bool TRANSPOSED>
+    __device__ __forceinline__ void load(const T* A, int M, int rowbase, int colbase, T* wl, int tid) {
         const __amdgpu_buffer_rsrc_t rsrc =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(A), 0, M * M * (int)sizeof(T), 0x00020000);
-        const int ncol = M - colbase;
-        int voff[RL];
-#pragma unroll
-        for (int rl = 0; rl < RL; ++rl) {
-            const int row = rowbase + S::RR + rl;
+        const int ncol = M - colbase;                       // columns c < ncol are inside the matrix
+        auto row_voff = [&](int row) {
             const int rowc = row < M ? row : M - 1;
-            voff[rl] = (TRANSPOSED ? colbase * M + rowc : rowc * M + colbase) * (int)sizeof(T);
-        }
-        auto fetch = [&](int j) -> T {
-            const int c = j / RL, rl = j % RL;
-            if (j >= S::NL) return (T)0;
-            const T v = buffer_load_elem(rsrc, voff[rl], (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
-            return (rowbase + S::RR + rl < M && c < ncol) ? v : (T)0;
+            return (TRANSPOSED ? colbase * M + rowc : rowc * M + colbase) * (int)sizeof(T);
         };
-        if (tid < S::WS) {
+        auto elem = [&](int voff, int row, int c) -> T {
+            const T v = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
+            return (row < M && c < ncol) ? v : (T)0;
+        };
+        // LDS rows first, fenced off from the register rows (fewer values in flight at once)
+        if (RL > 0 && tid < S::WS) {
+            int voff[RL > 0 ? RL : 1];
+#pragma unroll
+            for (int rl = 0; rl < RL; ++rl) voff[rl] = row_voff(rowbase + RR + rl);
 #pragma unroll
             for (int k = 0; k < S::NF4; ++k) {
-                V4 v;
-                v.x = fetch(4 * k); v.y = fetch(4 * k + 1); v.z = fetch(4 * k + 2); v.w = fetch(4 * k + 3);
-                *reinterpret_cast<V4*>(&wl[((size_t)k * S::WS + tid) * 4]) = v;
+                T v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * k + e, c = j / (RL > 0 ? RL : 1), rl = j % (RL > 0 ? RL : 1);
+                    v[e] = (j < S::NL) ? elem(voff[rl], rowbase + RR + rl, c) : (T)0;
+                }
+                V4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
+                *reinterpret_cast<V4*>(&wl[((size_t)k * S::WS + tid) * 4]) = q;
             }
         }
         asm volatile("" ::: "memory");
-    }
-    tile_load<T, S::RR, C, TRANSPOSED>(A, M, rowbase, colbase, w);
-}
-
-// acc[s][a] as tile_matvec, rows a < RA-RL from VGPRs and rows a >= RA-RL from the LDS image.  Software
-// pipeline per quad q of columns: issue the r reads of quad q+1 and the W units of quad q, run the
-// register FMAs of quad q (which cover the LDS latency), then the LDS-row FMAs.
-template <typename T, int RA, int C, int RL, int NB>
-__device__ __forceinline__ void tile_matvec_split(const T (&w)[RA - RL][C], const T* wl, int tid,
-                                                  const T* xs /* [NB][8*CP] */, int cg, T (&acc)[NB][8]) {
-    using S = TileSplit<RA, C, RL>;
-    constexpr int CP = SlabPad<C>::value;
-    constexpr int NQ = (C + 3) / 4;
-    constexpr int RR = S::RR;
-    using V4 = T __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int s = 0; s < NB; ++s)
+        for (int r = 0; r < RR; ++r) {
+            const int voff = row_voff(rowbase + r);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
-    // Stage boundaries are enforced with data dependencies (an empty asm that "redefines" the LDS addresses
-    // and the accumulators): the reads of stage q+1 cannot be hoisted above it, the FMAs of stage q cannot
-    // sink below it.  __builtin_amdgcn_sched_barrier alone is not enough -- instruction selection already
-    // reorders the (side-effect free) FMAs across it and every read ends up at the top (~80 staging VGPRs).
-    // The tied values are 32-bit LDS byte addresses: tying a generic pointer would lose its address space
-    // and turn every ds_read into a flat_load.
-    using LdsV4 = const __attribute__((address_space(3))) V4*;
-    using LdsT = const __attribute__((address_space(3))) T*;
-    unsigned xa = (unsigned)(size_t)(LdsT)(xs + cg * CP);
-    unsigned wa = (unsigned)(size_t)(LdsT)(wl + tid * 4);
-    V4 rv[NQ][NB];
-    V4 wu[S::NF4 > 0 ? S::NF4 : 1];
-    auto load_quad = [&](int q) {
-#pragma unroll
-        for (int s = 0; s < NB; ++s) rv[q][s] = *(LdsV4)(size_t)(xa + (unsigned)sizeof(T) * (s * 8 * CP + 4 * q));
-    };
-    auto load_unit = [&](int k) {
-        if (k < S::NF4) wu[k] = *(LdsV4)(size_t)(wa + (unsigned)sizeof(T) * (k * S::WS * 4));
-    };
-    load_quad(0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (q + 1 < NQ) load_quad(q + 1);
-#pragma unroll
-        for (int uu = 0; uu < RL; ++uu) load_unit(q * RL + uu);      // values 4*q*RL .. 4*(q+1)*RL - 1
-#pragma unroll
-        for (int s = 0; s < NB; ++s) {
-            const T rr[4] = {rv[q][s].x, rv[q][s].y, rv[q][s].z, rv[q][s].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (4 * q + e < C) {
-#pragma unroll
-                    for (int r = 0; r < RR; ++r) acc[s][r] = fma(w[r][4 * q + e], rr[e], acc[s][r]);
-                }
+            for (int c = 0; c < C; ++c) {
+                const T v = elem(voff, rowbase + r, c);
+                if (ODD && r == RR - 1) o[c] = v;
+                else if (r & 1) p[r / 2][c].y = v;
+                else p[r / 2][c].x = v;
             }
         }
+    }
+
+    // acc[s][a] = sum_c W[a][c] * x_s[col(cg, c)], rows a < RR from VGPRs, rows a >= RR from the LDS image.
+    // Software pipeline per quad q of columns: issue the x reads of quad q+1 and the W units of quad q, run the
+    // register FMAs of quad q (which cover the LDS latency), then the LDS-row FMAs.
+    template <int NB>
+    __device__ __forceinline__ void matvec(const T* wl, int tid, const T* xs /* [NB][8*CP] */, int cg,
+                                           T (&acc)[NB][8]) const {
+        constexpr int CP = SlabPad<C>::value;
+        constexpr int NQ = (C + 3) / 4;
+        // Stage boundaries are enforced with data dependencies (an empty asm that "redefines" the LDS
+        // addresses and the accumulators): the reads of stage q+1 cannot be hoisted above it, the FMAs of
+        // stage q cannot sink below it.  __builtin_amdgcn_sched_barrier alone is not enough -- instruction
+        // selection already reorders the (side-effect free) FMAs across it and every read ends up at the top
+        // (~80 staging VGPRs).  The tied values are 32-bit LDS byte addresses: tying a generic pointer would
+        // lose its address space and turn every ds_read into a flat_load.
+        using LdsV4 = const __attribute__((address_space(3))) V4*;
+        using LdsT = const __attribute__((address_space(3))) T*;
+        unsigned xa = (unsigned)(size_t)(LdsT)(xs + cg * CP);
+        unsigned wa = (unsigned)(size_t)(LdsT)(wl + tid * 4);
+        V2 a2[NB][NP > 0 ? NP : 1], al2[NB];
+        T ao[NB], al1[NB];
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
-            const T rr[4] = {rv[q][s].x, rv[q][s].y, rv[q][s].z, rv[q][s].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (4 * q + e < C) {
+            for (int k = 0; k < NP; ++k) a2[s][k] = (V2){(T)0, (T)0};
+            al2[s] = (V2){(T)0, (T)0};
+            ao[s] = al1[s] = (T)0;
+        }
+        V4 rv[NQ][NB];
+        V4 wu[S::NF4 > 0 ? S::NF4 : 1];
+        const V4 stub = {(T)cg, (T)(cg + 1), (T)(cg + 2), (T)(cg + 3)};     // diagnostic builds (SSN_ABLATE) only
+        auto load_quad = [&](int q) {
 #pragma unroll
-                    for (int rl = 0; rl < RL; ++rl) {
-                        const int j = (4 * q + e) * RL + rl;
-                        acc[s][RR + rl] = fma(wu[j / 4][j % 4], rr[e], acc[s][RR + rl]);
+            for (int s = 0; s < NB; ++s) {
+                if constexpr (SSN_ABLATE & 8) rv[q][s] = stub;
+                else rv[q][s] = *(LdsV4)(size_t)(xa + (unsigned)sizeof(T) * (s * 8 * CP + 4 * q));
+            }
+        };
+        load_quad(0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (q + 1 < NQ) load_quad(q + 1);
+#pragma unroll
+            for (int uu = 0; uu < RL; ++uu) {                         // values 4*q*RL .. 4*(q+1)*RL - 1
+                const int k = q * RL + uu;
+                if (k < S::NF4) {
+                    if constexpr (SSN_ABLATE & 32) wu[k] = stub;
+                    else wu[k] = *(LdsV4)(size_t)(wa + (unsigned)sizeof(T) * (k * S::WS * 4));
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                const T rr[4] = {rv[q][s].x, rv[q][s].y, rv[q][s].z, rv[q][s].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * q + e;
+                    if (c < C) {
+                        const V2 x2 = {rr[e], rr[e]};
+#pragma unroll
+                        for (int k = 0; k < NP; ++k) a2[s][k] = __builtin_elementwise_fma(p[k][c], x2, a2[s][k]);
+                        if (ODD) ao[s] = fma(o[c], rr[e], ao[s]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * q + e;
+                    if (c < C) {
+                        if constexpr (RL == 2) {
+                            const int j = c * 2;
+                            const V2 wp = {wu[j / 4][j % 4], wu[j / 4][j % 4 + 1]};
+                            al2[s] = __builtin_elementwise_fma(wp, (V2){rr[e], rr[e]}, al2[s]);
+                        } else if constexpr (RL == 1) {
+                            al1[s] = fma(wu[c / 4][c % 4], rr[e], al1[s]);
+                        }
                     }
                 }
             }
+            if (q + 1 < NQ) {
+#pragma unroll
+                for (int s = 0; s < NB; ++s) {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) asm volatile("" : "+v"(a2[s][k]));
+                    if (ODD) asm volatile("" : "+v"(ao[s]));
+                    if (RL == 2) asm volatile("" : "+v"(al2[s]));
+                    if (RL == 1) asm volatile("" : "+v"(al1[s]));
+                }
+                asm volatile("" : "+v"(xa), "+v"(wa));
+            }
         }
-        if (q + 1 < NQ) {
 #pragma unroll
-            for (int s = 0; s < NB; ++s)
+        for (int s = 0; s < NB; ++s) {
 #pragma unroll
-                for (int r = 0; r < RA; ++r) asm volatile("" : "+v"(acc[s][r]));
-            asm volatile("" : "+v"(xa), "+v"(wa));
+            for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { acc[s][2 * k] = a2[s][k].x; acc[s][2 * k + 1] = a2[s][k].y; }
+            if (ODD) acc[s][RR - 1] = ao[s];
+            if (RL == 2) { acc[s][RR] = al2[s].x; acc[s][RR + 1] = al2[s].y; }
+            if (RL == 1) acc[s][RR] = al1[s];
         }
     }
-}
+};
+
+
+// Static wave priority by the workgroup's (guessed) rank among the three workgroups sharing its CU, so that the
+// arbiter prefers one workgroup's waves on all four SIMDs instead of round-robining (which keeps the co-resident
+// workgroups in phase: all in their FMA block, then all in their serial part).  Worth ~2 % at the C2 shape.
+__device__ __forceinline__ void set_rank_priority(int rank) {
+    if (SSN_PRIO_MODE != 2) return;
+    if (rank == 0) __builtin_amdgcn_s_setprio(3);
+    else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(1);
+}   // all-register kernels use tile_load / tile_matvec
 
 }  // namespace ssn

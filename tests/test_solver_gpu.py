@@ -129,9 +129,10 @@ def test_test_inf_message():
     (50, 1, 2, 'float32'), (50, 8, 2, 'float32'), (100, 1, 2, 'float32'), (100, 8, 2, 'float32'),
     (100, 3, 2, 'float32'), (102, 5, 2, 'float32'), (16, 5, 2, 'float32'), (1, 1, 2, 'float32'),
     (75, 2, 2, 'float32'), (50, 2, 2, 'float64'), (23, 3, 2, 'float64'),
-    # variant 3: tile kernel with 5 rows per lane (5 waves at 2N = 200); variant 4: 7 rows per lane
+    # variant 3: tile kernel with split VGPR/LDS residency (2N = 200, 152); 4: whole tile in VGPRs
     (100, 1, 3, 'float32'), (100, 8, 3, 'float32'), (102, 3, 3, 'float32'), (50, 8, 3, 'float32'),
     (75, 2, 3, 'float32'), (16, 5, 3, 'float32'), (1, 1, 3, 'float32'), (100, 1, 4, 'float32'), (100, 2, 4, 'float32'),
+    (76, 1, 3, 'float32'), (76, 3, 4, 'float32'), (90, 3, 3, 'float32'),
 ])
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
