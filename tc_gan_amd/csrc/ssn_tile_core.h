@@ -141,11 +141,25 @@ __device__ __forceinline__ void tile_load(const T* A, int M, int rowbase, int co
         const int row = rowbase + r;
         const int rowc = row < M ? row : M - 1;
         const int voff = (TRANSPOSED ? colbase * M + rowc : rowc * M + colbase) * (int)sizeof(T);
+        if constexpr (!TRANSPOSED && sizeof(T) == 4) {
+            // the row is contiguous in memory: 16-byte loads (a row group's 8 lanes read one matrix row back to back)
+            // (bit_cast of the WHOLE vector: extracting the integer elements first is folded to a splat of one dword
+            // load by this compiler)
+            using V4 = float __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const T v = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
-            w[r][c] = (row < M && c < ncol) ? v : (T)0;
+            for (int c4 = 0; c4 + 4 <= C; c4 += 4) {
+                const V4 v = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, c4 * 4, 0));
+                w[r][c4] = v.x; w[r][c4 + 1] = v.y; w[r][c4 + 2] = v.z; w[r][c4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = C & ~3; c < C; ++c) w[r][c] = buffer_load_elem(rsrc, voff, c * 4, (T)0);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                w[r][c] = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
         }
+#pragma unroll
+        for (int c = 0; c < C; ++c) w[r][c] = (row < M && c < ncol) ? w[r][c] : (T)0;
     }
 }
 
@@ -192,22 +206,40 @@ template <typename T, int RA, int C, int RL> struct SplitTile {
             const int rowc = row < M ? row : M - 1;
             return (TRANSPOSED ? colbase * M + rowc : rowc * M + colbase) * (int)sizeof(T);
         };
-        auto elem = [&](int voff, int row, int c) -> T {
-            const T v = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
-            return (row < M && c < ncol) ? v : (T)0;
+        // one tile row -> t[0..C): 16-byte buffer loads where the row is contiguous in memory (a row group's 8
+        // lanes then read one whole matrix row back to back), single elements for the transposed tile / fp64
+        auto fetch_row = [&](int row, T (&t)[C]) {
+            const int voff = row_voff(row);
+            if constexpr (!TRANSPOSED && sizeof(T) == 4) {
+                // (bit_cast of the WHOLE vector: extracting the integer elements first is folded to a splat of one
+                // dword load by this compiler)
+#pragma unroll
+                for (int c4 = 0; c4 + 4 <= C; c4 += 4) {
+                    const V4 v = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, c4 * 4, 0));
+                    t[c4] = v.x; t[c4 + 1] = v.y; t[c4 + 2] = v.z; t[c4 + 3] = v.w;
+                }
+#pragma unroll
+                for (int c = C & ~3; c < C; ++c) t[c] = buffer_load_elem(rsrc, voff, c * 4, (T)0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    t[c] = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c] = (row < M && c < ncol) ? t[c] : (T)0;
         };
         // LDS rows first, fenced off from the register rows (fewer values in flight at once)
         if (RL > 0 && tid < S::WS) {
-            int voff[RL > 0 ? RL : 1];
+            T t[RL > 0 ? RL : 1][C];
 #pragma unroll
-            for (int rl = 0; rl < RL; ++rl) voff[rl] = row_voff(rowbase + RR + rl);
+            for (int rl = 0; rl < RL; ++rl) fetch_row(rowbase + RR + rl, t[rl]);
 #pragma unroll
             for (int k = 0; k < S::NF4; ++k) {
                 T v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int j = 4 * k + e, c = j / (RL > 0 ? RL : 1), rl = j % (RL > 0 ? RL : 1);
-                    v[e] = (j < S::NL) ? elem(voff[rl], rowbase + RR + rl, c) : (T)0;
+                    v[e] = (j < S::NL) ? t[rl][c] : (T)0;
                 }
                 V4 q; q.x = v[0]; q.y = v[1]; q.z = v[2]; q.w = v[3];
                 *reinterpret_cast<V4*>(&wl[((size_t)k * S::WS + tid) * 4]) = q;
@@ -216,13 +248,13 @@ template <typename T, int RA, int C, int RL> struct SplitTile {
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
-            const int voff = row_voff(rowbase + r);
+            T t[C];
+            fetch_row(rowbase + r, t);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const T v = elem(voff, rowbase + r, c);
-                if (ODD && r == RR - 1) o[c] = v;
-                else if (r & 1) p[r / 2][c].y = v;
-                else p[r / 2][c].x = v;
+                if (ODD && r == RR - 1) o[c] = t[c];
+                else if (r & 1) p[r / 2][c].y = t[c];
+                else p[r / 2][c].x = t[c];
             }
         }
     }
