@@ -290,6 +290,15 @@ int ssn_ff_backward_f32(const float *RF_w, const float *FF_con, const float *FF_
                         const float *q, const float *den, const float *gq, float *dsig,
                         const ssn_ff_params *p, void *stream);
 
+/* ---- 6. Moment matching (tc_gan/networks/moment_matching.py:91-104, 221-243; run/bptt_moments.py) ------------
+ * x[B][D] generated tuning curves (device fp32).  sums[2][D] (device fp64) = (sum_b x, sum_b x^2): all-reduce it
+ * over ranks when the minibatch is sharded, then pass the GLOBAL batch size.  data_moments, weights: [2][D] device
+ * fp64 (BPTTMomentMatcher.set_dataset).  gx[B][D] = d L0 / d x with L0 = mean(weights * (data_moments - (m, s))^2);
+ * out[1 + 2 D] (device fp64) = L0, m[D], s[D]  (sample mean / population variance of the minibatch). */
+int ssn_moment_sums_f32(const float *x, int B, int D, double *sums, void *stream);
+int ssn_moment_loss_grad_f32(const float *x, const double *sums, double global_batch, const double *data_moments,
+                             const double *weights, int B, int D, float *gx, double *out, void *stream);
+
 /* Heterogeneous-input variant (networks/ssn.py:645-772): ext *= amp[b][m], amp = 1 + v_pop * z_in,
  * device [B][2N] (NULL = homogeneous). */
 int ssn_stimulus_amp_f32(const float *bandwidths, const float *contrasts, float smoothness, const float *amp,

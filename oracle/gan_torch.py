@@ -207,3 +207,42 @@ def rmsprop_step(p, g, state, lr, rho=0.9, eps=1e-6):
 
 def sgd_step(p, g, state, lr):
     return p - lr * g
+
+
+# ------------------------------------------------------------------ moment matching
+def sample_moments(samples):
+    """moment_matching.py:91-104: (sample_size, channels) -> (2, channels): mean and POPULATION variance."""
+    return torch.stack([samples.mean(dim=0), samples.var(dim=0, unbiased=False)])
+
+
+def moment_weights(data, moment_weight_type='mean', regularization=1e-3, lam=1.0):
+    """`BPTTMomentMatcher.set_dataset` (moment_matching.py:348-367) -> (data_moments, weights), numpy fp64."""
+    data = np.asarray(data, dtype='float64')
+    dm = np.asarray([data.mean(axis=0), data.var(axis=0)])
+    num = np.broadcast_to([[1.0], [lam]], dm.shape)
+    if moment_weight_type == 'mean':
+        den = data.mean()
+        w = num / np.array([[den ** 2], [den ** 4]])
+    elif moment_weight_type == 'ew_mean':
+        den = dm[0] + regularization
+        w = num / np.array([den ** 2, den ** 4])
+    elif moment_weight_type == 'ew_relative':
+        w = num / (dm + regularization) ** 2
+    else:
+        raise ValueError(moment_weight_type)
+    return dm, np.array(w)
+
+
+def moment_matching_loss(J, D, S, z, bandwidths, contrasts, probes, data_moments, weights, num_sites, smoothness,
+                         io_type, k, n, tau_E, tau_I, dt, seqlen, skip_steps, rate_penalty_threshold,
+                         dynamics_cost, rate_cost):
+    """`MMGeneratorTrainer.post_init` (moment_matching.py:232-243): mean(w * (data_moments - gen_moments)^2)
+    + dynamics_cost * dynamics_penalty + rate_cost * rate_penalty, with the fixed prober of ssn.py:838-851
+    (tuning_curve = time_avg[:, :, probes] flattened over (stimulus, probe))."""
+    ext = stimulus(bandwidths, contrasts, smoothness, num_sites)
+    W = make_W(z, J, D, S, num_sites)
+    ta, dyn, rate = euler_ssn(W, ext, io_type, k, n, tau_E, tau_I, dt, seqlen, skip_steps, rate_penalty_threshold)
+    tc = ta[:, :, torch.as_tensor(np.asarray(probes), dtype=torch.long)].reshape(ta.shape[0], -1)
+    gm = sample_moments(tc)
+    loss = (t64(weights) * (t64(data_moments) - gm) ** 2).mean() + dynamics_cost * dyn + rate_cost * rate
+    return loss, dict(tuning_curve=tc, gen_moments=gm, dynamics_penalty=dyn, rate_penalty=rate)

@@ -192,6 +192,11 @@ libssnode.ssn_ff_forward_f32.argtypes = [c_void_p] * 8 + [POINTER(FFParams), c_v
 libssnode.ssn_ff_forward_f32.restype = c_int
 libssnode.ssn_ff_backward_f32.argtypes = [c_void_p] * 8 + [POINTER(FFParams), c_void_p]
 libssnode.ssn_ff_backward_f32.restype = c_int
+libssnode.ssn_moment_sums_f32.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+libssnode.ssn_moment_sums_f32.restype = c_int
+libssnode.ssn_moment_loss_grad_f32.argtypes = [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int, c_int,
+                                               c_void_p, c_void_p, c_void_p]
+libssnode.ssn_moment_loss_grad_f32.restype = c_int
 
 #: every symbol include/ssnode_mi355x.h declares (checked by tests/test_abi.py)
 DECLARED_SYMBOLS = (
@@ -206,7 +211,7 @@ DECLARED_SYMBOLS = (
     'ssn_gen_backward_f32', 'ssn_gen_backward_f64', 'ssn_jds_grad_f32', 'ssn_jds_grad_f64',
     'ssn_critic_num_params', 'ssn_critic_workspace_floats', 'ssn_critic_forward', 'ssn_critic_loss_grad',
     'ssn_critic_input_grad', 'ssn_optimizer_step',
-    'ssn_ff_forward_f32', 'ssn_ff_backward_f32',
+    'ssn_ff_forward_f32', 'ssn_ff_backward_f32', 'ssn_moment_sums_f32', 'ssn_moment_loss_grad_f32',
     'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
     'ssn_critic_norm_workspace_floats', 'ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm',
     'ssn_critic_input_grad_norm',

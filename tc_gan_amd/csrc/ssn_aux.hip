@@ -140,4 +140,64 @@ hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st) {
 template hipError_t launch_dot<float>(const float*, const float*, float*, int, hipStream_t);
 template hipError_t launch_dot<double>(const double*, const double*, double*, int, hipStream_t);
 
+
+// ---------------------------------------------------------------------------------
+// Moment matching (networks/moment_matching.py:91-243): per tuning-curve channel d the sample mean and
+// (population) variance over the minibatch, the weighted squared distance to the data moments, and its
+// gradient w.r.t. every generated tuning curve.  x[B][D] row-major.  Sums in fp64.
+// sums[2][D] = (sum_b x, sum_b x^2): produced per rank, all-reduced by the caller when the minibatch is
+// sharded over GPUs, then consumed with the GLOBAL batch size.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) moment_sums_kernel(const float* __restrict__ x, int B, int D, double* __restrict__ sums) {
+    const int d = blockIdx.x;
+    double s1 = 0, s2 = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double v = (double)x[(size_t)b * D + d];
+        s1 += v; s2 += v * v;
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[d] = red[0][0]; sums[D + d] = red[1][0]; }
+}
+
+// loss L0 = mean over the (2, D) array of w * (data - gen)^2 ;  gen = (m, s), m = S1/Bg, s = S2/Bg - m^2
+// dL0/dx[b][d] = (1 / (2 D)) * ( 2 w0 (m - mu) / Bg + 2 w1 (s - sigma) * 2 (x - m) / Bg )
+// out[0] = L0, out[1 + d] = m_d, out[1 + D + d] = s_d   (fp64)
+__global__ void __launch_bounds__(256) moment_loss_grad_kernel(const float* __restrict__ x, const double* __restrict__ sums,
+                                                               double Bg, const double* __restrict__ data_moments,
+                                                               const double* __restrict__ weights, int B, int D,
+                                                               float* __restrict__ gx, double* __restrict__ out) {
+    const int d = blockIdx.x;
+    const double m = sums[d] / Bg, s = sums[D + d] / Bg - m * m;
+    const double em = m - data_moments[d], es = s - data_moments[D + d];
+    const double w0 = weights[d], w1 = weights[D + d];
+    const double c0 = w0 * em / (Bg * D), c1 = 2.0 * w1 * es / (Bg * D);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double xv = (double)x[(size_t)b * D + d];
+        gx[(size_t)b * D + d] = (float)(c0 + c1 * (xv - m));
+    }
+    if (threadIdx.x == 0) {
+        out[1 + d] = m; out[1 + D + d] = s;
+        atomicAdd(&out[0], (w0 * em * em + w1 * es * es) / (2.0 * D));
+    }
+}
+
+hipError_t launch_moment_sums(const float* x, int B, int D, double* sums, hipStream_t st) {
+    if (D == 0) return hipSuccess;
+    hipLaunchKernelGGL(moment_sums_kernel, dim3(D), dim3(256), 0, st, x, B, D, sums);
+    return hipGetLastError();
+}
+hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg, const double* data_moments,
+                                   const double* weights, int B, int D, float* gx, double* out, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    if (e != hipSuccess || D == 0) return e;
+    hipLaunchKernelGGL(moment_loss_grad_kernel, dim3(D), dim3(256), 0, st, x, sums, Bg, data_moments, weights, B, D, gx, out);
+    return hipGetLastError();
+}
+
 }  // namespace ssn

@@ -319,6 +319,24 @@ int ssn_ff_backward_f32(const float* RF_w, const float* FF_con, const float* FF_
     return 0;
 }
 
+int ssn_moment_sums_f32(const float* x, int B, int D, double* sums, void* stream) {
+    if (B < 0 || D < 0 || (D > 0 && (!x || !sums))) {
+        g_last_error = "ssn_moment_sums: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_moment_sums(x, B, D, sums, (hipStream_t)stream));
+    return 0;
+}
+int ssn_moment_loss_grad_f32(const float* x, const double* sums, double global_batch, const double* data_moments,
+                             const double* weights, int B, int D, float* gx, double* out, void* stream) {
+    if (B < 0 || D < 0 || !(global_batch > 0) || !out || (D > 0 && (!x || !sums || !data_moments || !weights || !gx))) {
+        g_last_error = "ssn_moment_loss_grad: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_moment_loss_grad(x, sums, global_batch, data_moments, weights, B, D, gx, out, (hipStream_t)stream));
+    return 0;
+}
+
 int ssn_gen_supported(int M, int dtype_bytes) {
     if (M <= 0 || (M & 1)) return 0;
     return dtype_bytes == 8 ? ssn::gen_supported<double>(M) : ssn::gen_supported<float>(M);

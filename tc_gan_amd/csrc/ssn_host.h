@@ -110,6 +110,9 @@ hipError_t launch_ff_forward(const FFArgs& a, const FFLattice* lat, hipStream_t 
 hipError_t launch_ff_backward(const FFArgs& a, const float* gq, float* dsig, hipStream_t st);
 
 // ssn_aux.hip
+hipError_t launch_moment_sums(const float* x, int B, int D, double* sums, hipStream_t st);
+hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg, const double* data_moments,
+                                   const double* weights, int B, int D, float* gx, double* out, hipStream_t st);
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st);
 template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st);

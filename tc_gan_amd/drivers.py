@@ -8,7 +8,7 @@ import numpy as np
 
 from . import execution, param_file, ssnode
 from .recorders import (ConditionalTuningCurveStatsRecorder, DiscLearningRecorder, DiscParamStatsRecorder,
-                        FlexGenParamRecorder, LearningRecorder, _host)
+                        FlexGenParamRecorder, GenMomentsRecorder, LearningRecorder, MMLearningRecorder, _host)
 from .utils import Namespace
 
 logger = getLogger(__name__)
@@ -208,3 +208,49 @@ class BPTTcWGANDriver(BPTTWGANDriver):
     def pre_loop(self):
         super(BPTTcWGANDriver, self).pre_loop()
         self.tuning_curve_recorder = ConditionalTuningCurveStatsRecorder.from_driver(self)
+
+
+class MomentMatchingDriver(object):
+    """drivers.py:354-421."""
+
+    def __init__(self, mmatcher, datastore, iterations, quiet, gen_moments_record_interval, quit_JDS_threshold=-1):
+        self.mmatcher = mmatcher
+        self.datastore = datastore
+        self.iterations = iterations
+        self.quiet = quiet
+        self.gen_moments_record_interval = gen_moments_record_interval
+        self.quit_JDS_threshold = quit_JDS_threshold
+
+    gan = property(lambda self: self.mmatcher)        # for FlexGenParamRecorder
+
+    def pre_loop(self):
+        self.learning_recorder = MMLearningRecorder.from_driver(self)
+        self.gen_moments_recorder = GenMomentsRecorder.from_driver(self)
+        self.generator_recorder = FlexGenParamRecorder.from_driver(self)
+
+    def post_update(self, gen_step, update_result):
+        self.learning_recorder.record(gen_step, update_result)
+        if is_at_interval(gen_step, self.gen_moments_record_interval):
+            self.gen_moments_recorder.record(gen_step, update_result)
+        jj, dd, ss = self.generator_recorder.record(gen_step)
+        self.datastore.flush_all()
+        maybe_quit(self.datastore, JDS_fake=list(map(np.exp, [jj, dd, ss])),
+                   JDS_true=list(map(ssnode.DEFAULT_PARAMS.get, 'JDS')),
+                   quit_JDS_threshold=self.quit_JDS_threshold)
+
+    def iterate(self, update_func):
+        self.pre_loop()
+        logger.info('%s: start iterations', self.__class__.__name__)
+        with recording_exit_reason(self.datastore):
+            for gen_step in range(self.iterations):
+                self.post_update(gen_step, update_func(gen_step))
+        logger.info('%s: maximum iterations reached', self.__class__.__name__)
+
+    def run(self, learner):
+        learning_it = learner.learning()
+
+        def update_func(k):
+            info = next(learning_it)
+            assert info.step == k
+            return info
+        self.iterate(update_func)

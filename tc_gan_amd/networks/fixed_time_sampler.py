@@ -86,8 +86,10 @@ class FixedTimeTuningCurveSampler(object):
             cfg.pop(key, None)
         cfg.update(override)
         bandwidths, contrasts = learner.bandwidths, learner.contrasts
-        probes = probes_from_stim_space(learner.norm_probes if hasattr(learner, 'norm_probes') else learner.sample_sites,
-                                        learner.num_sites, learner.include_inhibitory_neurons)
+        if learner.gen.probes is not None:         # fixed prober (WGAN, moment matcher): reuse its probes
+            probes = learner.gen.probes
+        else:                                      # conditional prober (cWGAN)
+            probes = probes_from_stim_space(learner.norm_probes, learner.num_sites, learner.include_inhibitory_neurons)
         gen = TuningCurveGenerator(num_tcdom=len(bandwidths) * len(contrasts), probes=probes, batchsize=batchsize,
                                    include_rate_penalty=False, **cfg)
         return cls(gen, bandwidths, contrasts, seed)

@@ -62,6 +62,43 @@ class LearningRecorder(HDF5Recorder):
         return cls.make(driver.datastore, quiet=driver.quiet)
 
 
+class MMLearningRecorder(HDF5Recorder):
+    """recorders.py:150-172."""
+
+    tablename = 'learning'
+    dtype = np.dtype([('step', 'uint32'), ('loss', 'double'), ('rate_penalty', 'double'),
+                      ('dynamics_penalty', 'double'), ('train_time', 'double')])
+
+    def record(self, gen_step, update_result):
+        self._saverow([gen_step, update_result.loss, update_result.rate_penalty, update_result.dynamics_penalty,
+                       update_result.train_time])
+
+    @classmethod
+    def from_driver(cls, driver):
+        return cls.make(driver.datastore, quiet=driver.quiet)
+
+
+class GenMomentsRecorder(HDF5Recorder):
+    """recorders.py:175-199: minibatch mean and variance of every moment condition."""
+
+    tablename = 'gen_moments'
+    dedicated = True
+
+    def __init__(self, datastore, num_mom_conds):
+        super(GenMomentsRecorder, self).__init__(datastore)
+        self.num_mom_conds = num_mom_conds
+        self.dtype = np.dtype([('step', 'uint32')] +
+                              [('mean_{}'.format(i), 'double') for i in range(num_mom_conds)] +
+                              [('var_{}'.format(i), 'double') for i in range(num_mom_conds)])
+
+    def record(self, gen_step, update_result):
+        self._saverow([gen_step] + list(np.asarray(update_result.gen_moments).flat))
+
+    @classmethod
+    def from_driver(cls, driver):
+        return cls.make(driver.datastore, driver.mmatcher.num_mom_conds)
+
+
 class DiscLearningRecorder(HDF5Recorder):
     """recorders.py:202-214."""
 

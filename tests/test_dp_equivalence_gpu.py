@@ -45,14 +45,31 @@ def _train(n_gen_steps=2):
     return np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses)
 
 
-def _worker(rank, world, port, out):
+def _train_moments(n_steps=3):
+    """Moment matching: the loss depends on the moments of the GLOBAL minibatch (one all-reduce of the per-channel
+    sums before the loss, one of the parameter gradients after the adjoint sweep)."""
+    from tc_gan_amd.networks.moment_matching import make_moment_matcher
+    cfg = _config()
+    mm, _ = make_moment_matcher(dict(
+        num_sites=10, seqlen=40, skip_steps=30, batchsize=6, sample_sites=[0, 0.5], include_inhibitory_neurons=True,
+        bandwidths=[0.0625, 0.25, 0.75], contrasts=[5., 20.], J0=cfg['J0'], D0=cfg['D0'], S0=cfg['S0'], lam=0.1,
+        moment_weights_regularization=1e-3, moment_weight_type='ew_mean', learning_rate=0.01,
+        update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01, rate_penalty_threshold=5.0))
+    mm.set_dataset(np.random.RandomState(5).rand(9, mm.num_mom_conds) * 8)
+    it = mm.learning()
+    infos = [next(it) for _ in range(n_steps)]
+    return (np.concatenate([np.ravel(p) for p in mm.get_gen_param()]),
+            np.concatenate([np.ravel(i.gen_moments) for i in infos]), np.array([i.loss for i in infos]))
+
+
+def _worker(rank, world, port, out, what='gan'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _train()
+    res = _train() if what == 'gan' else _train_moments()
     out.put((rank,) + res)
     dist.barrier()
     dist.destroy_process_group()
@@ -76,4 +93,24 @@ def test_two_ranks_follow_the_single_process_run():
         np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
     np.testing.assert_array_equal(res[0][2], res[1][2])          # replicas stay bit-identical
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_two_ranks_moment_matching_follows_the_single_process_run():
+    sys.path.insert(0, ROOT)
+    jds1, moments1, losses1 = _train_moments()
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 28700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, 'moments')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(res[r][3], losses1, rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(res[r][2], moments1, rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
     np.testing.assert_array_equal(res[0][1], res[1][1])

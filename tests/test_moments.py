@@ -1,0 +1,163 @@
+"""Moment matching: weights (the reference's own tests, networks/tests/test_moment_matching.py:7-32, against
+both the oracle restatement and the product's host function) on the CPU; one full update against torch
+autograd on the fp64 restatement and the CLI on the GPU (run/tests/test_bptt_moments.py:10-40)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_torch as og
+from oracle import ssn_numpy as on
+
+TYPES = ('mean', 'ew_mean', 'ew_relative')
+
+
+def _weights(kind, data, type, lam):
+    if kind == 'oracle':
+        return og.moment_weights(data, type, 1e-3, lam)
+    from tc_gan_amd.networks.moment_matching import calc_moment_weights
+    return calc_moment_weights(data, type, 1e-3, lam)
+
+
+@pytest.mark.parametrize('kind', ['oracle', 'product'])
+@pytest.mark.parametrize('type', TYPES)
+@pytest.mark.parametrize('num_tcdom', [1, 2, 5])
+def test_moment_weights_shape_and_lam0(kind, type, num_tcdom):
+    dm, w = _weights(kind, np.ones((3, num_tcdom)), type, 1)
+    assert w.shape == dm.shape == (2, num_tcdom)
+    wm, wv = _weights(kind, np.ones((3, num_tcdom)), type, 0)[1]
+    assert (wm > 0).any() and (wv == 0).all()
+
+
+@pytest.mark.parametrize('type', TYPES)
+def test_moment_weights_product_equals_oracle(type):
+    from tc_gan_amd.networks.moment_matching import MOMENT_WEIGHT_TYPES
+    assert MOMENT_WEIGHT_TYPES == TYPES
+    data = np.random.RandomState(3).rand(17, 6) * 20
+    for a, b in zip(_weights('oracle', data, type, 0.1), _weights('product', data, type, 0.1)):
+        np.testing.assert_allclose(a, b, rtol=1e-13)
+    # closed forms of moment_matching.py:25-88
+    dm, w = _weights('oracle', data, type, 0.1)
+    if type == 'mean':
+        np.testing.assert_allclose(w[0], 1 / data.mean() ** 2)
+        np.testing.assert_allclose(w[1], 0.1 / data.mean() ** 4)
+    elif type == 'ew_mean':
+        np.testing.assert_allclose(w[1], 0.1 / (dm[0] + 1e-3) ** 4)
+    else:
+        np.testing.assert_allclose(w[1], 0.1 / (dm[1] + 1e-3) ** 2)
+
+
+JDS = on.new_JDS()
+MM_PARAMS = dict(num_sites=10, seqlen=40, skip_steps=30, batchsize=6, sample_sites=[0, 0.5],
+                 include_inhibitory_neurons=True, bandwidths=[0.0625, 0.25, 0.75], contrasts=[5., 20.],
+                 J0=JDS['J'], D0=JDS['D'], S0=JDS['S'], lam=0.1, moment_weights_regularization=1e-3,
+                 learning_rate=0.01, update_name='sgd', dynamics_cost=1.0, rate_cost=0.01, rate_penalty_threshold=5.0,
+                 J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mwt', TYPES)
+def test_one_moment_matching_update_vs_oracle(mwt):
+    """Same seed -> same zs; loss, penalties, minibatch moments and the post-update (J, D, S)."""
+    from tc_gan_amd.networks.moment_matching import make_moment_matcher
+    mm, rest = make_moment_matcher(dict(MM_PARAMS, moment_weight_type=mwt, truth_size=3))
+    assert rest == {'truth_size': 3}
+    assert mm.num_mom_conds == 6 * 4 and list(mm.sample_sites) == list(mm.gen.probes[:2])
+    data = np.random.RandomState(5).rand(9, mm.num_mom_conds) * 8
+    mm.set_dataset(data)
+    info = next(mm.learning())
+    assert info.step == 0
+
+    N = 10
+    rng = np.random.RandomState(0)
+    zs = og.t64(rng.rand(6, 2 * N, 2 * N))
+    dm, w = og.moment_weights(data, mwt, 1e-3, 0.1)
+    bw = np.tile(np.asarray(MM_PARAMS['bandwidths']), 2)[None].repeat(6, 0)      # contrast-major grid (wgan.py:293-296)
+    con = np.repeat(np.asarray(MM_PARAMS['contrasts']), 3)[None].repeat(6, 0)
+    np.testing.assert_array_equal(bw, mm.stimulator_bandwidths)
+    np.testing.assert_array_equal(con, mm.stimulator_contrasts)
+    J, D, S = (og.t64(JDS[k]).clone().requires_grad_(True) for k in 'JDS')
+    loss, aux = og.moment_matching_loss(
+        J, D, S, zs, bw, con, mm.gen.probes, dm, w, num_sites=N, smoothness=on.DEFAULT_PARAMS['smoothness'],
+        io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=0.1, seqlen=40, skip_steps=30,
+        rate_penalty_threshold=5.0, dynamics_cost=1.0, rate_cost=0.01)
+    gJ, gD, gS = torch.autograd.grad(loss, [J, D, S])
+    np.testing.assert_allclose(info.loss, float(loss), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(info.dynamics_penalty, float(aux['dynamics_penalty']), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(info.rate_penalty, float(aux['rate_penalty']), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(info.gen_moments, aux['gen_moments'].detach().numpy(), rtol=1e-3, atol=1e-6)
+    for name, g in (('J', gJ), ('D', gD), ('S', gS)):
+        want = np.clip(JDS[name] - 0.01 * g.numpy(), 1e-3, 10)
+        got = getattr(mm.gen, name)
+        np.testing.assert_allclose(got - JDS[name], want - JDS[name], rtol=5e-3,
+                                   atol=5e-3 * np.abs(want - JDS[name]).max())
+
+
+@pytest.mark.gpu
+def test_moment_loss_gradient_kernel_vs_autograd():
+    """ssn_moment_sums_f32 + ssn_moment_loss_grad_f32 on their own, larger shapes."""
+    from tc_gan_amd.networks.moment_matching import BPTTMomentMatcher, calc_moment_weights
+    rs = np.random.RandomState(1)
+    for B, D in ((1, 1), (7, 3), (300, 24), (1024, 8)):
+        x = rs.rand(B, D) * 10
+        data = rs.rand(50, D) * 10
+
+        class Bare(BPTTMomentMatcher):
+            def __init__(self):
+                from tc_gan_amd.networks.cwgan import GradientAllReducer
+                self.reducer = GradientAllReducer()
+                self.global_batchsize = B
+                self.moment_weight_type, self.moment_weights_regularization, self.lam = 'ew_mean', 1e-3, 0.3
+        mm = Bare()
+        mm.set_dataset(data)
+        gx, l0, gm = mm.moment_loss_grad(torch.as_tensor(x, device='cuda', dtype=torch.float32))
+        xt = og.t64(x.astype('float32')).requires_grad_(True)
+        dm, w = calc_moment_weights(data, 'ew_mean', 1e-3, 0.3)
+        want = (og.t64(w) * (og.t64(dm) - og.sample_moments(xt)) ** 2).mean()
+        gw, = torch.autograd.grad(want, xt)
+        np.testing.assert_allclose(l0, float(want), rtol=1e-10)
+        np.testing.assert_allclose(gm, og.sample_moments(xt).detach().numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gx.cpu().numpy(), gw.numpy(), rtol=2e-6, atol=1e-7 * np.abs(gw.numpy()).max())
+
+
+def _load_tables(directory, store):
+    path_h5 = os.path.join(directory, store + '.hdf5')
+    if os.path.exists(path_h5):
+        import h5py
+        with h5py.File(path_h5, 'r') as f:
+            return {k: f[k][...] for k in f}
+    return dict(np.load(os.path.join(directory, store + '.npz')))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('args', [
+    [],
+    ['--sample-sites', '0, 0.5'],
+    ['--include-inhibitory-neurons'],
+    ['--ssn-type', 'heteroin', '--dataset-provider', 'fixedtime', '--include-inhibitory-neurons'],
+    ['--ssn-type', 'deg-heteroin', '--dataset-provider', 'fixedtime', '--moment-weight-type', 'ew_relative'],
+])
+def test_cli_single_g_step(args, tmp_path, monkeypatch):
+    from tc_gan_amd.run import bptt_moments
+    monkeypatch.chdir(tmp_path)
+    bptt_moments.main(['--iterations', '1', '--truth_size', '1', '--n_samples', '1', '--n_bandwidths', '1',
+                       '--seqlen', '4', '--skip-steps', '2', '--gen-moments-record-interval', '1',
+                       '--datastore', 'results', '--quiet'] + args)
+    out = tmp_path / 'results'
+    info = json.load(open(out / 'info.json'))
+    assert info['extra_info']['script_file'] == bptt_moments.__file__
+    assert json.load(open(out / 'exit.json')) == dict(reason='end_of_iteration', good=True)
+    assert np.load(out / 'truth.npy').shape[0] == 1
+    tables = _load_tables(str(out), 'store')
+    assert set(tables) == {'learning', 'generator'}
+    assert tables['learning'].dtype.names == ('step', 'loss', 'rate_penalty', 'dynamics_penalty', 'train_time')
+    assert len(tables['learning']) == 1 and np.isfinite(tables['learning']['loss']).all()
+    gm = _load_tables(str(out), 'gen_moments')['gen_moments']
+    nsites = 2 if '--sample-sites' in args else 1
+    ncond = nsites * (2 if '--include-inhibitory-neurons' in args else 1)
+    assert gm.dtype.names == ('step',) + tuple('mean_%d' % i for i in range(ncond)) + tuple('var_%d' % i for i in range(ncond))
+    vnames = {'heteroin': ('V_E', 'V_I'), 'deg-heteroin': ('V',)}.get(
+        args[args.index('--ssn-type') + 1] if '--ssn-type' in args else 'default', ())
+    assert tables['generator'].dtype.names[:1 + len(vnames)] == ('gen_step',) + vnames
