@@ -94,8 +94,10 @@ def cpu_baseline(N, NB, T, sample_B, threads):
                        (sample_B, NB, T, M, threads, best))
 
 
-def run_c3(args, rank, world, local_rank):
-    """BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
+def run_c3(args, rank, world, local_rank, paper=False):
+    """``paper=True``: the shape of the reference's published run (scripts/fig4/gan/run.json): 2N=202, 128 models,
+    seqlen 240 / skip 200, tau_E=2, deg-heteroin SSN, 4x128 critic with LayerNorm on layers 2-4, rmsprop.
+    Default: BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
     updates (each with a fresh generator forward) + one generator BPTT update; 1024 weight draws x 8
     bandwidths per GPU, 2N=200, seqlen 1200 / skip 1000, 3x512 critic on bf16 MFMA, adam-wgan.
     N>1: num_models = 1024*N sharded 1024 per rank, one RCCL all-reduce per update (weak scaling);
@@ -104,7 +106,7 @@ def run_c3(args, rank, world, local_rank):
     import torch.distributed as dist
     from tc_gan_amd.networks.cwgan import make_gan
     J, D, S = new_jds()
-    N, models, NB, T, skip = 100, 1024, 8, 1200, 1000
+    N, models, NB, T, skip = (101, 128, 8, 240, 200) if paper else (100, 1024, 8, 1200, 1000)
     bandwidths = [0, 0.0625, 0.125, 0.1875, 0.25, 0.5, 0.75, 1]
     cfg = dict(num_sites=N, num_models=models * world, probes_per_model=1, norm_probes=[0.0],
                include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
@@ -114,6 +116,11 @@ def run_c3(args, rank, world, local_rank):
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
                          nonlinearity='rectify', precision='bf16'))
+    if paper:
+        cfg.update(tau_E=2, ssn_type='deg-heteroin', V=0.1)
+        cfg['gen'].update(learning_rate=1e-4, update_name='rmsprop', dynamics_cost=0.0, rate_cost=100.0)
+        cfg['disc'].update(learning_rate=0.02, update_name='rmsprop', layers=[128] * 4,
+                           normalization=['none', 'layer', 'layer', 'layer'], reg_l2_decay=0.001, rate_penalty_bound=1.0)
     gan, _ = make_gan(cfg)
     # truth: 2048 curves from the generator itself at the true parameters (dataset_by_fixedtime), seed 42
     rs = np.random.RandomState(42)
@@ -156,7 +163,8 @@ def run_c3(args, rank, world, local_rank):
     kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
               prober_model_ids=np.arange(models), prober_cell_types=np.zeros(models))
     from tc_gan_amd import genops
-    ext, z, W = gan.gen._device_inputs(bw, kw['stimulator_contrasts'], gan.gen.gen_noise(None, bw)['model_zs'])
+    noise = gan.gen.gen_noise(None, bw)
+    ext, z, W = gan.gen._device_inputs(bw, kw['stimulator_contrasts'], noise['model_zs'], noise.get('model_zs_in'))
     gp = gan.gen.gen_params(200.0)
     genops.gen_forward(W, ext, gp)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -171,11 +179,14 @@ def run_c3(args, rank, world, local_rank):
     achieved = units * (2 * M + 8) / (kernel_ms * 1e-3) * 1e-12
     iters_per_s = args.steps / elapsed
     out = {
-        'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '1024-model GAN iterations/s',
+        'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '%d-model GAN iterations/s' % models,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (critic GEMMs bf16)',
         'data': 'synthetic',
-        'config': {'workload': 'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
+        'config': {'workload': ('C3 paper shape (scripts/fig4/gan/run.json): 2N=202, 128 models x 8 bandwidths per GPU, '
+                                'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
+                                'rmsprop, device-side z (Philox)') if paper else
+                               'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
                                '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
                                'device-side z (Philox)', 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
         'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
@@ -249,7 +260,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c5'])
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c3paper', 'c5'])
     ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 tile (library picks the shape), '
                     '3 tile/split residency, 4 tile/all-register')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -276,6 +287,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.workload == 'c3paper':
+        return run_c3(args, rank, world, local_rank, paper=True)
     if args.workload == 'c3':
         return run_c3(args, rank, world, local_rank)
     if args.workload == 'c5':

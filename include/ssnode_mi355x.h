@@ -162,7 +162,7 @@ typedef struct ssn_gen_params {
     int io_type;                 /* SSN_IO_* */
     int seqlen;                  /* T: Euler steps from r = 0 */
     int skip_steps;              /* first output index of the measurement window */
-    int reserved;
+    int kernel;                  /* 0 library default, 1 VALU tile kernels, 2 MFMA kernels (fp32, NB >= 4) */
     double k, n;
     double tau_E, tau_I, dt;     /* eps = dt / tau per neuron */
     double rate_soft_bound, rate_hard_bound;

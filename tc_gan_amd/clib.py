@@ -117,7 +117,7 @@ for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_sti
 class GenParams(Structure):
     """``ssn_gen_params`` of include/ssnode_mi355x.h."""
     _fields_ = [
-        ('io_type', c_int), ('seqlen', c_int), ('skip_steps', c_int), ('reserved', c_int),
+        ('io_type', c_int), ('seqlen', c_int), ('skip_steps', c_int), ('kernel', c_int),
         ('k', c_double), ('n', c_double),
         ('tau_E', c_double), ('tau_I', c_double), ('dt', c_double),
         ('rate_soft_bound', c_double), ('rate_hard_bound', c_double),

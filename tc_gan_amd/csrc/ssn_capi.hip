@@ -173,6 +173,18 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
     a.B = B; a.NB = NB; a.M = M; a.seqlen = g->seqlen; a.skip = g->skip_steps;
     a.eps_E = (T)(g->dt / g->tau_E); a.eps_I = (T)(g->dt / g->tau_I); a.theta = (T)g->rate_penalty_threshold;
     a.io = gen_io_consts<T>(*g);
+    if constexpr (sizeof(T) == 4) {
+        const bool mfma_ok = ssn::gen_mfma_supported(M, NB);
+        if (g->kernel == 2 && !mfma_ok) {
+            g_last_error = "ssn_gen_forward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
+            return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+        }
+        // default: the MFMA kernel needs one workgroup per (draw, 8 stimuli) on most CUs to pay off
+        if (g->kernel == 2 || (g->kernel == 0 && mfma_ok && (long)B * ((NB + 7) / 8) >= 192)) {
+            SSN_TRY(ssn::launch_gen_forward_mfma(a, (hipStream_t)stream));
+            return 0;
+        }
+    }
     SSN_TRY(ssn::launch_gen_forward<T>(a, (hipStream_t)stream));
     return 0;
 }

@@ -283,7 +283,7 @@ static hipError_t launch_gen_nb(const Args& a, hipStream_t st) {
         // (two stimuli per workgroup at C >= 19 measured no faster at the C3 shape: the loop is VALU-issue bound)
         if constexpr (C <= 13) { if (a.NB >= 2) return launch_gen_k<T, C, 0, 2, FWD>(a, st); }
         // split VGPR/LDS residency (3 waves/SIMD, three workgroups per CU), as in the solver
-        if constexpr (C == 25) return launch_gen_k<T, C, 2, 1, FWD>(a, st);
+        if constexpr (C == 25 || C == 26) return launch_gen_k<T, C, 2, 1, FWD>(a, st);
         if constexpr (C == 19) return launch_gen_k<T, C, 1, 1, FWD>(a, st);
     }
     return launch_gen_k<T, C, 0, 1, FWD>(a, st);

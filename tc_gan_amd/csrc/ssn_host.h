@@ -56,6 +56,10 @@ template <typename T> hipError_t launch_stream(const SolveArgs<T>& a, hipStream_
 template <typename T> bool tile_supported(int M, int NB);
 template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st, int shape = 0);   // 0 default, 1 split residency, 2 all-register
 
+// ssn_mfma.hip (fp32, NB >= 4)
+bool gen_mfma_supported(int M, int NB);
+hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st);
+
 // ssn_gen.hip
 template <typename T> bool gen_supported(int M);
 template <typename T> hipError_t launch_gen_forward(const GenFwdArgs<T>& a, hipStream_t st);

@@ -1,0 +1,287 @@
+// MFMA form of the fixed-time SSN recurrence for SEVERAL stimuli per weight draw (fp32).
+//
+// Every real caller drives one W with NB = 8 stimuli (the 8 bandwidths of a tuning curve), so the per-step
+// product W (M x M) * R (M x NB) is a small GEMM.  v_mfma_f32_4x4x1_16b_f32 maps it without waste:
+//   16 blocks x (4 x 1) * (1 x 4):  A = one column of W for 64 rows (lane l <-> row l: the wave's 64-row slab of W
+//   lives in VGPRs, one row per lane, M registers),  B = r[stimulus l % 4][k] (the lane's stimulus),  D = 4 VGPRs:
+//   lane (blk = l / 4, j = l % 4) ends with the COMPLETE sums of rows 4 blk .. 4 blk + 3 for stimulus j.
+// No cross-lane reduction, no partial sums; all 64 lanes finish 4 (row, stimulus) pairs each.  fp32 MFMA peak equals
+// the packed-FMA VALU peak (157 TFLOP/s) but one wave per SIMD keeps the matrix pipe busy by itself, whereas the VALU
+// tile kernels (ssn_tile.hip) are bound by per-wave issue, LDS traffic and their serial part:
+// tools/microbench/mfma_matvec_rate.hip: 4195 cycles per step for 256 rows x 200 columns x 8 stimuli on one CU
+// = 524 cycles per (draw, stimulus) step, against ~1000 for the split tile shape.
+//
+// Workgroup = 2 * ceil(M / 64) waves for one (draw, group of 8 stimuli) = two MFMA groups of 4 stimuli, SPECIALISED:
+//   * "matrix" waves 0 .. wm-1 hold the W slabs and do nothing but MFMA chains (4 interleaved partial chains per group),
+//   * "serial" waves wm .. 2 wm - 1 (same lane -> (rows, stimulus) map, a few dozen registers) run the serial part of
+//     every step: nonlinearity, Euler update, windowed reductions, trajectory stores, state write.
+// A wave issues in order, one instruction every ~4 cycles, so MFMAs and the ~260 VALU instructions of the serial part
+// do NOT overlap inside one wave (measured: 16.8 ms vs 7.9 ms without the serial part at the C3 shape, however the
+// two were interleaved); issued from two different waves of the same SIMD they do.
+// The two stimulus groups run HALF A STEP APART; phase p (one barrier each):
+//   matrix waves: chain of (group p & 1, step p >> 1) -> accumulators to LDS (abuf)
+//   serial waves: serial part of (group (p-1) & 1, step (p-1) >> 1) from abuf -> new state to LDS (rbuf)
+// State in LDS: rbuf[2][8][MK+4], per stimulus contiguous in the neuron index; a lane reads the B operands of 4
+// consecutive k with one ds_read_b128 (the 4 stimuli of a group sit on disjoint banks) and the serial lane writes its
+// 4 finished rows with one ds_write_b128.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "ssn_device.h"
+#include "ssn_host.h"
+
+#ifndef SSN_MFMA_ABLATE
+#define SSN_MFMA_ABLATE 0      // diagnostic builds: 1 = no serial part (wrong results, timing only)
+#endif
+
+namespace ssn {
+
+typedef float mf4 __attribute__((ext_vector_type(4)));
+
+// f(v) and f'(v) of ssn_gen.hip (kept in sync: ssnode.c:25-53 / ssnode.py:129-149)
+__device__ __forceinline__ void mfma_io_eval_grad(float v, const IoConsts<float>& c, float& f, float& df) {
+    if (!(v > 0.f)) { f = (v != v) ? v : 0.f; df = 0.f; return; }
+    if (c.io_type == SSN_IO_POWER || v <= c.v0) { f = pow_rate(v, c.k, c.n); df = c.n * f / v; return; }
+    if (c.io_type == SSN_IO_LINEAR) { f = c.soft + c.lin_slope * (v - c.v0); df = c.lin_slope; return; }
+    const float th = tanh_pos(c.tanh_gain * (v - c.v0));
+    f = c.soft + c.span * th;
+    df = c.span_gain * (1.f - th * th);
+}
+
+// the wave's 64-row slab of the row-major M x M matrix A (TRANSPOSED: of its transpose): wr[k] = slab[lane][k]
+template <int MK, bool TRANSPOSED>
+__device__ __forceinline__ void slab_load(const float* A, int M, int row, float (&wr)[MK]) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, M * M * 4, 0x00020000);
+    const int rowc = row < M ? row : M - 1;
+    if constexpr (!TRANSPOSED) {
+        const int voff = rowc * M * 4;
+#pragma unroll
+        for (int k4 = 0; k4 < MK; k4 += 4) {
+            // (whole-vector bit_cast: see ssn_tile_core.h)
+            const mf4 v = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k4 * 4, 0));
+            wr[k4] = v.x; wr[k4 + 1] = v.y; wr[k4 + 2] = v.z; wr[k4 + 3] = v.w;
+        }
+    } else {
+        const int voff = rowc * 4;                       // element (row, k) = A[k][row]: coalesced over lanes
+#pragma unroll
+        for (int k = 0; k < MK; ++k)
+            wr[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rsrc, voff, __builtin_amdgcn_readfirstlane((k < M ? k : M - 1) * M * 4), 0));
+    }
+#pragma unroll
+    for (int k = 0; k < MK; ++k) wr[k] = (row < M && k < M) ? wr[k] : 0.f;
+}
+
+// Branch-free f(v), f'(v): the serial part must stay in the basic block of the MFMA chain it hides behind, so the
+// lane-dependent cases (v <= 0, v <= v0) are selects and the (uniform) I/O type is folded into coefficients --
+// a select on a uniform condition would be turned back into a branch.  Same values as io_eval_grad (ssn_gen.hip).
+struct IoSelect {
+    float k, n, v0_low, soft, gain, c_lin, c_tanh, c_tanh_gain;
+    __device__ __forceinline__ explicit IoSelect(const IoConsts<float>& c) {
+        const bool lin = c.io_type == SSN_IO_LINEAR, th = c.io_type == SSN_IO_TANH;
+        k = c.k; n = c.n; soft = c.soft; gain = c.tanh_gain;
+        v0_low = (c.io_type == SSN_IO_POWER) ? __builtin_inff() : c.v0;    // v <= v0_low: power-law branch
+        c_lin = lin ? c.lin_slope : 0.f;
+        c_tanh = th ? c.span : 0.f;
+        c_tanh_gain = th ? c.span_gain : 0.f;
+        v0 = c.v0;
+    }
+    float v0;
+    // WANT_DF = false skips f' (only the backward needs it); the saturating branch is evaluated only when some lane
+    // of the wave is above v0 (rates above the soft bound are rare): one wave-uniform branch.
+    template <bool WANT_DF>
+    __device__ __forceinline__ void eval4(const float (&v)[4], float (&f)[4], float (&df)[4]) const {
+        bool any_high = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float vp = fmaxf(v[i], 1e-30f);
+            const float pw = k * __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(vp));
+            f[i] = (v[i] > 0.f) ? pw : ((v[i] != v[i]) ? v[i] : 0.f);
+            if (WANT_DF) df[i] = (v[i] > 0.f) ? n * pw * __builtin_amdgcn_rcpf(vp) : 0.f;
+            any_high = any_high || (v[i] > v0_low);
+        }
+        if (__builtin_amdgcn_ballot_w64(any_high) != 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float d = v[i] - v0;
+                const float th = tanh_pos(gain * d);
+                const bool high = v[i] > v0_low;
+                f[i] = high ? fmaf(c_tanh, th, fmaf(c_lin, d, soft)) : f[i];
+                if (WANT_DF) df[i] = high ? fmaf(c_tanh_gain, 1.f - th * th, c_lin) : df[i];
+            }
+        }
+    }
+};
+
+template <int MK, bool SAVE>
+__global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<float> a) {
+    constexpr int RS = MK + 4;                    // LDS row stride: the 4 stimuli of a group on disjoint banks
+    constexpr int NQ = MK / 4, DEPTH = 4;         // B-operand reads run DEPTH quads (16 MFMAs) ahead of their use
+    __shared__ __align__(16) float rbuf[2][8][RS];
+    __shared__ __align__(16) float abuf[2][4][64][4];   // accumulator hand-off: [group][matrix wave][lane]
+    const int M = a.M, N = a.M / 2, T_ = a.seqlen;
+    const int ngroups = (a.NB + 7) / 8;
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (int)(blockDim.x >> 7);        // matrix waves (= serial waves)
+    const int blk = lane >> 2, j = lane & 3;
+    const int nphase = 2 * T_ + 1;
+    for (int c = threadIdx.x; c < 2 * 8 * RS; c += blockDim.x) (&rbuf[0][0][0])[c] = 0.f;
+
+    if (wave < wm) {
+        // ================================ matrix wave ================================
+        float wr[MK];
+        slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
+        using LdsV4 = const __attribute__((address_space(3))) mf4*;
+        using LdsF = const __attribute__((address_space(3))) float*;
+        __syncthreads();
+        for (int p = 0; p < nphase; ++p) {
+            if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
+                const int g = p & 1, it = p >> 1;
+                // acc[v] = sum_k wr[k] * x[stimulus 4 g + j][k].  The order [read quad q + DEPTH][4 MFMAs of quad q] is
+                // pinned with data dependencies (empty asm on the LDS address and the accumulators): left alone, the
+                // compiler emits read - wait - use per quad.
+                unsigned xa = (unsigned)(size_t)(LdsF)&rbuf[it & 1][4 * g + j][0];
+                mf4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+                mf4 bq[NQ];
+#pragma unroll
+                for (int q = 0; q < DEPTH; ++q) bq[q] = *(LdsV4)(size_t)(xa + 16u * q);
+                asm volatile("" : "+v"(xa));
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + DEPTH < NQ) bq[q + DEPTH] = *(LdsV4)(size_t)(xa + 16u * (q + DEPTH));
+                    a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q], bq[q].x, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 1], bq[q].y, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 2], bq[q].z, a2, 0, 0, 0);
+                    a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 3], bq[q].w, a3, 0, 0, 0);
+                    asm volatile("" : "+v"(xa), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                }
+                *reinterpret_cast<mf4*>(&abuf[g][wave][lane][0]) = (a0 + a1) + (a2 + a3);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ================================ serial wave ================================
+    const int sw = wave - wm;
+    const int er = 64 * sw + 4 * blk;             // first of the 4 rows this lane finishes
+    const IoSelect io(a.io);
+    float eps[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) eps[v] = (er + v < N) ? a.eps_E : a.eps_I;
+    // per group g: my stimulus s0 + 4 g + j.  Trajectory stores go through a raw buffer whose out-of-range offsets
+    // are dropped by the hardware: lanes without a real (stimulus, row) get offset -1 instead of a branch.
+    bool live[2];
+    float rc[2][4], ex[2][4], ta[2][4], dp[2][4], rpn[2][4];
+    int toff[2];                                  // byte offset of (my stimulus, step 0, row er) within this draw's block
+    const size_t blk_elems = (size_t)a.NB * T_ * M;
+    __amdgpu_buffer_rsrc_t rs_traj, rs_df;
+    if constexpr (SAVE) {
+        rs_traj = __builtin_amdgcn_make_buffer_rsrc(a.traj + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+        rs_df = __builtin_amdgcn_make_buffer_rsrc(a.df + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB;
+        toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rc[g][v] = ta[g][v] = dp[g][v] = rpn[g][v] = 0.f;
+            ex[g][v] = (live[g] && er + v < M) ? a.ext[((size_t)b * a.NB + s) * M + er + v] : 0.f;
+        }
+    }
+    // serial part of (group g, step it): u = acc + ext -> f, f' -> Euler step, windowed reductions, trajectory, state
+    auto serial = [&](auto G, int it) {
+        constexpr int g = decltype(G)::value;
+        const mf4 acc = *reinterpret_cast<const mf4*>(&abuf[g][sw][lane][0]);
+        const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float win = (it >= a.skip) ? 1.f : 0.f, win2 = (it > a.skip) ? 1.f : 0.f;
+        float rnew[4], dfn[4] = {0.f, 0.f, 0.f, 0.f};   // scalars: see the bit_cast note in ssn_tile_core.h
+        float uu[4], ff[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uu[v] = accs[v] + ex[g][v];
+        io.template eval4<SAVE>(uu, ff, dfn);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float f = ff[v];
+            const float r1 = fmaf(eps[v], f - rc[g][v], rc[g][v]);             // (1 - eps) r + eps f(u)
+            const float dd = r1 - rc[g][v];
+            ta[g][v] = fmaf(win, r1, ta[g][v]);
+            rpn[g][v] = fmaf(win, fmaxf(r1 - a.theta, 0.f), rpn[g][v]);
+            dp[g][v] = fmaf(win2 * dd, dd, dp[g][v]);
+            rc[g][v] = r1;
+            rnew[v] = (er + v < M) ? r1 : 0.f;
+        }
+        if constexpr (SAVE) {
+            if (er + 3 < M) {       // whole quad inside the matrix (always when M % 4 == 0)
+                const int off = toff[g] < 0 ? -1 : toff[g] + it * M * 4;
+                const mf4 rv = {rnew[0], rnew[1], rnew[2], rnew[3]}, dv = {dfn[0], dfn[1], dfn[2], dfn[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                    unsigned __attribute__((ext_vector_type(4))), rv), rs_traj, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                    unsigned __attribute__((ext_vector_type(4))), dv), rs_df, off, 0, 0);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int off = (toff[g] < 0 || er + v >= M) ? -1 : toff[g] + (it * M + v) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rnew[v]), rs_traj, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[v]), rs_df, off, 0, 0);
+                }
+            }
+        }
+        if (er < M) *reinterpret_cast<mf4*>(&rbuf[(it + 1) & 1][4 * g + j][er]) = (mf4){rnew[0], rnew[1], rnew[2], rnew[3]};
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+    __syncthreads();
+    __syncthreads();                                  // phase 0: nothing to finish yet
+    for (int it = 0; it < T_; ++it) {
+        if (!(SSN_MFMA_ABLATE & 1)) serial(G0, it);     // phase 2 it + 1
+        __syncthreads();
+        if (!(SSN_MFMA_ABLATE & 1)) serial(G1, it);     // phase 2 it + 2
+        __syncthreads();
+    }
+
+    const float inv = 1.f / (float)(T_ - a.skip);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!live[g]) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (er + v >= M) continue;
+            const size_t o = ((size_t)b * a.NB + s0 + 4 * g + j) * M + er + v;
+            a.time_avg[o] = ta[g][v] * inv;
+            a.dyn_row[o] = dp[g][v];
+            a.rate_row[o] = rpn[g][v];
+        }
+    }
+}
+
+static int mfma_pick_mk(int M) {
+    const int ladder[] = {104, 152, 200, 208};
+    for (int mk : ladder) if (M <= mk) return mk;
+    return 0;
+}
+bool gen_mfma_supported(int M, int NB) { return (M % 2 == 0) && NB >= 4 && mfma_pick_mk(M) != 0; }
+
+template <int MK>
+static hipError_t launch_fwd_mk(const GenFwdArgs<float>& a, hipStream_t st) {
+    const int waves = (a.M + 63) / 64;
+    const int ngroups = (a.NB + 7) / 8;
+    if (a.traj) hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, true>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    else hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, false>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st) {
+    switch (mfma_pick_mk(a.M)) {
+        case 104: return launch_fwd_mk<104>(a, st);
+        case 152: return launch_fwd_mk<152>(a, st);
+        case 200: return launch_fwd_mk<200>(a, st);
+        case 208: return launch_fwd_mk<208>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ssn

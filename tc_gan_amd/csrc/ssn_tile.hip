@@ -244,7 +244,7 @@ static hipError_t launch_tile_k(const SolveArgs<T>& a, hipStream_t st) {
 template <typename T, int C>
 static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st, bool split) {
     if constexpr (sizeof(T) == 4) {
-        if constexpr (C == 25) { if (split) return launch_tile_k<T, TILE_RA, C, 2, 1, 3>(a, st); }
+        if constexpr (C == 25) { if (split) return launch_tile_k<T, TILE_RA, C, 2, 1, 3>(a, st); }   // (C = 26 spills in the loop)
         if constexpr (C == 19) { if (split) return launch_tile_k<T, TILE_RA, C, 1, 1, 3>(a, st); }
         // 7*C W registers + 8*NB accumulators + 4*NB states must stay under 256 VGPRs (no spills)
         if constexpr (C <= 19) { if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 0, 4, 2>(a, st); }

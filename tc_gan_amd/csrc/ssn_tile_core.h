@@ -156,7 +156,7 @@ __device__ __forceinline__ void tile_load(const T* A, int M, int rowbase, int co
         } else {
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                w[r][c] = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
+                w[r][c] = buffer_load_elem(rsrc, voff, (TRANSPOSED ? __builtin_amdgcn_readfirstlane(c * M) : c) * (int)sizeof(T), (T)0);
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) w[r][c] = (row < M && c < ncol) ? w[r][c] : (T)0;
@@ -223,7 +223,7 @@ template <typename T, int RA, int C, int RL> struct SplitTile {
             } else {
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    t[c] = buffer_load_elem(rsrc, voff, (TRANSPOSED ? c * M : c) * (int)sizeof(T), (T)0);
+                    t[c] = buffer_load_elem(rsrc, voff, (TRANSPOSED ? __builtin_amdgcn_readfirstlane(c * M) : c) * (int)sizeof(T), (T)0);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) t[c] = (row < M && c < ncol) ? t[c] : (T)0;

@@ -16,15 +16,19 @@ def _problem(N, B, NB, seed, T, skip, theta):
     rs = np.random.RandomState(seed)
     jds = on.new_JDS()
     z = rs.rand(B, 2 * N, 2 * N)
-    bws = np.tile(np.asarray(P['bandwidths'])[None, :NB], (B, 1))
+    bws = np.tile(np.resize(np.asarray(P['bandwidths']), NB)[None, :] * (1 + 0.05 * (np.arange(NB) // 8)), (B, 1))
     con = np.tile(rs.choice([5., 20.], size=(B, 1)), (1, NB))
     return jds, z, bws, con
 
 
 @pytest.mark.parametrize('io_type', ['asym_tanh', 'asym_power', 'asym_linear'])
-@pytest.mark.parametrize('N,B,NB,dtype', [(10, 3, 8, 'float64'), (50, 2, 4, 'float32'), (100, 2, 3, 'float32'),
-                                           (102, 2, 1, 'float32'), (26, 3, 5, 'float64')])
-def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype):
+@pytest.mark.parametrize('N,B,NB,dtype,kernel', [
+    (10, 3, 8, 'float64', 0), (50, 2, 4, 'float32', 1), (100, 2, 3, 'float32', 0), (102, 2, 1, 'float32', 0),
+    (26, 3, 5, 'float64', 0),
+    # fp32 with NB >= 4: the MFMA kernels (kernel 0 = library default = 2 here), tile kernels forced with 1
+    (50, 2, 4, 'float32', 2), (100, 2, 8, 'float32', 0), (100, 1, 8, 'float32', 1), (101, 2, 9, 'float32', 2),
+    (76, 1, 11, 'float32', 0), (10, 3, 8, 'float32', 2), (33, 2, 5, 'float32', 2), (104, 1, 4, 'float32', 2)])
+def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
     from tc_gan_amd import genops, stimuli, weight_gen
     T, skip, theta = 60, 40, 2.0
     jds, z, bws, con = _problem(N, B, NB, N + NB, T, skip, theta)
@@ -35,7 +39,7 @@ def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype):
                                                 return_trajectory=True, **gen)
     W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype=dtype)
     ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype=dtype)
-    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, **gen)
+    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, kernel=kernel, **gen)
     out = genops.gen_forward(W, ext, gp, save=True)
     rtol = 1e-4 if dtype == 'float32' else 1e-9
     np.testing.assert_allclose(out['time_avg'].cpu().numpy(), ta_o.numpy(), rtol=rtol, atol=rtol * 1e-2)
