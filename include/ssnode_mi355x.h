@@ -299,6 +299,24 @@ int ssn_moment_sums_f32(const float *x, int B, int D, double *sums, void *stream
 int ssn_moment_loss_grad_f32(const float *x, const double *sums, double global_batch, const double *data_moments,
                              const double *weights, int B, int D, float *gx, double *out, void *stream);
 
+/* ---- 7. Fixed-point implicit gradient (tc_gan/gradient_expressions/SS_grad.py:17-99, make_w_batch.py:36-121) -----
+ * dW[b][i][j][p][q] = d W[b][i][j] / d theta[p][q] for theta = J (which 0; independent of z, z may be NULL),
+ * D (1) or S (2): the tensors make_WJ_with_x / make_WD_with_x / make_WS_with_x build (identity dJ'/dJ). */
+int ssn_build_dw_f32(const float *z, const float *J, const float *D, const float *S, int which, float *dW, int B, int N,
+                     void *stream);
+int ssn_build_dw_f64(const double *z, const double *J, const double *D, const double *S, int which, double *dW, int B,
+                     int N, void *stream);
+/* The batched linear systems of WRgrad_batch at fixed points R[nz][nb][M]:  A[z][b] = 1 - Phi W[z],
+ * rhs[z][b][i][c] = Phi_i * sum_j dW[z][i][j][c] R[z][b][j],  Phi = f'(W R + I) (I [nb][M], or [nz][nb][M] when
+ * i_per_draw; dW [nz][M][M][4], or [1][M][M][4] when !dw_per_draw).  Solving A x = rhs gives dR/dtheta[z][b][M][2][2].
+ * p: io_type, k, n, rate_soft_bound, rate_hard_bound are used.  All device pointers. */
+int ssn_ss_grad_system_f32(const float *R, const float *W, const float *dW, int dw_per_draw, const float *I,
+                           int i_per_draw, int nz, int nb, int M, const ssn_solver_params *p, float *A, float *rhs,
+                           void *stream);
+int ssn_ss_grad_system_f64(const double *R, const double *W, const double *dW, int dw_per_draw, const double *I,
+                           int i_per_draw, int nz, int nb, int M, const ssn_solver_params *p, double *A, double *rhs,
+                           void *stream);
+
 /* Heterogeneous-input variant (networks/ssn.py:645-772): ext *= amp[b][m], amp = 1 + v_pop * z_in,
  * device [B][2N] (NULL = homogeneous). */
 int ssn_stimulus_amp_f32(const float *bandwidths, const float *contrasts, float smoothness, const float *amp,

@@ -209,6 +209,30 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
 
 }  // namespace
 
+template <typename T>
+static int build_dw_impl(const T* z, const T* J, const T* D, const T* S, int which, T* dW, int B, int N, void* stream) {
+    if (B < 0 || N < 1 || which < 0 || which > 2 || (B > 0 && (!dW || (which > 0 && !z) || !J || !D || !S))) {
+        g_last_error = "ssn_build_dw: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    T jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_build_dw<T>(z, jds, which, dW, B, N, (hipStream_t)stream));
+    return 0;
+}
+template <typename T>
+static int ss_system_impl(const T* R, const T* W, const T* dW, int dw_per_draw, const T* I, int i_per_draw, int nz,
+                          int nb, int M, const ssn_solver_params* p, T* A, T* rhs, void* stream) {
+    if (nz == 0 || nb == 0) return 0;
+    if (!p || !R || !W || !dW || !I || !A || !rhs || nz < 0 || nb < 0 || M <= 0 || (M & 1) || p->io_type < 0 ||
+        p->io_type > 2) {
+        g_last_error = "ssn_ss_grad_system: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_ss_system<T>(R, W, dW, dw_per_draw, I, i_per_draw, ssn::make_io_consts<T>(*p), nz, nb, M, A, rhs,
+                                     (hipStream_t)stream));
+    return 0;
+}
 extern "C" {
 
 long ssn_critic_num_params(const int* dims, int nlayers) {
@@ -329,6 +353,22 @@ int ssn_ff_backward_f32(const float* RF_w, const float* FF_con, const float* FF_
     a.q = const_cast<float*>(q); a.den = const_cast<float*>(den);
     SSN_TRY(ssn::launch_ff_backward(a, gq, dsig, (hipStream_t)stream));
     return 0;
+}
+
+int ssn_build_dw_f32(const float* z, const float* J, const float* D, const float* S, int which, float* dW, int B, int N,
+                     void* stream) { return build_dw_impl<float>(z, J, D, S, which, dW, B, N, stream); }
+int ssn_build_dw_f64(const double* z, const double* J, const double* D, const double* S, int which, double* dW, int B,
+                     int N, void* stream) { return build_dw_impl<double>(z, J, D, S, which, dW, B, N, stream); }
+
+int ssn_ss_grad_system_f32(const float* R, const float* W, const float* dW, int dw_per_draw, const float* I,
+                           int i_per_draw, int nz, int nb, int M, const ssn_solver_params* p, float* A, float* rhs,
+                           void* stream) {
+    return ss_system_impl<float>(R, W, dW, dw_per_draw, I, i_per_draw, nz, nb, M, p, A, rhs, stream);
+}
+int ssn_ss_grad_system_f64(const double* R, const double* W, const double* dW, int dw_per_draw, const double* I,
+                           int i_per_draw, int nz, int nb, int M, const ssn_solver_params* p, double* A, double* rhs,
+                           void* stream) {
+    return ss_system_impl<double>(R, W, dW, dw_per_draw, I, i_per_draw, nz, nb, M, p, A, rhs, stream);
 }
 
 int ssn_moment_sums_f32(const float* x, int B, int D, double* sums, void* stream) {

@@ -56,6 +56,11 @@ template <typename T> hipError_t launch_stream(const SolveArgs<T>& a, hipStream_
 template <typename T> bool tile_supported(int M, int NB);
 template <typename T> hipError_t launch_tile(const SolveArgs<T>& a, hipStream_t st, int shape = 0);   // 0 default, 1 split residency, 2 all-register
 
+// ssn_ssgrad.hip
+template <typename T> hipError_t launch_build_dw(const T* z, const T* jds12, int which, T* dW, int B, int N, hipStream_t st);
+template <typename T> hipError_t launch_ss_system(const T* R, const T* W, const T* dW, int dw_per_draw, const T* I, int i_per_draw,
+                                                  const IoConsts<T>& io, int nz, int nb, int M, T* A, T* rhs, hipStream_t st);
+
 // ssn_mfma.hip (fp32, NB >= 4)
 bool gen_mfma_supported(int M, int NB);
 hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st);
