@@ -37,3 +37,15 @@ def ff_output(RF_l, RF_d, TH, TH_d, J, a, RF_w, FF_con, FF_str, TH_sam, pos, sti
     drive = torch.einsum('sig,shg->sih', act, weights)
     thr = TH + torch.sign(TH_sam) * TH_sam.abs() ** a * TH_d                         # (nsam, nhid)
     return torch.relu(drive - thr[:, None, :])
+
+
+def ff_critic_loss(w, xd, xg, xp, lam=1.0, plam=1.0):
+    """FF_lalazar_model.py:398-437 with ``SD.make_net(INSHAPE, "WGAN")`` (no hidden layers: one bias-free linear
+    unit): mean D(xg) - mean D(xd) + lam * mean((||dD(log(1 + xp))/dxp|| - 1)^2) + plam * sum(w^2);
+    the gradient norm through autograd, as the script's T.jacobian does."""
+    xp = xp.clone().requires_grad_(True)
+    d = torch.log(1 + xp) @ w
+    g, = torch.autograd.grad(d.sum(), xp, create_graph=True)
+    pen = ((torch.sqrt((g ** 2).sum(dim=1)) - 1) ** 2).mean()
+    wdist = (xg @ w).mean() - (xd @ w).mean()
+    return wdist + lam * pen + plam * (w ** 2).sum(), wdist

@@ -48,3 +48,61 @@ def test_ff_sparse_connectivity_shape_of_the_model_script():
     assert con.shape == (3, 1, 1000) and con.sum(axis=2).max() <= 10
     out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, ff_model.default_stimuli(), 10)
     assert out.shape == (3, 27, 1) and bool(torch.isfinite(out).all())
+
+
+def test_ff_wgan_steps_vs_autograd(tmp_path):
+    """One critic step and one generator step of the FF WGAN (FF_lalazar_model.py:223-330, 398-454): closed-form
+    critic gradient vs autograd on the restated loss, Adam(.5, .9) update, generator gradient through the kernels."""
+    from oracle import gan_torch as og
+    from tc_gan_amd import ff_model, ff_wgan
+    box, nsam = 8, 6
+    curves = np.random.RandomState(3).rand(40, 27) * 30
+    gan = ff_wgan.FFWGAN(box, curves, nsam=nsam, seed=7)
+    w0 = gan.w.cpu().numpy().astype('float64')
+    # -- critic loss / gradient on fixed minibatches
+    rs = np.random.RandomState(2)
+    xd, xg = rs.rand(nsam, 27) * 20, rs.rand(nsam, 27) * 20
+    ee = rs.rand(nsam, 1)
+    xp = ee * xd + (1 - ee) * xg
+    tw = of.torch.tensor(w0, dtype=of.DT, requires_grad=True)
+    loss_o, wdist_o = of.ff_critic_loss(tw, *(of.torch.tensor(a, dtype=of.DT) for a in (xd, xg, xp)))
+    g_o, = of.torch.autograd.grad(loss_o, tw)
+    wdist, loss, grad = gan.critic_loss_grad(*(torch.as_tensor(a, device='cuda', dtype=torch.float32) for a in (xd, xg, xp)))
+    np.testing.assert_allclose(wdist, float(wdist_o), rtol=1e-5)
+    np.testing.assert_allclose(loss, float(loss_o), rtol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g_o.numpy(), rtol=2e-5, atol=1e-6)
+    # -- one critic step = Adam(beta1 .5, beta2 .9) on that kind of gradient, RNG order of the script
+    rng = np.random.RandomState(7)
+    rng.choice(np.arange(1), 1)
+    a = np.sqrt(6.0 / 28)
+    np.testing.assert_allclose(w0, rng.uniform(-a, a, 27), rtol=1e-6)
+    ss = ff_model.generate_samples(rng, nsam, box, 1)
+    ff_model.generate_samples(rng, nsam, box, 1)
+    idx = rng.choice(np.arange(len(curves)), nsam)
+    eps = rng.rand(nsam, 1)
+    p = {k: of.torch.tensor(float(v), dtype=of.DT) for k, v in ff_model.START_PARAMS.items()}
+    con, strn, wid, ths = (of.torch.tensor(a, dtype=of.DT) for a in ss)
+    out = of.ff_output(p['RF_low'].exp(), p['RF_del'].exp(), p['THR'], p['THR_del'].exp(), p['Js'].exp(), p['As'].exp(),
+                        wid, con, strn, ths, of.grid_positions(box), of.default_stimuli())[:, :, 0]
+    xd_t = of.torch.tensor(curves[idx], dtype=of.DT)
+    eps_t = of.torch.tensor(eps, dtype=of.DT)
+    tw = of.torch.tensor(w0, dtype=of.DT, requires_grad=True)
+    loss_o, wdist_o = of.ff_critic_loss(tw, xd_t, out, eps_t * xd_t + (1 - eps_t) * out)
+    g_o, = of.torch.autograd.grad(loss_o, tw)
+    w1 = og.adam_step(w0, g_o.numpy(), {}, 0.01, beta1=0.5, beta2=0.9)
+    got = gan.critic_step()
+    np.testing.assert_allclose(got, float(wdist_o), rtol=2e-3, atol=1e-4)
+    np.testing.assert_allclose(gan.w.cpu().numpy(), w1, rtol=2e-3, atol=2e-5)
+    # -- generator step: loss value and the direction of the Adam step (first step moves by lr * sign(grad))
+    before = dict(gan.params)
+    gloss, _ = gan.generator_step()
+    assert np.isfinite(gloss)
+    moved = [abs(gan.params[n] - before[n]) for n in ff_model.PARAM_NAMES]
+    assert all(m <= 0.01001 for m in moved) and max(moved) > 0.009
+    # -- the loop writes the script's files
+    gan.train(2, outdir=str(tmp_path), n_critic=1, n_critic_first=2)
+    tag = 'wgan_FF_8_8'
+    assert open(tmp_path / 'FF_logs' / ('FF_log_' + tag + '.csv')).readline() == 'RF\tRFd\tJ\tth\tth_d\n'
+    assert len(open(tmp_path / 'FF_logs' / ('FF_losslog_' + tag + '.csv')).readlines()) == 1 + (2 + 1) + (1 + 1)
+    assert len(open(tmp_path / ('tuning_curves' + tag + '.csv')).readlines()) == 2 * nsam
+    assert (tmp_path / 'disc_params' / ('D_par_0_' + tag + '.npy')).exists()
