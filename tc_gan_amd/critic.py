@@ -192,6 +192,20 @@ class Updater(object):
         self.step = 0
         self._state = None
 
+    def state_dict(self):
+        """Optimizer state for checkpoints (step counter and the two moment buffers)."""
+        st = self._state
+        return dict(step=self.step, m=None if st is None else st[0].cpu().numpy(),
+                    v=None if st is None else st[1].cpu().numpy())
+
+    def load_state_dict(self, d):
+        self.step = int(d['step'])
+        if d.get('m') is None:
+            self._state = None
+        else:
+            self._state = tuple(torch.as_tensor(np.asarray(d[k]), device='cuda', dtype=torch.float32).contiguous()
+                                for k in ('m', 'v'))
+
     def __call__(self, params, grads, clip=None):
         """In-place update of the flat device tensor `params` from `grads`."""
         if self._state is None or self._state[0].shape != params.shape:

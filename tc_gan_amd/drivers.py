@@ -118,7 +118,10 @@ class BPTTWGANDriver(object):
     """drivers.py:61-180 + 298-337 (GANDriver machinery specialised to the BPTT WGANs)."""
 
     def __init__(self, gan, datastore, iterations, quiet, disc_param_save_interval, disc_param_template,
-                 disc_param_save_on_error, quit_JDS_threshold=-1, **kwargs):
+                 disc_param_save_on_error, quit_JDS_threshold=-1, checkpoint_interval=-1, resume_from=None, **kwargs):
+        self.checkpoint_interval = checkpoint_interval      # new: write <datastore>/checkpoint.pkl every K generator steps
+        self.resume_from = resume_from                      # new: continue from such a file
+        self.start_step = 0
         self.gan = gan
         self.datastore = datastore
         self.iterations = iterations
@@ -151,6 +154,8 @@ class BPTTWGANDriver(object):
         if is_at_interval(gen_step, self.disc_param_save_interval):
             param_file.dump(self.gan.discriminator,
                             self.datastore.path('disc_param', self.disc_param_template.format(gen_step)))
+        if is_at_interval(gen_step, self.checkpoint_interval):
+            self.gan.save_checkpoint(self.datastore.path('checkpoint.pkl'), gen_step)
         self.datastore.flush_all()
         # NB: the reference exponentiates (J, D, S) here (they used to be stored as logs) and compares with the
         # original parameters; kept for identical exit behaviour (drivers.py:147-152).
@@ -172,12 +177,15 @@ class BPTTWGANDriver(object):
         self.pre_loop()
         logger.info('%s: start iterations', self.__class__.__name__)
         with recording_exit_reason(self.datastore):
-            for gen_step in range(self.iterations):
+            for gen_step in range(self.start_step, self.iterations):
                 self.post_update(gen_step, update_func(gen_step))
         logger.info('%s: maximum iterations reached', self.__class__.__name__)
 
     def run(self, gan):
-        learning_it = gan.learning()
+        if self.resume_from:
+            self.start_step = gan.load_checkpoint(self.resume_from)
+            logger.info('resumed from %s: continuing with generator step %d', self.resume_from, self.start_step)
+        learning_it = gan.learning(self.start_step)
         state = {}
 
         def update_func(k):

@@ -6,9 +6,9 @@ Host-side mirror of ``tc_gan/execution.py`` (no arithmetic).  Same on-disk names
 ``disc_param_stats`` in the shared store and ``tc_stats`` in a dedicated one.
 
 The reference keeps typed tables in ``store.hdf5`` via h5py (execution.py:156-213).  When h5py is
-importable the same files are written; otherwise (this image has no h5py) each store becomes a
-``.npz`` of structured arrays with identical table names and dtypes (``store.npz``,
-``tc_stats.npz``), rewritten on every ``flush_all``.
+importable the same files are written; otherwise (this image has no h5py) every table becomes a
+``<table>.csv`` with a header row (same column names), appended row by row -- the format the reference's
+own loader tries first (loaders/datastore_loader.py:55-59).  `tc_gan_amd.loaders.load_records` reads both.
 """
 from getpass import getuser
 from logging import getLogger
@@ -110,26 +110,29 @@ class DataTables(object):
 
 class TypedTables(object):
     """Typed row tables: ``create_table(name, dtype, dedicated)``, ``saverow(name, typed_row)``
-    (the interface of HDF5Tables, execution.py:156-191)."""
+    (the interface of HDF5Tables, execution.py:156-191).
+
+    With h5py: ``store.hdf5`` (+ one file per dedicated table), as the reference writes them.  Without h5py:
+    one ``<table>.csv`` with a header row per table, appended row by row -- the format the reference's loader
+    looks for FIRST (loaders/datastore_loader.py:55-59), so its `load_records` reads either."""
 
     shared_filename = 'store'
 
     def __init__(self, directory):
         self.directory = directory
-        self._rows = {}        # table -> list of structured scalars
         self._dtype = {}
         self._file_of = {}
         try:
             import h5py       # noqa: F401
             self.backend = 'hdf5'
         except ImportError:
-            self.backend = 'npz'
+            self.backend = 'csv'
         self._h5 = {}
+        self._csv = {}
 
     def create_table(self, name, dtype, dedicated=False):
         assert name not in self._dtype
         self._dtype[name] = numpy.dtype(dtype)
-        self._rows[name] = []
         self._file_of[name] = name if dedicated else self.shared_filename
         if self.backend == 'hdf5':
             import h5py
@@ -137,6 +140,10 @@ class TypedTables(object):
             if fname not in self._h5:
                 self._h5[fname] = h5py.File(os.path.join(self.directory, fname), 'w')
             self._h5[fname].create_dataset(name, (0,), maxshape=(None,), dtype=self._dtype[name])
+        else:
+            f = open(os.path.join(self.directory, name + '.csv'), 'w')
+            f.write(','.join(self._dtype[name].names) + '\n')
+            self._csv[name] = f
 
     def saverow(self, name, row, echo=False, flush=False):
         if name not in self._dtype:
@@ -146,30 +153,19 @@ class TypedTables(object):
             ds.resize((len(ds) + 1,))
             ds[-1] = row
         else:
-            self._rows[name].append(row)
+            self._csv[name].write(','.join(repr(v) for v in row.tolist()) + '\n')
         if flush:
             self.flush_all()
         if echo:
             print(*row.tolist(), sep=',')
 
     def flush_all(self):
-        if self.backend == 'hdf5':
-            for f in self._h5.values():
-                f.flush()
-            return
-        by_file = {}
-        for name, rows in self._rows.items():
-            arr = numpy.array(rows, dtype=self._dtype[name]) if rows else numpy.zeros(0, dtype=self._dtype[name])
-            by_file.setdefault(self._file_of[name], {})[name] = arr
-        for fname, tables in by_file.items():
-            path = os.path.join(self.directory, fname + '.npz')
-            tmp = path + '.tmp.npz'
-            numpy.savez(tmp, **tables)
-            os.replace(tmp, path)
+        for f in list(self._h5.values()) + list(self._csv.values()):
+            f.flush()
 
     def close(self):
         self.flush_all()
-        for f in self._h5.values():
+        for f in list(self._h5.values()) + list(self._csv.values()):
             f.close()
 
 

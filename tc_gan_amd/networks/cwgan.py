@@ -20,6 +20,8 @@ grads | loss scalars) makes the replicas take identical optimizer steps.
 """
 from logging import getLogger
 
+import os
+
 import numpy as np
 import torch
 
@@ -359,14 +361,56 @@ class ConditionalBPTTWassersteinGAN(object):
                      self.disc_train_watch.mean(), self.gen_train_watch.mean())
         yield info
 
-    def learning(self):
-        """wgan.py:439-444: `critic_iters_init` critic steps before generator step 0, then `critic_iters`."""
+    def learning(self, start_step=0):
+        """wgan.py:439-444: `critic_iters_init` critic steps before generator step 0, then `critic_iters`.
+        `start_step` > 0 continues a run restored with `load_state_dict` (no second initial critic phase)."""
         import itertools
-        for info in self._single_gen_step(0, self.critic_iters_init):
-            yield info
-        for gen_step in itertools.count(1):
+        if start_step == 0:
+            for info in self._single_gen_step(0, self.critic_iters_init):
+                yield info
+        for gen_step in itertools.count(max(start_step, 1)):
             for info in self._single_gen_step(gen_step, self.critic_iters):
                 yield info
+
+    # -- checkpoints (not in the reference: its runs cannot be resumed) -------------------------------------
+    def state_dict(self):
+        """Everything a bit-identical continuation needs: generator and critic parameters, the optimizer states,
+        the host RandomState (shared with the minibatch sampler) and the device noise generator."""
+        kind, keys, pos, has_gauss, cached = self.rng.get_state()
+        d = dict(gen={name: np.array(value) for name, value in self.gen.get_all_params()},
+                 disc=self.disc.get_flat(), disc_updater=self.disc_updater.state_dict(),
+                 gen_updaters={name: self.gen_updaters[name].state_dict() for name in self._pnames},
+                 rng=dict(kind=kind, keys=keys, pos=pos, has_gauss=has_gauss, cached=cached))
+        if self.gen._zgen is not None:
+            d['zgen'] = self.gen._zgen.get_state().cpu().numpy()
+        return d
+
+    def load_state_dict(self, d):
+        self.gen.set_params(d['gen'])
+        self.disc.set_flat(np.asarray(d['disc']))
+        self.disc_updater.load_state_dict(d['disc_updater'])
+        for name in self._pnames:
+            self.gen_updaters[name].load_state_dict(d['gen_updaters'][name])
+        r = d['rng']
+        self.rng.set_state((str(r['kind']), np.asarray(r['keys'], dtype='uint32'), int(r['pos']), int(r['has_gauss']),
+                            float(r['cached'])))
+        if self.gen._zgen is not None and 'zgen' in d:
+            self.gen._zgen.set_state(torch.as_tensor(np.asarray(d['zgen'], dtype='uint8')))
+
+    def save_checkpoint(self, path, gen_step):
+        import pickle
+        tmp = path + '.tmp'
+        with open(tmp, 'wb') as f:
+            pickle.dump(dict(version=1, gen_step=int(gen_step), state=self.state_dict()), f, protocol=4)
+        os.replace(tmp, path)
+
+    def load_checkpoint(self, path):
+        """Restore a checkpoint (after `set_dataset`); returns the generator step to continue WITH."""
+        import pickle
+        with open(path, 'rb') as f:
+            ck = pickle.load(f)
+        self.load_state_dict(ck['state'])
+        return ck['gen_step'] + 1
 
 
 def make_gan(config):

@@ -34,7 +34,8 @@ def make_parser():
 
 
 def init_driver(datastore, iterations, quit_JDS_threshold, quiet, tc_stats_record_interval,
-                disc_param_save_interval, disc_param_template, disc_param_save_on_error, layers, **run_config):
+                disc_param_save_interval, disc_param_template, disc_param_save_on_error, layers,
+                checkpoint_interval=-1, resume_from=None, **run_config):
     del layers                       # only used for the datastore name (execution.format_datastore)
     run_config = utils.subdict_by_prefix(run_config, 'disc_')
     run_config = utils.subdict_by_prefix(run_config, 'gen_')
@@ -42,7 +43,8 @@ def init_driver(datastore, iterations, quit_JDS_threshold, quiet, tc_stats_recor
     driver = BPTTcWGANDriver(
         gan, datastore, iterations=iterations, quiet=quiet, tc_stats_record_interval=tc_stats_record_interval,
         disc_param_save_interval=disc_param_save_interval, disc_param_template=disc_param_template,
-        disc_param_save_on_error=disc_param_save_on_error, quit_JDS_threshold=quit_JDS_threshold)
+        disc_param_save_on_error=disc_param_save_on_error, quit_JDS_threshold=quit_JDS_threshold,
+        checkpoint_interval=checkpoint_interval, resume_from=resume_from)
     return dict(driver=driver, **rest)
 
 

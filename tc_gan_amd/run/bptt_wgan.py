@@ -74,6 +74,11 @@ def add_learning_options(parser):
     parser.add_argument('--disc-param-save-interval', default=5, type=int)
     parser.add_argument('--disc-param-template', default='last.npz')
     parser.add_argument('--disc-param-save-on-error', action='store_true')
+    parser.add_argument('--checkpoint-interval', default=-1, type=int,
+                        help='Write <datastore>/checkpoint.pkl (parameters, optimizer states, RNG states) every given '
+                             'generator step; -1 never (new)')
+    parser.add_argument('--resume-from', default=None,
+                        help='checkpoint.pkl of an earlier run to continue from: --iterations stays the TOTAL count (new)')
     parser.add_argument('--n_bandwidths', default=4, type=int, choices=(1, 4, 5, 8))
     parser.add_argument('--load-gen-param', help='generator.csv whose last row is the starting point.')
     execution.add_base_learning_options(parser)
@@ -89,7 +94,9 @@ def preprocess(run_config):
     run_config['bandwidths'] = _BANDWIDTHS[run_config.pop('n_bandwidths')]
     load_gen_param = run_config.pop('load_gen_param')
     if load_gen_param:
-        lastrow = np.loadtxt(load_gen_param, delimiter=',')[-1]
+        with open(load_gen_param) as f:                      # typed-table CSVs carry a header row, legacy ones do not
+            has_header = not f.readline().split(',', 1)[0].strip().lstrip('-').replace('.', '', 1).replace('e', '', 1).isdigit()
+        lastrow = np.atleast_2d(np.loadtxt(load_gen_param, delimiter=',', skiprows=int(has_header)))[-1]
         lastrow = lastrow[1:] if len(lastrow) == 13 else lastrow
         J0, D0, S0 = lastrow.reshape((3, 2, 2))
         run_config.update(J0=J0, D0=D0, S0=S0)

@@ -175,3 +175,43 @@ def test_heteroin_generator_update_vs_oracle(ssn_type, V0):
                                atol=1e-2 * np.abs(want_V - np.asarray(V0)).max() + 1e-9)
     want_J = np.clip(JDS['J'] - 0.01 * gJ.numpy(), 1e-3, 10)
     np.testing.assert_allclose(gan.gen.J - JDS['J'], want_J - JDS['J'], rtol=1e-2, atol=1e-2 * np.abs(want_J - JDS['J']).max())
+
+
+def test_checkpoint_resume_continues_the_same_run(tmp_path):
+    """Four generator steps in one go == two steps, checkpoint, a NEW GAN object restored from it, two more
+    (parameters, optimizer states and the shared host RandomState all travel)."""
+    from tc_gan_amd.networks.cwgan import make_gan
+    cfg = dict(TEST_PARAMS, critic_iters_init=3, critic_iters=2)
+    cfg['gen'] = dict(cfg['gen'], update_name='adam-wgan')
+    cfg['disc'] = dict(cfg['disc'], update_name='rmsprop', normalization=['none', 'layer'])
+
+    def run(gan, start, n_gen_steps):
+        it = gan.learning(start)
+        done, losses = 0, []
+        while done < n_gen_steps:
+            info = next(it)
+            if not info.is_discriminator:
+                done += 1
+                losses.append(info.gen_loss)
+        return losses
+
+    def fresh():
+        gan, _ = make_gan(cfg)
+        gan.set_dataset(_fake_data(gan, 9, np.random.RandomState(4)))
+        return gan
+
+    full = fresh()
+    losses_full = run(full, 0, 4)
+    first = fresh()
+    run(first, 0, 2)
+    path = str(tmp_path / 'checkpoint.pkl')
+    first.save_checkpoint(path, gen_step=1)
+    second = fresh()
+    start = second.load_checkpoint(path)
+    assert start == 2
+    losses_tail = run(second, start, 2)
+    np.testing.assert_allclose(losses_tail, losses_full[2:], rtol=1e-4, atol=1e-6)
+    for a, b in zip(second.get_gen_param(), full.get_gen_param()):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(second.disc.get_flat(), full.disc.get_flat(), rtol=1e-4, atol=1e-6)
+    assert second.disc_updater.step == full.disc_updater.step == 3 + 3 * 2

@@ -123,12 +123,17 @@ def test_moment_loss_gradient_kernel_vs_autograd():
 
 
 def _load_tables(directory, store):
+    """Typed tables of a run: store.hdf5 / <table>.hdf5 with h5py, <table>.csv without (structured arrays)."""
     path_h5 = os.path.join(directory, store + '.hdf5')
     if os.path.exists(path_h5):
         import h5py
         with h5py.File(path_h5, 'r') as f:
             return {k: f[k][...] for k in f}
-    return dict(np.load(os.path.join(directory, store + '.npz')))
+    names = ([store] if store != 'store' else
+             [n[:-4] for n in os.listdir(directory) if n.endswith('.csv') and n[:-4] in
+              ('learning', 'disc_learning', 'generator', 'disc_param_stats')])
+    return {n: np.genfromtxt(os.path.join(directory, n + '.csv'), delimiter=',', names=True, dtype=None, ndmin=1)
+            for n in names}
 
 
 @pytest.mark.gpu

@@ -11,12 +11,17 @@ pytestmark = pytest.mark.gpu
 
 
 def _load_tables(directory, store):
+    """Typed tables of a run: store.hdf5 / <table>.hdf5 with h5py, <table>.csv without (structured arrays)."""
     path_h5 = os.path.join(directory, store + '.hdf5')
     if os.path.exists(path_h5):
         import h5py
         with h5py.File(path_h5, 'r') as f:
             return {k: f[k][...] for k in f}
-    return dict(np.load(os.path.join(directory, store + '.npz')))
+    names = ([store] if store != 'store' else
+             [n[:-4] for n in os.listdir(directory) if n.endswith('.csv') and n[:-4] in
+              ('learning', 'disc_learning', 'generator', 'disc_param_stats')])
+    return {n: np.genfromtxt(os.path.join(directory, n + '.csv'), delimiter=',', names=True, dtype=None, ndmin=1)
+            for n in names}
 
 
 @pytest.mark.parametrize('args', [
@@ -73,3 +78,17 @@ def test_known_error_exit_code(tmp_path, monkeypatch):
                             '--dataset-provider', 'fixedtime'])
     assert code == 4
     assert json.load(open(tmp_path / 'results' / 'exit.json'))['reason'] == 'JDS_distance'
+
+
+def test_cli_checkpoint_and_resume(tmp_path, monkeypatch):
+    from tc_gan_amd.run import bptt_cwgan
+    monkeypatch.chdir(tmp_path)
+    common = ['--truth_size', '2', '--num-models', '2', '--n_bandwidths', '1', '--WGAN_n_critic0', '1', '--seqlen', '4',
+              '--skip-steps', '2', '--disc-layers', '[8]', '--quiet', '--dataset-provider', 'fixedtime']
+    bptt_cwgan.main(['--iterations', '2', '--datastore', 'first', '--checkpoint-interval', '1'] + common)
+    assert os.path.exists(tmp_path / 'first' / 'checkpoint.pkl')
+    bptt_cwgan.main(['--iterations', '4', '--datastore', 'second', '--resume-from', str(tmp_path / 'first' / 'checkpoint.pkl')]
+                    + common)
+    tables = _load_tables(str(tmp_path / 'second'), 'store')
+    assert list(tables['learning']['gen_step']) == [2, 3]
+    assert json.load(open(tmp_path / 'second' / 'exit.json'))['good']
