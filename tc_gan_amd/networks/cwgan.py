@@ -28,7 +28,7 @@ import torch
 from .. import clib
 from ..critic import Critic, Updater
 from ..gradient_expressions.utils import sample_sites_from_stim_space
-from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product
+from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product, to_device
 from .ssn import TuningCurveGenerator
 from .utils import gridify_tc_samples
 from .wgan import DEFAULT_PARAMS as _WGAN_DEFAULTS
@@ -269,57 +269,92 @@ class ConditionalBPTTWassersteinGAN(object):
         return self.gen.forward(rng=self.rng, save=save, model_rate_penalty_threshold=self.rate_penalty_threshold,
                                 **kw), local
 
-    def train_discriminator(self, info):
+    # A critic step is split in two so that the NEXT generator forward (which does not depend on the critic update)
+    # is already queued on the stream when the host blocks on this step's scalars: `_prepare_disc` draws from the
+    # host RNG (same order as the reference: minibatch, eps, zs) and launches the forward; `_finish_disc` runs the
+    # critic update and reads loss / accuracy / penalties back with ONE device-to-host copy.
+    def _prepare_disc(self):
         batch = self.next_minibatch()
         eps_full = self.rng.rand(batch.batchsize, 1)
         noise = self._draw_noise(batch)
         with self.gen_forward_watch:
             gen_out, local = self.gen_forward(batch, noise)
-            xg = gen_out.prober_tuning_curve
-            rate_penalty = self._mean_scalar(gen_out.model_rate_penalty)
-            dynamics_penalty = self._mean_scalar(gen_out.model_dynamics_penalty)
-        xd = torch.as_tensor(local.tuning_curves, device='cuda', dtype=torch.float32)
-        cd = torch.as_tensor(np.ascontiguousarray(local.conditions), device='cuda', dtype=torch.float32)
+        return Namespace(batch=batch, eps_full=eps_full, gen_out=gen_out, local=local,
+                         gen_time=self.gen_forward_watch.times[-1])
+
+    def _launch_disc(self, ctx):
+        """Queue the critic update of a prepared step (no host wait); the four scalars of the step go to pinned
+        host memory with an asynchronous copy followed by an event."""
+        gen_out, local = ctx.gen_out, ctx.local
+        xg = gen_out.prober_tuning_curve
+        pens = torch.stack([gen_out.model_rate_penalty.reshape(()).to(torch.float32),
+                            gen_out.model_dynamics_penalty.reshape(()).to(torch.float32)])
+        self.reducer.mean_(pens)
+        xd = to_device(local.tuning_curves, torch.float32)
+        cd = to_device(np.ascontiguousarray(local.conditions), torch.float32)
         per = local.batchsize
         r0 = self.reducer.rank * per if self.reducer.on else 0
-        eps = torch.as_tensor(eps_full[r0:r0 + per], device='cuda', dtype=torch.float32)
+        eps = to_device(ctx.eps_full[r0:r0 + per], torch.float32)
         xp = eps * xd + (1 - eps) * xg.to(torch.float32)                      # cwgan.py:481
-        info.gen_out = gen_out
-        info.dynamics_penalty = dynamics_penalty
-        info.rate_penalty = rate_penalty
-        info.xd, info.xg, info.xp = xd, xg, xp
-        info.cd = info.cg = info.cp = cd
-        info.batch = batch
-        info.gen_time = self.gen_forward_watch.times[-1]
-
+        ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
+        ctx.skipped = False
         bound = self.disc_rate_penalty_bound
-        if bound > 0 and rate_penalty > bound:                                   # cwgan.py:493-498
-            info.disc_loss = np.nan
-            info.accuracy = np.nan
-            info.disc_time = np.nan
-            return info
-
+        if bound > 0 and float(pens[0]) > bound:                                # cwgan.py:493-498 (needs the value now)
+            ctx.skipped = True
+            ctx.host = torch.cat([pens, pens.new_full((2,), float('nan'))]).cpu()
+            ctx.event = None
+            return
         with self.disc_train_watch:
             stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
             self.reducer.mean_(self.disc.grads, stats)
             self.disc_updater(self.disc.params, self.disc.grads)
-            info.disc_loss = float(stats[3])
         acc = torch.stack([self.disc.forward(xg, cd).mean() - self.disc.forward(xd, cd).mean()])
         self.reducer.mean_(acc)
-        info.accuracy = float(acc[0])
-        info.disc_time = self.disc_train_watch.times[-1]
+        ctx.host = torch.empty(4, dtype=torch.float32, pin_memory=True)
+        ctx.host.copy_(torch.cat([pens, stats[3:4].to(torch.float32), acc.to(torch.float32)]), non_blocking=True)
+        ctx.event = torch.cuda.Event()
+        ctx.event.record()
+        ctx.disc_time = self.disc_train_watch.times[-1]
+
+    def _read_disc(self, info, ctx):
+        """Wait for the scalars of a launched step (only for its own kernels: later launches are not waited for)."""
+        if ctx.event is not None:
+            ctx.event.synchronize()
+        host = ctx.host.numpy()
+        info.gen_out = ctx.gen_out
+        info.xd, info.xg, info.xp = ctx.xd, ctx.xg, ctx.xp
+        info.cd = info.cg = info.cp = ctx.cd
+        info.batch = ctx.batch
+        info.gen_time = ctx.gen_time
+        info.rate_penalty, info.dynamics_penalty = float(host[0]), float(host[1])
+        info.disc_loss, info.accuracy = float(host[2]), float(host[3])
+        info.disc_time = np.nan if ctx.skipped else ctx.disc_time
         return info
+
+    def _finish_disc(self, info, ctx):
+        self._launch_disc(ctx)
+        return self._read_disc(info, ctx)
+
+    def train_discriminator(self, info):
+        return self._finish_disc(info, self._prepare_disc())
 
     def _mean_scalar(self, t):
         t = t.reshape(1).to(torch.float32).clone()
         self.reducer.mean_(t)
         return float(t[0])
 
-    def train_generator(self, info, batch):
+    def _prepare_gen(self, batch):
+        """Noise draw + generator forward with the trajectory kept (independent of the critic: may be queued before
+        the last critic step of the iteration has finished)."""
         noise = self._draw_noise(batch)
         with self.gen_train_watch:
             gen_out, local = self.gen_forward(batch, noise, save=True)
-            cd = torch.as_tensor(np.ascontiguousarray(local.conditions), device='cuda', dtype=torch.float32)
+        return gen_out, local
+
+    def train_generator(self, info, batch, prepared=None):
+        gen_out, local = prepared if prepared is not None else self._prepare_gen(batch)
+        with self.gen_train_watch:
+            cd = to_device(np.ascontiguousarray(local.conditions), torch.float32)
             xg = gen_out.prober_tuning_curve.to(torch.float32)
             nb = xg.shape[0]
             gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
@@ -348,14 +383,24 @@ class ConditionalBPTTWassersteinGAN(object):
         self.gen_forward_watch = StopWatch()
         self.gen_train_watch = StopWatch()
         self.disc_train_watch = StopWatch()
+        ctx = self._prepare_disc() if critic_iters > 0 else None
+        prepared_gen = None
         for disc_step in range(critic_iters):
+            last = disc_step + 1 == critic_iters
+            # queue this step's critic update, THEN do the host work of the next step and queue its forward, and only
+            # then wait for this step's scalars: the GPU always has the next forward queued (host RNG order unchanged)
+            self._launch_disc(ctx)
+            nxt = None if last else self._prepare_disc()
+            if last:
+                prepared_gen = self._prepare_gen(ctx.batch)    # reuses the LAST critic batch's conditions (cwgan.py:535-539)
             info = Namespace(is_discriminator=True, gen_step=gen_step, disc_step=disc_step)
-            info = self.train_discriminator(info)
+            info = self._read_disc(info, ctx)
             yield info
+            ctx = nxt
         disc_info = info
         batch = info.batch
         info = Namespace(is_discriminator=False, gen_step=gen_step)
-        info = self.train_generator(info, batch)       # reuses the LAST critic batch's conditions (cwgan.py:535-539)
+        info = self.train_generator(info, batch, prepared_gen)
         logger.debug('[Loss] Acc: %-9.3g D: %-9.3g G: %-9.3g [Time] Fwd: %.3g D: %.3g G: %.3g',
                      disc_info.accuracy, disc_info.disc_loss, info.gen_loss, self.gen_forward_watch.mean(),
                      self.disc_train_watch.mean(), self.gen_train_watch.mean())

@@ -20,6 +20,7 @@ import torch
 from .. import clib, genops
 from ..gradient_expressions.utils import sample_sites_from_stim_space_impl
 from ..stimuli import stimulus_batch
+from ..utils import to_device
 from ..weight_gen import generate_weight_batch
 
 ssn_impl_choices = ('default',)
@@ -203,8 +204,8 @@ class TuningCurveGenerator(object):
             probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
                                                        self.num_sites, type='uint16').astype(np.int64) \
                 + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
-            ids = torch.as_tensor(np.asarray(prober_model_ids).astype(np.int64), device='cuda')
-            pr = torch.as_tensor(probes, device='cuda')
+            ids = to_device(np.asarray(prober_model_ids).astype(np.int64))
+            pr = to_device(probes)
             return time_avg[ids, :, pr], ids, pr                                       # cwgan.py:98
         pr = torch.as_tensor(self.probes, device='cuda')
         tc = time_avg[:, :, pr].reshape(time_avg.shape[0], -1)                         # ssn.py:846-848

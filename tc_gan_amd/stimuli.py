@@ -12,6 +12,7 @@ import numpy as np
 
 from . import clib
 from .clib import libssnode
+from .utils import to_device
 
 
 def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32', amp=None):
@@ -21,15 +22,15 @@ def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32'
     import torch
     clib.require_gpu()
     td = {'float32': torch.float32, 'float64': torch.float64}[str(np.dtype(dtype))]
-    bw = torch.as_tensor(bandwidths).to('cuda', td).contiguous()
-    con = torch.as_tensor(contrasts).to('cuda', td).contiguous()
+    bw = to_device(bandwidths, td).contiguous()
+    con = to_device(contrasts, td).contiguous()
     assert bw.shape == con.shape and bw.dim() == 2
     B, NB = bw.shape
     ext = torch.empty((B, NB, 2 * num_sites), device='cuda', dtype=td)
     fn, ct = ((libssnode.ssn_stimulus_amp_f32, ctypes.c_float) if td == torch.float32
               else (libssnode.ssn_stimulus_amp_f64, ctypes.c_double))
     if amp is not None:
-        amp = torch.as_tensor(amp).to('cuda', td).contiguous()
+        amp = to_device(amp, td).contiguous()
         assert amp.shape == (B, 2 * num_sites)
     clib.check(fn(bw.data_ptr(), con.data_ptr(), ct(smoothness), amp.data_ptr() if amp is not None else None,
                   ext.data_ptr(), int(B), int(NB), int(num_sites),

@@ -122,3 +122,17 @@ def csv_line(value_parser):
 
 def log_timing_message(name, seconds):
     return '{} done in {:.3g} sec'.format(name, seconds)
+
+
+def to_device(x, dtype=None):
+    """Host array -> CUDA tensor through pinned staging memory and an ASYNCHRONOUS copy, so that the host does
+    not wait for the kernels already queued on the stream (a pageable-memory copy does); CUDA tensors pass through."""
+    import torch
+    if torch.is_tensor(x) and x.is_cuda:
+        return x if dtype is None else x.to(dtype)
+    t = x if torch.is_tensor(x) else torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    if t.numel() == 0:
+        return t.to('cuda')
+    return t.contiguous().pin_memory().to('cuda', non_blocking=True)
