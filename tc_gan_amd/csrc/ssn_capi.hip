@@ -203,6 +203,17 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
     a.B = B; a.NB = NB; a.M = M; a.seqlen = g->seqlen; a.skip = g->skip_steps;
     a.eps_E = (T)(g->dt / g->tau_E); a.eps_I = (T)(g->dt / g->tau_I); a.theta = (T)g->rate_penalty_threshold;
     a.c_dyn = (T)c_dyn; a.c_rate = (T)c_rate;
+    if constexpr (sizeof(T) == 4) {
+        const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (long)NB * g->seqlen * M < (1L << 29);
+        if (g->kernel == 2 && !mfma_ok) {
+            g_last_error = "ssn_gen_backward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
+            return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+        }
+        if (g->kernel == 2 || (g->kernel == 0 && mfma_ok && (long)B * ((NB + 7) / 8) >= 192)) {
+            SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
+            return 0;
+        }
+    }
     SSN_TRY(ssn::launch_gen_backward<T>(a, (hipStream_t)stream));
     return 0;
 }

@@ -112,10 +112,35 @@ struct IoSelect {
     }
 };
 
+// acc[v] = sum_k wr[k] * x[k] for the lane's stimulus row `xs` (LDS), four interleaved partial chains.  The order
+// [read quad q + DEPTH][4 MFMAs of quad q] is pinned with data dependencies (empty asm on the LDS address and the
+// accumulators): left alone, the compiler emits read - wait - use per quad.
+template <int MK>
+__device__ __forceinline__ mf4 slab_chain(const float (&wr)[MK], const float* xs) {
+    constexpr int NQ = MK / 4, DEPTH = 4;         // B-operand reads run DEPTH quads (16 MFMAs) ahead of their use
+    using LdsV4 = const __attribute__((address_space(3))) mf4*;
+    using LdsF = const __attribute__((address_space(3))) float*;
+    unsigned xa = (unsigned)(size_t)(LdsF)xs;
+    mf4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    mf4 bq[NQ];
+#pragma unroll
+    for (int q = 0; q < DEPTH; ++q) bq[q] = *(LdsV4)(size_t)(xa + 16u * q);
+    asm volatile("" : "+v"(xa));
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + DEPTH < NQ) bq[q + DEPTH] = *(LdsV4)(size_t)(xa + 16u * (q + DEPTH));
+        a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q], bq[q].x, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 1], bq[q].y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 2], bq[q].z, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 3], bq[q].w, a3, 0, 0, 0);
+        asm volatile("" : "+v"(xa), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));     // VGPR ties: no AGPR split of the file
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+
 template <int MK, bool SAVE>
 __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<float> a) {
     constexpr int RS = MK + 4;                    // LDS row stride: the 4 stimuli of a group on disjoint banks
-    constexpr int NQ = MK / 4, DEPTH = 4;         // B-operand reads run DEPTH quads (16 MFMAs) ahead of their use
     __shared__ __align__(16) float rbuf[2][8][RS];
     __shared__ __align__(16) float abuf[2][4][64][4];   // accumulator hand-off: [group][matrix wave][lane]
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
@@ -132,31 +157,11 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
         // ================================ matrix wave ================================
         float wr[MK];
         slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
-        using LdsV4 = const __attribute__((address_space(3))) mf4*;
-        using LdsF = const __attribute__((address_space(3))) float*;
         __syncthreads();
         for (int p = 0; p < nphase; ++p) {
             if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
                 const int g = p & 1, it = p >> 1;
-                // acc[v] = sum_k wr[k] * x[stimulus 4 g + j][k].  The order [read quad q + DEPTH][4 MFMAs of quad q] is
-                // pinned with data dependencies (empty asm on the LDS address and the accumulators): left alone, the
-                // compiler emits read - wait - use per quad.
-                unsigned xa = (unsigned)(size_t)(LdsF)&rbuf[it & 1][4 * g + j][0];
-                mf4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-                mf4 bq[NQ];
-#pragma unroll
-                for (int q = 0; q < DEPTH; ++q) bq[q] = *(LdsV4)(size_t)(xa + 16u * q);
-                asm volatile("" : "+v"(xa));
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (q + DEPTH < NQ) bq[q + DEPTH] = *(LdsV4)(size_t)(xa + 16u * (q + DEPTH));
-                    a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q], bq[q].x, a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 1], bq[q].y, a1, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 2], bq[q].z, a2, 0, 0, 0);
-                    a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[4 * q + 3], bq[q].w, a3, 0, 0, 0);
-                    asm volatile("" : "+v"(xa), "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
-                }
-                *reinterpret_cast<mf4*>(&abuf[g][wave][lane][0]) = (a0 + a1) + (a2 + a3);
+                *reinterpret_cast<mf4*>(&abuf[g][wave][lane][0]) = slab_chain<MK>(wr, &rbuf[it & 1][4 * g + j][0]);
             }
             __syncthreads();
         }
@@ -202,7 +207,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
         float uu[4], ff[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) uu[v] = accs[v] + ex[g][v];
-        io.template eval4<SAVE>(uu, ff, dfn);
+        if (SSN_MFMA_ABLATE & 4) { for (int v = 0; v < 4; ++v) ff[v] = uu[v] * 0.5f; } else io.template eval4<SAVE>(uu, ff, dfn);
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const float f = ff[v];
@@ -259,6 +264,148 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     }
 }
 
+// Reverse-time adjoint sweep (same recurrence as gen_backward_kernel, ssn_gen.hip) in the specialised MFMA form:
+// the matrix waves hold the slabs of W^T and compute W^T delta_tau, the serial waves own the adjoint state.
+// Per group: serial(tau) [a_tau = g_tau + carry; delta_tau = eps f'(u_tau) a_tau -> LDS, HBM] -> matrix(tau) ->
+// serial(tau - 1) [carry = (1 - eps) a_tau + W^T delta_tau] ...; group 0 serial phases are the even ones, group 1 the
+// odd ones, the matrix waves serve the other group in every phase.
+template <int MK>
+__global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<float> a) {
+    constexpr int RS = MK + 4;
+    __shared__ __align__(16) float dbuf[8][RS];          // delta_tau per stimulus, contiguous in the neuron index
+    __shared__ __align__(16) float abuf[2][4][64][4];
+    const int M = a.M, N = a.M / 2, T_ = a.seqlen;
+    const int ngroups = (a.NB + 7) / 8;
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (int)(blockDim.x >> 7);
+    const int blk = lane >> 2, j = lane & 3;
+    const int nphase = 2 * T_;
+    for (int c = threadIdx.x; c < 8 * RS; c += blockDim.x) (&dbuf[0][0])[c] = 0.f;
+
+    if (wave < wm) {
+        float wr[MK];
+        slab_load<MK, true>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
+        __syncthreads();
+        for (int p = 0; p < nphase; ++p) {
+            if (p >= 1) {
+                const int g = (p - 1) & 1;
+                *reinterpret_cast<mf4*>(&abuf[g][wave][lane][0]) = slab_chain<MK>(wr, &dbuf[4 * g + j][0]);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    const int sw = wave - wm;
+    const int er = 64 * sw + 4 * blk;
+    const float inv = 1.f / (float)(T_ - a.skip);
+    float eps[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) eps[v] = (er + v < N) ? a.eps_E : a.eps_I;
+    // trajectory / delta streams of this draw through raw buffers (out-of-range offsets read 0 / are dropped)
+    const size_t blk_elems = (size_t)a.NB * T_ * M;
+    const __amdgpu_buffer_rsrc_t rs_traj =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.traj) + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dlt =
+        __builtin_amdgcn_make_buffer_rsrc(a.delta + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    const bool quad = er + 3 < M;                 // whole quad of rows inside the matrix (always when M % 4 == 0)
+    bool live[2];
+    int toff[2];
+    float gta[2][4], carry[2][4], xn[2][4], xc[2][4], xm[2][4], dfc[2][4], dsum[2][4];
+    float pxm[2][4], pdf[2][4];                   // loads in flight for the END of the group's next serial part
+    auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float (&out)[4]) {
+        if (quad) {
+            const mf4 q = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                out[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (off < 0 || er + v >= M) ? -1 : off + 4 * v, 0, 0));
+        }
+    };
+    auto store4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, const float (&val)[4]) {
+        if (quad) {
+            const mf4 q = {val[0], val[1], val[2], val[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(4))), q), rs, off, 0, 0);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[v]), rs, (off < 0 || er + v >= M) ? -1 : off + 4 * v, 0, 0);
+        }
+    };
+    auto at_step = [&](int g, int t) { return toff[g] < 0 ? -1 : toff[g] + t * M * 4; };   // byte offset of index t
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB;
+        toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
+        const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            gta[g][v] = (live[g] && er + v < M) ? a.g_time_avg[((size_t)b * a.NB + s) * M + er + v] * inv : 0.f;
+            carry[g][v] = dsum[g][v] = xn[g][v] = 0.f;
+        }
+        load4(rs_traj, at_step(g, T_ - 1), xc[g]);                                   // x_T
+        if (T_ >= 2) load4(rs_traj, at_step(g, T_ - 2), xm[g]); else { for (int v = 0; v < 4; ++v) xm[g][v] = 0.f; }
+        load4(rs_dlt, at_step(g, T_ - 1), dfc[g]);                                   // f'(u_T)
+        store4(rs_dlt, at_step(g, T_ - 1), zero4);                                   // slot T-1 of the shifted delta stays zero
+        // what serial(T) hands over at its end: x_{T-2} and f'(u_{T-1})
+        if (T_ >= 3) load4(rs_traj, at_step(g, T_ - 3), pxm[g]); else { for (int v = 0; v < 4; ++v) pxm[g][v] = 0.f; }
+        if (T_ >= 2) load4(rs_dlt, at_step(g, T_ - 2), pdf[g]); else { for (int v = 0; v < 4; ++v) pdf[g][v] = 0.f; }
+    }
+    // serial part of (group g, step tau): first = no matrix result yet (tau == T)
+    auto serial = [&](auto G, int tau) {
+        constexpr int g = decltype(G)::value;
+        // HBM reads run TWO serial parts ahead (a serial part is too short to cover their latency): issued here,
+        // consumed at the end of serial(tau - 1); what this call consumes was issued by serial(tau + 1)
+        float nxm[4] = {0.f, 0.f, 0.f, 0.f}, ndf[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tau >= 4) load4(rs_traj, at_step(g, tau - 4), nxm);
+        if (tau >= 3) load4(rs_dlt, at_step(g, tau - 3), ndf);
+        if (tau < T_) {
+            const mf4 acc = *reinterpret_cast<const mf4*>(&abuf[g][sw][lane][0]);     // W^T delta_{tau+1}
+            carry[g][0] += acc.x; carry[g][1] += acc.y; carry[g][2] += acc.z; carry[g][3] += acc.w;
+        }
+        float delta[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float gg = 0.f;                      // direct gradient of the loss w.r.t. x_tau (window: tau >= skip + 1)
+            if (tau >= a.skip + 1) {
+                gg = gta[g][v] + ((xc[g][v] > a.theta) ? a.c_rate : 0.f);
+                if (tau <= T_ - 1) gg -= 2.f * a.c_dyn * (xn[g][v] - xc[g][v]);
+                if (tau >= a.skip + 2) gg += 2.f * a.c_dyn * (xc[g][v] - xm[g][v]);
+            }
+            const float at = gg + carry[g][v];
+            delta[v] = (er + v < M) ? eps[v] * dfc[g][v] * at : 0.f;
+            carry[g][v] = fmaf(-eps[v], at, at);                                       // (1 - eps) a_t
+            dsum[g][v] += delta[v];
+            xn[g][v] = xc[g][v]; xc[g][v] = xm[g][v]; xm[g][v] = pxm[g][v]; dfc[g][v] = pdf[g][v];
+            pxm[g][v] = nxm[v]; pdf[g][v] = ndf[v];
+        }
+        if (live[g] && er < M) *reinterpret_cast<mf4*>(&dbuf[4 * g + j][er]) = (mf4){delta[0], delta[1], delta[2], delta[3]};
+        if (tau >= 2) store4(rs_dlt, at_step(g, tau - 2), delta);                      // shifted: pairs with x_{tau-1}
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+    __syncthreads();
+    for (int i = 0; i < T_; ++i) {
+        serial(G0, T_ - i);                           // phase 2 i
+        __syncthreads();
+        serial(G1, T_ - i);                           // phase 2 i + 1
+        __syncthreads();
+    }
+    if (a.g_ext) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (!live[g]) continue;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (er + v < M) a.g_ext[((size_t)b * a.NB + s0 + 4 * g + j) * M + er + v] = dsum[g][v];
+        }
+    }
+}
+
 static int mfma_pick_mk(int M) {
     const int ladder[] = {104, 152, 200, 208};
     for (int mk : ladder) if (M <= mk) return mk;
@@ -280,6 +427,23 @@ hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st) {
         case 152: return launch_fwd_mk<152>(a, st);
         case 200: return launch_fwd_mk<200>(a, st);
         case 208: return launch_fwd_mk<208>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MK>
+static hipError_t launch_bwd_mk(const GenBwdArgs<float>& a, hipStream_t st) {
+    const int waves = (a.M + 63) / 64;
+    const int ngroups = (a.NB + 7) / 8;
+    hipLaunchKernelGGL((gen_backward_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st) {
+    switch (mfma_pick_mk(a.M)) {
+        case 104: return launch_bwd_mk<104>(a, st);
+        case 152: return launch_bwd_mk<152>(a, st);
+        case 200: return launch_bwd_mk<200>(a, st);
+        case 208: return launch_bwd_mk<208>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -50,9 +50,12 @@ def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
 
 
 @pytest.mark.parametrize('io_type', ['asym_tanh', 'asym_power'])
-@pytest.mark.parametrize('N,B,NB,dtype', [(6, 3, 3, 'float64'), (20, 2, 8, 'float64'), (50, 2, 2, 'float32'),
-                                           (100, 2, 2, 'float32')])
-def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype):
+@pytest.mark.parametrize('N,B,NB,dtype,kernel', [
+    (6, 3, 3, 'float64', 0), (20, 2, 8, 'float64', 0), (50, 2, 2, 'float32', 0), (100, 2, 2, 'float32', 0),
+    # fp32 with NB >= 4: MFMA forward + adjoint kernels (2), tile kernels (1)
+    (100, 1, 8, 'float32', 2), (100, 1, 8, 'float32', 1), (50, 2, 5, 'float32', 2), (101, 1, 4, 'float32', 2),
+    (20, 2, 9, 'float32', 2)])
+def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype, kernel):
     """dL/dJ, dL/dD, dL/dS for L = sum(G * time_avg) + c_d * dyn_pen + c_r * rate_pen."""
     from tc_gan_amd import genops, stimuli, weight_gen
     T, skip, theta = 50, 30, 1.0
@@ -72,7 +75,7 @@ def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype):
     zt = torch.as_tensor(z).to('cuda', getattr(torch, dtype))
     W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], zt, dtype=dtype)
     ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype=dtype)
-    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, **gen)
+    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, kernel=kernel, **gen)
     out = genops.gen_forward(W, ext, gp, save=True)
     Gd = torch.as_tensor(G).to('cuda', getattr(torch, dtype))
     delta = genops.gen_backward(W, out['traj'], out['df'], Gd, dyn_cost / out['n_dyn'], rate_cost / out['n_rate'], gp)
