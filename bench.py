@@ -178,6 +178,10 @@ def run_c3(args, rank, world, local_rank, paper=False):
     units = float(M) * models * NB * T                     # neuron-steps of one generator forward (per rank)
     achieved = units * (2 * M + 8) / (kernel_ms * 1e-3) * 1e-12
     iters_per_s = args.steps / elapsed
+    traffic = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'hbm_traffic.json')
+    if not paper and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get('c3')
     out = {
         'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '%d-model GAN iterations/s' % models,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -189,8 +193,10 @@ def run_c3(args, rank, world, local_rank, paper=False):
                                'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
                                '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
                                'device-side z (Philox)', 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
-        'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': None, 'kernel': 'gen_forward_kernel',
+        # fp32-input MFMA (v_mfma_f32_4x4x1) peak = fp32 vector peak = 157.3 TFLOP/s (MI355X_MICROARCH.md)
+        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
+                     'kernel': 'gen_forward_mfma_kernel (fp32 MFMA)' if not paper else 'gen_forward_kernel (tile, VALU)',
                      'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8,
                      'ssn_steps_per_s_in_loop': 7 * units * iters_per_s * world},
         'last_gen_loss': info.gen_loss,
