@@ -215,3 +215,56 @@ def test_checkpoint_resume_continues_the_same_run(tmp_path):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(second.disc.get_flat(), full.disc.get_flat(), rtol=1e-4, atol=1e-6)
     assert second.disc_updater.step == full.disc_updater.step == 3 + 3 * 2
+
+
+@pytest.mark.parametrize('truth_size,probes_per_model,norm_probes,inhibitory', [
+    (1, 1, [0], False), (1, 1, [0], True), (8, 2, [0, 0.5], False), (8, 2, [0], True), (8, 2, [0, 0.5], True)])
+def test_conditional_tuning_curves_vs_fixed_point_dataset(truth_size, probes_per_model, norm_probes, inhibitory):
+    """networks/tests/test_conditional_tuning_curve.py:141-204: the dataset comes from the fixed-point solver
+    (`ssnode.sample_tuning_curves`, fp64, atol 1e-10); feeding the z of the sampled draws to the fp32 fixed-time
+    generator (seqlen 4000, skip = seqlen - 1) through the `RandomChoiceSampler` minibatch must reproduce the
+    dataset's tuning curves and the solver's fixed points (reference tolerance 5e-4)."""
+    from tc_gan_amd import ssnode
+    from tc_gan_amd.networks.cwgan import RandomChoiceSampler, make_gan
+    from tc_gan_amd.gradient_expressions.utils import sample_sites_from_stim_space
+    N, seqlen = 20, 4000
+    bandwidths, contrasts = [0.0625, 0.25, 0.75], [5.]     # one contrast, as in the reference test (20 saturates an I
+    # cell at N = 20, whose fixed point the fixed-time run approaches too slowly)
+    cfg = dict(TEST_PARAMS, num_sites=N, seqlen=seqlen, skip_steps=seqlen - 1, num_models=truth_size,
+               probes_per_model=probes_per_model, norm_probes=norm_probes, include_inhibitory_neurons=inhibitory,
+               bandwidths=bandwidths, contrasts=contrasts, include_time_avg=True)
+    gan, _ = make_gan(cfg)
+    data, (zs, rates, fpinfo) = ssnode.sample_tuning_curves(
+        sample_sites=sample_sites_from_stim_space(norm_probes, N), NZ=truth_size, seed=1, bandwidths=bandwidths,
+        contrast=contrasts, N=N, track_offset_identity=True, include_inhibitory_neurons=inhibitory,
+        J=JDS['J'], D=JDS['D'], S=JDS['S'], io_type='asym_tanh', atol=1e-10, dt=5e-4, max_iter=400000)
+    data = np.array(data.T)
+    zs, rates = np.asarray(zs), np.asarray(rates)
+    assert fpinfo.rejections == 0 and zs.shape == (truth_size, 2 * N, 2 * N)
+    kw = dict(bandwidths=bandwidths, contrasts=contrasts, norm_probes=norm_probes, e_ratio=gan.e_ratio,
+              include_inhibitory_neurons=inhibitory)
+    sampler = RandomChoiceSampler.from_grid_data(data, seed=np.random.RandomState(3), **kw)
+    # the same draws on an "index dataset" tell which truth sample every minibatch row came from
+    index_data = np.broadcast_to(np.arange(truth_size, dtype='float64')[:, None], data.shape)
+    id_sampler = RandomChoiceSampler.from_grid_data(index_data, seed=np.random.RandomState(3), **kw)
+    batch = sampler.select_minibatch(truth_size, probes_per_model)
+    ids = id_sampler.select_minibatch(truth_size, probes_per_model).tc_md[:, :, 0].astype(int)
+    used = sorted(set(ids.flat))
+    padded = np.zeros(truth_size, dtype=int)          # num_models >= number of distinct samples ([1] in the reference test)
+    padded[:len(used)] = used
+    gen_kwargs = batch.gen_kwargs
+    gen_kwargs['prober_model_ids'] = np.array([used.index(i) for i in ids.flatten()], dtype='uint16')
+    # every model has to see the contrast of ITS rows: rows of a model share one contrast, but the squeezed models do not
+    row_contrast = batch.conditions[:, 0]
+    con = np.full(truth_size, contrasts[0])
+    con[gen_kwargs['prober_model_ids']] = row_contrast
+    gen_kwargs['stimulator_contrasts'] = np.broadcast_to(con[:, None], (truth_size, len(bandwidths))).astype('float32')
+    out = gan.gen.forward(model_zs=zs[padded], model_rate_penalty_threshold=200., **gen_kwargs)
+    xg = out.prober_tuning_curve.cpu().numpy()
+    np.testing.assert_allclose(xg, batch.tuning_curves, rtol=5e-4, atol=5e-4)
+    # time_avg (models, stimuli = this model's contrast x bandwidths, neurons) vs the solver's fixed points
+    ta = out.model_time_avg.cpu().numpy()
+    fp = rates.reshape(truth_size, len(contrasts), len(bandwidths), 2 * N)
+    for m in set(gen_kwargs['prober_model_ids']):
+        ci = contrasts.index(float(con[m]))
+        np.testing.assert_allclose(ta[m], fp[padded[m], ci], rtol=5e-4, atol=5e-4)
