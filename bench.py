@@ -268,7 +268,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c3paper', 'c5'])
     ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 tile (library picks the shape), '
-                    '3 tile/split residency, 4 tile/all-register')
+                    '3 tile/split residency, 4 tile/all-register, 5 fp32 MFMA (NB >= 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
     args = ap.parse_args()
@@ -383,7 +383,7 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': desc + ', asym_tanh, atol=0, fp32, W rebuilt from resident z each step',
                    'neurons': M, 'batch_per_gpu': B, 'stimuli_per_draw': NB, 'euler_steps': T,
-                   'kernel': {4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
+                   'kernel': {5: 'solve_mfma_kernel', 4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
                    'parallelism': 'draws sharded over %d GPU(s), no data-path collective' % world},
         'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,

@@ -38,17 +38,23 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     a.st = ssn::make_step_consts<T>(*p);
     hipStream_t st = (hipStream_t)stream;
     // variant: -1 auto (tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
-    // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs
+    // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs,
+    // 5 fp32 MFMA kernel (NB >= 4)
     const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
-    if ((variant == 1 && !regw_ok) || (variant >= 2 && !tile_ok) || variant > 4) {
+    bool mfma_ok = false;
+    if constexpr (sizeof(T) == 4) mfma_ok = ssn::gen_mfma_supported(M, NB);
+    if ((variant == 1 && !regw_ok) || (variant >= 2 && variant <= 4 && !tile_ok) || (variant == 5 && !mfma_ok) || variant > 5) {
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
+    // auto never picks the MFMA solver (variant 5): with the per-stimulus stop protocol on top it measures 108 ms
+    // at the C2/NB=8 shape against 85 ms for the split tile kernel (the fixed-time generator, without it, wins)
     if (variant < 0) variant = tile_ok ? 2 : (regw_ok ? 1 : 0);
     switch (variant) {
         case 2: SSN_TRY(ssn::launch_tile<T>(a, st, 0)); break;
         case 3: SSN_TRY(ssn::launch_tile<T>(a, st, 1)); break;
         case 4: SSN_TRY(ssn::launch_tile<T>(a, st, 2)); break;
+        case 5: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_mfma(a, st)); } break;
         case 1: SSN_TRY(ssn::launch_regw<T>(a, st)); break;
         default: SSN_TRY(ssn::launch_stream<T>(a, st)); break;
     }

@@ -65,6 +65,7 @@ template <typename T> hipError_t launch_ss_system(const T* R, const T* W, const 
 bool gen_mfma_supported(int M, int NB);
 hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st);
 hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st);
+hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st);
 
 // ssn_gen.hip
 template <typename T> bool gen_supported(int M);

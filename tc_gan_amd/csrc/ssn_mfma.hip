@@ -406,6 +406,157 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
     }
 }
 
+// Fixed-point solver (Euler loop of tc_gan/ext/ssnode.c:69-187, contract of solve_tile_kernel) in the specialised MFMA
+// form, for NB >= 4 stimuli per draw.  Serial part of (group g, step it): r1 = r + (-r + f(W r + ext)) eps, the two
+// stop tests, freeze per stimulus.  Stop protocol: the flags of (g, it) (one word per stimulus: low half "some row not
+// converged", high half "some row hit the rate bound"; three rotating slots) are complete after the barrier of the
+// phase in which serial(g, it) ran; in the NEXT phase EVERY wave reads them and updates the same frozen mask / codes /
+// step counts, so matrix and serial waves leave the loop in the same phase.
+template <int MK>
+__global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) {
+    constexpr int RS = MK + 4;
+    __shared__ __align__(16) float rbuf[2][8][RS];
+    __shared__ __align__(16) float abuf[2][4][64][4];
+    __shared__ __align__(16) int flags[3][8];
+    const int M = a.M, N = a.N, max_iter = a.st.max_iter;
+    const int ngroups = (a.NB + 7) / 8;
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (int)(blockDim.x >> 7);
+    const int blk = lane >> 2, j = lane & 3;
+    const bool matrix = wave < wm;
+    const int sw = wave - wm;
+    const int er = 64 * (matrix ? wave : sw) + 4 * blk;
+
+    for (int c = threadIdx.x; c < 2 * 8 * RS; c += blockDim.x) (&rbuf[0][0][0])[c] = 0.f;
+    if (threadIdx.x < 24) (&flags[0][0])[threadIdx.x] = 0;
+    __syncthreads();
+
+    // ---- uniform bookkeeping, identical in every wave -------------------------------------------------
+    unsigned frozen = 0;                           // bit s: stimulus s0 + s has stopped (or does not exist)
+    int code[8], nsteps[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        code[s] = 1; nsteps[s] = max_iter;
+        if (s0 + s >= a.NB) frozen |= 1u << s;
+    }
+    auto verdict = [&](auto G, int it) {           // flags of (group G, step it) -> frozen / code / nsteps
+        constexpr int g = decltype(G)::value;
+        const int4 f4 = *reinterpret_cast<const int4*>(&flags[it % 3][4 * g]);
+        const int f[4] = {__builtin_amdgcn_readfirstlane(f4.x), __builtin_amdgcn_readfirstlane(f4.y),
+                          __builtin_amdgcn_readfirstlane(f4.z), __builtin_amdgcn_readfirstlane(f4.w)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * g + q;
+            const bool fnc = f[q] & 0xffff, fhb = f[q] >> 16;
+            if (!((frozen >> s) & 1u) && (!fnc || fhb)) {
+                code[s] = fnc ? 2 : 0;
+                nsteps[s] = it + 1;
+                frozen |= 1u << s;
+            }
+        }
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+
+    // The two roles run the SAME phase structure (same barriers, same exits) in separate loops, so that the
+    // registers of one role (200 for the slab) are not live in the other.
+    if (matrix) {
+        float wr[MK];
+        slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
+        __syncthreads();
+        for (int it = 0; it <= max_iter; ++it) {
+            if (it >= 1) verdict(G0, it - 1);                                   // phase 2 it
+            if (frozen == 0xffu) break;
+            if (it < max_iter) *reinterpret_cast<mf4*>(&abuf[0][wave][lane][0]) = slab_chain<MK>(wr, &rbuf[it & 1][j][0]);
+            __syncthreads();
+            if (it >= 1) verdict(G1, it - 1);                                   // phase 2 it + 1
+            if (frozen == 0xffu) break;
+            if (it < max_iter) *reinterpret_cast<mf4*>(&abuf[1][wave][lane][0]) = slab_chain<MK>(wr, &rbuf[it & 1][4 + j][0]);
+            __syncthreads();
+        }
+        return;
+    }
+
+    float eps[4], rc[2][4], rp[2][4], ex[2][4];
+    bool live[2];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) eps[v] = (er + v < N) ? a.st.eps_E : a.st.eps_I;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB;
+        const size_t vec = ((size_t)b * a.NB + (live[g] ? s : 0)) * M;
+        float r4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool ok = live[g] && er + v < M;
+            rc[g][v] = rp[g][v] = r4[v] = ok ? a.r[vec + er + v] : 0.f;
+            ex[g][v] = ok ? a.ext[(a.ext_per_draw ? vec : (size_t)s * M) + er + v] : 0.f;
+        }
+        if (live[g] && er < M) *reinterpret_cast<mf4*>(&rbuf[0][4 * g + j][er]) = (mf4){r4[0], r4[1], r4[2], r4[3]};
+    }
+    const IoSelect io(a.io);
+    auto serial = [&](auto G, int it) {            // serial part of (group G, step it)
+        constexpr int g = decltype(G)::value;
+        const mf4 acc = *reinterpret_cast<const mf4*>(&abuf[g][sw][lane][0]);
+        const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
+        const bool upd = live[g] && !((frozen >> (4 * g + j)) & 1u);
+        float uu[4], ff[4], dummy[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uu[v] = accs[v] + ex[g][v];
+        io.template eval4<false>(uu, ff, dummy);
+        bool nc = false, hb = false;
+        float rnew[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float r1 = rc[g][v] + (-rc[g][v] + ff[v]) * eps[v];          // ssnode.c:64-67
+            const bool row = upd && er + v < M;
+            nc = nc || (row && fabsf(r1 - rc[g][v]) >= a.st.atol);
+            hb = hb || (row && a.st.check_hard && r1 >= a.st.hard_stop);
+            rp[g][v] = row ? rc[g][v] : rp[g][v];
+            rc[g][v] = row ? r1 : rc[g][v];
+            rnew[v] = (er + v < M) ? rc[g][v] : 0.f;
+        }
+        short* fw = reinterpret_cast<short*>(&flags[it % 3][4 * g + j]);
+        if (nc) fw[0] = 1;
+        if (hb) fw[1] = 1;
+        if (upd && er < M) *reinterpret_cast<mf4*>(&rbuf[(it + 1) & 1][4 * g + j][er]) = (mf4){rnew[0], rnew[1], rnew[2], rnew[3]};
+        if (sw == 0 && lane < 4) flags[(it + 1) % 3][4 * g + lane] = 0;
+    };
+    __syncthreads();
+    for (int it = 0; it <= max_iter; ++it) {
+        if (it >= 1) verdict(G0, it - 1);                                       // phase 2 it: serial part of (1, it - 1)
+        if (frozen == 0xffu) break;
+        if (it >= 1) serial(G1, it - 1);
+        __syncthreads();
+        if (it >= 1) verdict(G1, it - 1);                                       // phase 2 it + 1: serial part of (0, it)
+        if (frozen == 0xffu) break;
+        if (it < max_iter) serial(G0, it);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!live[g]) continue;
+        const int s = 4 * g + j;
+        const size_t unit = (size_t)b * a.NB + s0 + s;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (er + v >= M) continue;
+            a.r[unit * M + er + v] = rc[g][v];
+            if (a.r_prev) a.r_prev[unit * M + er + v] = rp[g][v];
+        }
+        if (sw == 0 && blk == 0) {
+            int c = 1, n = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q == s) { c = code[q]; n = nsteps[q]; }
+            a.codes[unit] = c;
+            if (a.steps) a.steps[unit] = n;
+        }
+    }
+}
+
 static int mfma_pick_mk(int M) {
     const int ladder[] = {104, 152, 200, 208};
     for (int mk : ladder) if (M <= mk) return mk;
@@ -444,6 +595,23 @@ hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st) 
         case 152: return launch_bwd_mk<152>(a, st);
         case 200: return launch_bwd_mk<200>(a, st);
         case 208: return launch_bwd_mk<208>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MK>
+static hipError_t launch_solve_mk(const SolveArgs<float>& a, hipStream_t st) {
+    const int waves = (a.M + 63) / 64;
+    const int ngroups = (a.NB + 7) / 8;
+    hipLaunchKernelGGL((solve_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st) {
+    switch (mfma_pick_mk(a.M)) {
+        case 104: return launch_solve_mk<104>(a, st);
+        case 152: return launch_solve_mk<152>(a, st);
+        case 200: return launch_solve_mk<200>(a, st);
+        case 208: return launch_solve_mk<208>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -133,6 +133,9 @@ def test_test_inf_message():
     (100, 1, 3, 'float32'), (100, 8, 3, 'float32'), (102, 3, 3, 'float32'), (50, 8, 3, 'float32'),
     (75, 2, 3, 'float32'), (16, 5, 3, 'float32'), (1, 1, 3, 'float32'), (100, 1, 4, 'float32'), (100, 2, 4, 'float32'),
     (76, 1, 3, 'float32'), (76, 3, 4, 'float32'), (90, 3, 3, 'float32'),
+    # variant 5: fp32 MFMA kernel (NB >= 4: matrix + serial waves, two stimulus groups half a step apart)
+    (100, 8, 5, 'float32'), (100, 4, 5, 'float32'), (50, 5, 5, 'float32'), (101, 9, 5, 'float32'), (16, 11, 5, 'float32'),
+    (76, 8, 5, 'float32'),
 ])
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
@@ -150,7 +153,7 @@ def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
 
 
 @pytest.mark.parametrize('dtype,variant', [('float64', 0), ('float64', 1), ('float64', 2), ('float32', 1),
-                                           ('float32', 2), ('float32', 0), ('float32', 3), ('float32', 4)])
+                                           ('float32', 2), ('float32', 0), ('float32', 3), ('float32', 4), ('float32', 5)])
 def test_converging_batch_codes_steps_states(oracle_lib, dtype, variant):
     """Default solver settings (atol 1e-5, dt 8e-4): per-pair convergence step and state."""
     from tc_gan_amd.ssnode import fixed_points_batch
