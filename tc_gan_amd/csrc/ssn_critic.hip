@@ -69,24 +69,43 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
 
     const int kbeg = blockIdx.z * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        // ---- stage op(A)[m0:m0+64][k0:k0+BK] and op(B)[k0:k0+BK][n0:n0+64] ----------------
-        for (int e = tid; e < BM * BK; e += 256) {
+    // Each thread stages EPT elements of op(A) and of op(B) per K tile.  The global loads of tile k+1 are issued
+    // into registers before the MFMAs of tile k (software pipelining): these GEMMs are small (a handful of
+    // workgroups per CU at best), so an exposed load latency per K step was most of their run time.
+    constexpr int EPT = BM * BK / 256;
+    float ra[EPT], rb[EPT];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * 256;
             // make the index that is contiguous in memory the fastest-varying one
             int mi, ki;
             if (g.sak == 1) { ki = e % BK; mi = e / BK; } else { mi = e % BM; ki = e / BM; }
             const int m = m0 + mi, k = k0 + ki;
-            const float v = (m < g.M && k < kend) ? g.A[m * g.sam + k * g.sak] : 0.f;
-            if constexpr (BF16) As16[mi][ki] = to_bf16(v); else As32[mi][ki] = v;
+            ra[i] = (m < g.M && k < kend) ? g.A[m * g.sam + k * g.sak] : 0.f;
+            int ni, kj;
+            if (g.sbk == 1) { kj = e % BK; ni = e / BK; } else { ni = e % BN; kj = e / BN; }
+            const int n = n0 + ni, k2 = k0 + kj;
+            rb[i] = (n < g.N && k2 < kend) ? g.B[k2 * g.sbk + n * g.sbn] : 0.f;
         }
-        for (int e = tid; e < BN * BK; e += 256) {
-            int ni, ki;
-            if (g.sbk == 1) { ki = e % BK; ni = e / BK; } else { ni = e % BN; ki = e / BN; }
-            const int n = n0 + ni, k = k0 + ki;
-            const float v = (n < g.N && k < kend) ? g.B[k * g.sbk + n * g.sbn] : 0.f;
-            if constexpr (BF16) Bs16[ni][ki] = to_bf16(v); else Bs32[ni][ki] = v;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * 256;
+            int mi, ki;
+            if (g.sak == 1) { ki = e % BK; mi = e / BK; } else { mi = e % BM; ki = e / BM; }
+            if constexpr (BF16) As16[mi][ki] = to_bf16(ra[i]); else As32[mi][ki] = ra[i];
+            int ni, kj;
+            if (g.sbk == 1) { kj = e % BK; ni = e / BK; } else { ni = e % BN; kj = e / BN; }
+            if constexpr (BF16) Bs16[ni][kj] = to_bf16(rb[i]); else Bs32[ni][kj] = rb[i];
         }
+    };
+    if (kbeg < kend) load_tile(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_tile();
         __syncthreads();
+        if (k0 + BK < kend) load_tile(k0 + BK);
         if constexpr (BF16) {
             // lane l: A[row l&31][k = 8*(l>>5) + j], B[k = 8*(l>>5) + j][col l&31], j = 0..7 (per 16-deep step)
 #pragma unroll
