@@ -90,15 +90,29 @@ struct IoSelect {
     // of the wave is above v0 (rates above the soft bound are rare): one wave-uniform branch.
     template <bool WANT_DF>
     __device__ __forceinline__ void eval4(const float (&v)[4], float (&f)[4], float (&df)[4]) const {
-        bool any_high = false;
+        // The power law is evaluated for all four values UNCONDITIONALLY (the empty asm pins it): left alone, the
+        // compiler sinks log/exp under a `v > 0` branch per value, which serialises the four dependent chains --
+        // and the serial wave only gets issue slots once the matrix wave of its SIMD has finished its chain
+        // (tools/microbench/mfma_valu_coissue.hip), so its latency, not its instruction count, is what is exposed.
+        float pw[4], vp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float vp = fmaxf(v[i], 1e-30f);
-            const float pw = k * __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(vp));
-            f[i] = (v[i] > 0.f) ? pw : ((v[i] != v[i]) ? v[i] : 0.f);
-            if (WANT_DF) df[i] = (v[i] > 0.f) ? n * pw * __builtin_amdgcn_rcpf(vp) : 0.f;
-            any_high = any_high || (v[i] > v0_low);
+            asm("v_max_f32 %0, 0x0da24260, %1" : "=v"(vp[i]) : "v"(v[i]));          // max(v, 1e-30)
+            pw[i] = k * __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(vp[i]));
         }
+        asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]));
+        float rv[4];
+        if (WANT_DF) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rv[i] = n * pw[i] * __builtin_amdgcn_rcpf(vp[i]);
+            asm volatile("" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[i] = (v[i] > 0.f) ? pw[i] : ((v[i] != v[i]) ? v[i] : 0.f);
+            if (WANT_DF) df[i] = (v[i] > 0.f) ? rv[i] : 0.f;
+        }
+        const bool any_high = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > v0_low;
         if (__builtin_amdgcn_ballot_w64(any_high) != 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -138,11 +152,116 @@ __device__ __forceinline__ mf4 slab_chain(const float (&wr)[MK], const float* xs
     return (a0 + a1) + (a2 + a3);
 }
 
+// ---- balanced K-split operand layout --------------------------------------------------------------------
+// The slab form gives every matrix wave 64 rows x MK columns: with M = 200 the fourth wave holds 8 real rows and the
+// chain is 200 MFMAs long in every wave.  The rows of one MFMA block need not be related to the other blocks', and
+// the four interleaved chains of a wave need not belong to the same rows, so the unit of work is a SLOT
+// (wave, chain, block) = (row quad q, column part p): 4 rows x KP columns.  NQ = MK / 4 quads x P parts fill
+// WM * 64 slots almost exactly (MK = 200: 50 x 5 = 250 of 256) and every wave runs 4 chains of KP = 40 MFMAs: 160
+// per phase instead of 200.  A lane ends with P partial sums per (row, stimulus) spread over P slots; they go to LDS
+// slot by slot and the serial lane of (quad, stimulus) adds them (P 16-byte reads).
+template <int MK>
+struct KSplit {
+    static constexpr int WM = (MK + 63) / 64;                  // matrix waves
+    static constexpr int SLOTS = WM * 64;
+    static constexpr int NQ = MK / 4;                          // row quads
+    static constexpr int P = SLOTS / NQ;                       // column parts per quad
+    static constexpr int KP = ((MK + P - 1) / P + 3) / 4 * 4;  // columns per part (16-byte B-operand reads)
+    static constexpr int NS4 = KP / 4;
+    static constexpr bool enabled = 4 * KP < MK;               // shorter chains than the slab form
+    static constexpr int RS = (P * KP > MK ? P * KP : MK) + 8; // state row stride: the (stimulus, part) reads of one
+                                                               // wave instruction on disjoint banks (MK = 200, 152)
+    // slot of (wave, chain, block) -> (part, quad); slots >= NQ * P idle (part P: all columns out of range)
+    __device__ static __forceinline__ int slot(int wave, int c, int blk) { return (wave * 4 + c) * 16 + blk; }
+};
+
+// wr[c][s] = A[4 q_c + i][p_c KP + s] (TRANSPOSED: A[p_c KP + s][4 q_c + i]) for lane (blk, i), zero outside M x M
+template <int MK, bool TRANSPOSED>
+__device__ __forceinline__ void ksplit_load(const float* A, int M, int wave, int lane, float (&wr)[4][KSplit<MK>::KP]) {
+    using KS = KSplit<MK>;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, M * M * 4, 0x00020000);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int u = KS::slot(wave, c, lane >> 2);
+        const int part = u / KS::NQ, row = 4 * (u % KS::NQ) + (lane & 3);
+        const int k0 = part * KS::KP;
+        const int rowc = row < M ? row : M - 1;
+        if constexpr (!TRANSPOSED) {
+            const int voff = (rowc * M + k0) * 4;
+#pragma unroll
+            for (int s4 = 0; s4 < KS::NS4; ++s4) {
+                const mf4 v = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, s4 * 16, 0));
+                wr[c][4 * s4] = v.x; wr[c][4 * s4 + 1] = v.y; wr[c][4 * s4 + 2] = v.z; wr[c][4 * s4 + 3] = v.w;
+            }
+        } else {
+            const int voff = (k0 * M + rowc) * 4;
+#pragma unroll
+            for (int s = 0; s < KS::KP; ++s)
+                wr[c][s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rsrc, voff, __builtin_amdgcn_readfirstlane(s * M * 4), 0));
+        }
+#pragma unroll
+        for (int s = 0; s < KS::KP; ++s) wr[c][s] = (row < M && k0 + s < M) ? wr[c][s] : 0.f;
+    }
+}
+
+// The four chains of one phase: chain c multiplies its slot's 4 x KP block with x[k0_c .. k0_c + KP) of the lane's
+// stimulus row (LDS byte address xa[c]) and stores the 4 partial sums to out[c] (LDS).  Read/MFMA order pinned as in
+// slab_chain: the B operands of step group s4 + DEPTH are requested before the 16 MFMAs of group s4.
+template <int MK>
+__device__ __forceinline__ void ksplit_chain(const float (&wr)[4][KSplit<MK>::KP], unsigned (&xa)[4], mf4* const (&out)[4]) {
+    using KS = KSplit<MK>;
+    constexpr int NS4 = KS::NS4, DEPTH = 2;
+    using LdsV4 = const __attribute__((address_space(3))) mf4*;
+    mf4 acc[4];
+    mf4 bq[NS4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = (mf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s4 = 0; s4 < DEPTH && s4 < NS4; ++s4)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bq[s4][c] = *(LdsV4)(size_t)(xa[c] + 16u * s4);
+    asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));
+#pragma unroll
+    for (int s4 = 0; s4 < NS4; ++s4) {
+        if (s4 + DEPTH < NS4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bq[s4 + DEPTH][c] = *(LdsV4)(size_t)(xa[c] + 16u * (s4 + DEPTH));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[c][4 * s4 + e], bq[s4][c][e], acc[c], 0, 0, 0);
+        asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]),
+                          "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *out[c] = acc[c];
+}
+
+// serial side: complete sums of (quad q, stimulus j) = the P partial sums of slots p NQ + q
+template <int MK>
+__device__ __forceinline__ mf4 ksplit_gather(const mf4* ab /* [SLOTS][4] of one group */, int q, int j) {
+    using KS = KSplit<MK>;
+    const int qc = q < KS::NQ ? q : KS::NQ - 1;
+    mf4 part[KS::P];
+#pragma unroll
+    for (int p = 0; p < KS::P; ++p) part[p] = ab[(p * KS::NQ + qc) * 4 + j];
+    mf4 acc = part[0];
+#pragma unroll
+    for (int p = 1; p < KS::P; ++p) acc += part[p];
+    return acc;
+}
+
 template <int MK, bool SAVE>
 __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<float> a) {
-    constexpr int RS = MK + 4;                    // LDS row stride: the 4 stimuli of a group on disjoint banks
+    using KS = KSplit<MK>;
+    constexpr bool KSP = KS::enabled;
+    constexpr int RS = KSP ? KS::RS : MK + 4;     // LDS row stride: the 4 stimuli of a group on disjoint banks
     __shared__ __align__(16) float rbuf[2][8][RS];
-    __shared__ __align__(16) float abuf[2][4][64][4];   // accumulator hand-off: [group][matrix wave][lane]
+    // accumulator hand-off: slab form [group][matrix wave][lane], K-split form [group][slot][stimulus]
+    __shared__ __align__(16) mf4 abuf[2][KSP ? KS::SLOTS * 4 : 4 * 64];
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
     const int ngroups = (a.NB + 7) / 8;
     const int b = blockIdx.x / ngroups;
@@ -155,15 +274,37 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
 
     if (wave < wm) {
         // ================================ matrix wave ================================
-        float wr[MK];
-        slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
-        __syncthreads();
-        for (int p = 0; p < nphase; ++p) {
-            if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
-                const int g = p & 1, it = p >> 1;
-                *reinterpret_cast<mf4*>(&abuf[g][wave][lane][0]) = slab_chain<MK>(wr, &rbuf[it & 1][4 * g + j][0]);
-            }
+        if constexpr (KSP) {
+            float wr[4][KS::KP];
+            ksplit_load<MK, false>(a.W + (size_t)b * M * M, M, wave, lane, wr);
+            using LdsF = const __attribute__((address_space(3))) float*;
+            const unsigned rb0 = (unsigned)(size_t)(LdsF)&rbuf[0][0][0];
+            unsigned xoff[4];                     // byte offset of (my stimulus row, first column of chain c's part)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             __syncthreads();
+            for (int p = 0; p < nphase; ++p) {
+                if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
+                    const int g = p & 1, it = p >> 1;
+                    const unsigned base = rb0 + (unsigned)((((it & 1) * 8 + 4 * g) * RS) * 4);
+                    unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
+                    mf4* const out[4] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j],
+                                         &abuf[g][KS::slot(wave, 2, blk) * 4 + j], &abuf[g][KS::slot(wave, 3, blk) * 4 + j]};
+                    ksplit_chain<MK>(wr, xa, out);
+                }
+                __syncthreads();
+            }
+        } else {
+            float wr[MK];
+            slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
+            __syncthreads();
+            for (int p = 0; p < nphase; ++p) {
+                if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
+                    const int g = p & 1, it = p >> 1;
+                    abuf[g][wave * 64 + lane] = slab_chain<MK>(wr, &rbuf[it & 1][4 * g + j][0]);
+                }
+                __syncthreads();
+            }
         }
         return;
     }
@@ -200,7 +341,9 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     // serial part of (group g, step it): u = acc + ext -> f, f' -> Euler step, windowed reductions, trajectory, state
     auto serial = [&](auto G, int it) {
         constexpr int g = decltype(G)::value;
-        const mf4 acc = *reinterpret_cast<const mf4*>(&abuf[g][sw][lane][0]);
+        mf4 acc;
+        if constexpr (KSP) acc = ksplit_gather<MK>(&abuf[g][0], 16 * sw + blk, j);
+        else acc = abuf[g][sw * 64 + lane];
         const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
         const float win = (it >= a.skip) ? 1.f : 0.f, win2 = (it > a.skip) ? 1.f : 0.f;
         float rnew[4], dfn[4] = {0.f, 0.f, 0.f, 0.f};   // scalars: see the bit_cast note in ssn_tile_core.h
@@ -566,7 +709,7 @@ bool gen_mfma_supported(int M, int NB) { return (M % 2 == 0) && NB >= 4 && mfma_
 
 template <int MK>
 static hipError_t launch_fwd_mk(const GenFwdArgs<float>& a, hipStream_t st) {
-    const int waves = (a.M + 63) / 64;
+    const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
     const int ngroups = (a.NB + 7) / 8;
     if (a.traj) hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, true>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
     else hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, false>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
