@@ -414,9 +414,11 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
 // odd ones, the matrix waves serve the other group in every phase.
 template <int MK>
 __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<float> a) {
-    constexpr int RS = MK + 4;
+    using KS = KSplit<MK>;
+    constexpr bool KSP = KS::enabled;
+    constexpr int RS = KSP ? KS::RS : MK + 4;
     __shared__ __align__(16) float dbuf[8][RS];          // delta_tau per stimulus, contiguous in the neuron index
-    __shared__ __align__(16) float abuf[2][4][64][4];
+    __shared__ __align__(16) mf4 abuf[2][KSP ? KS::SLOTS * 4 : 4 * 64];    // hand-off, as in the forward kernel
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
     const int ngroups = (a.NB + 7) / 8;
     const int b = blockIdx.x / ngroups;
@@ -428,15 +430,37 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
     for (int c = threadIdx.x; c < 8 * RS; c += blockDim.x) (&dbuf[0][0])[c] = 0.f;
 
     if (wave < wm) {
-        float wr[MK];
-        slab_load<MK, true>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
-        __syncthreads();
-        for (int p = 0; p < nphase; ++p) {
-            if (p >= 1) {
-                const int g = (p - 1) & 1;
-                *reinterpret_cast<mf4*>(&abuf[g][wave][lane][0]) = slab_chain<MK>(wr, &dbuf[4 * g + j][0]);
-            }
+        if constexpr (KSP) {
+            float wr[4][KS::KP];
+            ksplit_load<MK, true>(a.W + (size_t)b * M * M, M, wave, lane, wr);
+            using LdsF = const __attribute__((address_space(3))) float*;
+            const unsigned db0 = (unsigned)(size_t)(LdsF)&dbuf[0][0];
+            unsigned xoff[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             __syncthreads();
+            for (int p = 0; p < nphase; ++p) {
+                if (p >= 1) {
+                    const int g = (p - 1) & 1;
+                    const unsigned base = db0 + (unsigned)(4 * g * RS * 4);
+                    unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
+                    mf4* const out[4] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j],
+                                         &abuf[g][KS::slot(wave, 2, blk) * 4 + j], &abuf[g][KS::slot(wave, 3, blk) * 4 + j]};
+                    ksplit_chain<MK>(wr, xa, out);
+                }
+                __syncthreads();
+            }
+        } else {
+            float wr[MK];
+            slab_load<MK, true>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
+            __syncthreads();
+            for (int p = 0; p < nphase; ++p) {
+                if (p >= 1) {
+                    const int g = (p - 1) & 1;
+                    abuf[g][wave * 64 + lane] = slab_chain<MK>(wr, &dbuf[4 * g + j][0]);
+                }
+                __syncthreads();
+            }
         }
         return;
     }
@@ -507,7 +531,9 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
         if (tau >= 4) load4(rs_traj, at_step(g, tau - 4), nxm);
         if (tau >= 3) load4(rs_dlt, at_step(g, tau - 3), ndf);
         if (tau < T_) {
-            const mf4 acc = *reinterpret_cast<const mf4*>(&abuf[g][sw][lane][0]);     // W^T delta_{tau+1}
+            mf4 acc;                                                                  // W^T delta_{tau+1}
+            if constexpr (KSP) acc = ksplit_gather<MK>(&abuf[g][0], 16 * sw + blk, j);
+            else acc = abuf[g][sw * 64 + lane];
             carry[g][0] += acc.x; carry[g][1] += acc.y; carry[g][2] += acc.z; carry[g][3] += acc.w;
         }
         float delta[4];
@@ -727,7 +753,7 @@ hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st) {
 
 template <int MK>
 static hipError_t launch_bwd_mk(const GenBwdArgs<float>& a, hipStream_t st) {
-    const int waves = (a.M + 63) / 64;
+    const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
     const int ngroups = (a.NB + 7) / 8;
     hipLaunchKernelGGL((gen_backward_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
     return hipGetLastError();
