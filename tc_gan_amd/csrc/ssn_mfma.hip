@@ -75,10 +75,10 @@ __device__ __forceinline__ void slab_load(const float* A, int M, int row, float 
 // lane-dependent cases (v <= 0, v <= v0) are selects and the (uniform) I/O type is folded into coefficients --
 // a select on a uniform condition would be turned back into a branch.  Same values as io_eval_grad (ssn_gen.hip).
 struct IoSelect {
-    float k, n, v0_low, soft, gain, c_lin, c_tanh, c_tanh_gain;
+    float k, n, log2k, v0_low, soft, gain, c_lin, c_tanh, c_tanh_gain;
     __device__ __forceinline__ explicit IoSelect(const IoConsts<float>& c) {
         const bool lin = c.io_type == SSN_IO_LINEAR, th = c.io_type == SSN_IO_TANH;
-        k = c.k; n = c.n; soft = c.soft; gain = c.tanh_gain;
+        k = c.k; n = c.n; log2k = __builtin_log2f(c.k); soft = c.soft; gain = c.tanh_gain;
         v0_low = (c.io_type == SSN_IO_POWER) ? __builtin_inff() : c.v0;    // v <= v0_low: power-law branch
         c_lin = lin ? c.lin_slope : 0.f;
         c_tanh = th ? c.span : 0.f;
@@ -90,29 +90,28 @@ struct IoSelect {
     // of the wave is above v0 (rates above the soft bound are rare): one wave-uniform branch.
     template <bool WANT_DF>
     __device__ __forceinline__ void eval4(const float (&v)[4], float (&f)[4], float (&df)[4]) const {
-        // The power law is evaluated for all four values UNCONDITIONALLY (the empty asm pins it): left alone, the
-        // compiler sinks log/exp under a `v > 0` branch per value, which serialises the four dependent chains --
-        // and the serial wave only gets issue slots once the matrix wave of its SIMD has finished its chain
-        // (tools/microbench/mfma_valu_coissue.hip), so its latency, not its instruction count, is what is exposed.
-        float pw[4], vp[4];
+        // The power law k v^n = 2^(n log2 v + log2 k) is evaluated for all four values UNCONDITIONALLY (the empty asm
+        // pins it): left alone, the compiler sinks log/exp under a `v > 0` branch per value, which serialises the
+        // four dependent chains.  v = 0 gives 2^-inf = 0 by itself, v < 0 gives NaN and is selected away, NaN stays NaN.
+        float pw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            asm("v_max_f32 %0, 0x0da24260, %1" : "=v"(vp[i]) : "v"(v[i]));          // max(v, 1e-30)
-            pw[i] = k * __builtin_amdgcn_exp2f(n * __builtin_amdgcn_logf(vp[i]));
-        }
+        for (int i = 0; i < 4; ++i) pw[i] = __builtin_amdgcn_exp2f(fmaf(n, __builtin_amdgcn_logf(v[i]), log2k));
         asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]));
         float rv[4];
         if (WANT_DF) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rv[i] = n * pw[i] * __builtin_amdgcn_rcpf(vp[i]);
+            for (int i = 0; i < 4; ++i) rv[i] = n * pw[i] * __builtin_amdgcn_rcpf(v[i]);
             asm volatile("" : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f[i] = (v[i] > 0.f) ? pw[i] : ((v[i] != v[i]) ? v[i] : 0.f);
+            f[i] = (v[i] < 0.f) ? 0.f : pw[i];
             if (WANT_DF) df[i] = (v[i] > 0.f) ? rv[i] : 0.f;
         }
-        const bool any_high = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])) > v0_low;
+        float vmax;                               // NaN operands are ignored by v_max: they take no saturating branch
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(v[3]));
+        const bool any_high = vmax > v0_low;
         if (__builtin_amdgcn_ballot_w64(any_high) != 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -339,13 +338,15 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
         }
     }
     // serial part of (group g, step it): u = acc + ext -> f, f' -> Euler step, windowed reductions, trajectory, state
-    auto serial = [&](auto G, int it) {
+    // WIN: step inside the averaging window (it >= skip); before it the three windowed sums are not touched
+    auto serial = [&](auto G, auto WIN, int it) {
         constexpr int g = decltype(G)::value;
+        constexpr bool win_on = decltype(WIN)::value;
         mf4 acc;
         if constexpr (KSP) acc = ksplit_gather<MK>(&abuf[g][0], 16 * sw + blk, j);
         else acc = abuf[g][sw * 64 + lane];
         const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
-        const float win = (it >= a.skip) ? 1.f : 0.f, win2 = (it > a.skip) ? 1.f : 0.f;
+        const float win2 = (it > a.skip) ? 1.f : 0.f;
         float rnew[4], dfn[4] = {0.f, 0.f, 0.f, 0.f};   // scalars: see the bit_cast note in ssn_tile_core.h
         float uu[4], ff[4];
 #pragma unroll
@@ -356,9 +357,11 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
             const float f = ff[v];
             const float r1 = fmaf(eps[v], f - rc[g][v], rc[g][v]);             // (1 - eps) r + eps f(u)
             const float dd = r1 - rc[g][v];
-            ta[g][v] = fmaf(win, r1, ta[g][v]);
-            rpn[g][v] = fmaf(win, fmaxf(r1 - a.theta, 0.f), rpn[g][v]);
-            dp[g][v] = fmaf(win2 * dd, dd, dp[g][v]);
+            if constexpr (win_on) {
+                ta[g][v] += r1;
+                rpn[g][v] += fmaxf(r1 - a.theta, 0.f);
+                dp[g][v] = fmaf(win2 * dd, dd, dp[g][v]);
+            }
             rc[g][v] = r1;
             rnew[v] = (er + v < M) ? r1 : 0.f;
         }
@@ -385,10 +388,19 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     constexpr std::integral_constant<int, 1> G1{};
     __syncthreads();
     __syncthreads();                                  // phase 0: nothing to finish yet
-    for (int it = 0; it < T_; ++it) {
-        if (!(SSN_MFMA_ABLATE & 1)) serial(G0, it);     // phase 2 it + 1
+    constexpr std::integral_constant<bool, false> W0{};
+    constexpr std::integral_constant<bool, true> W1{};
+    const int nskip = a.skip < T_ ? (a.skip > 0 ? a.skip : 0) : T_;
+    for (int it = 0; it < nskip; ++it) {
+        if (!(SSN_MFMA_ABLATE & 1)) serial(G0, W0, it);     // phase 2 it + 1
         __syncthreads();
-        if (!(SSN_MFMA_ABLATE & 1)) serial(G1, it);     // phase 2 it + 2
+        if (!(SSN_MFMA_ABLATE & 1)) serial(G1, W0, it);     // phase 2 it + 2
+        __syncthreads();
+    }
+    for (int it = nskip; it < T_; ++it) {
+        if (!(SSN_MFMA_ABLATE & 1)) serial(G0, W1, it);
+        __syncthreads();
+        if (!(SSN_MFMA_ABLATE & 1)) serial(G1, W1, it);
         __syncthreads();
     }
 
