@@ -47,8 +47,8 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
-    // auto never picks the MFMA solver (variant 5): with the per-stimulus stop protocol on top it measures 108 ms
-    // at the C2/NB=8 shape against 85 ms for the split tile kernel (the fixed-time generator, without it, wins)
+    // auto does not pick the MFMA solver (variant 5): with the per-stimulus stop protocol on top it measures 85 ms
+    // at the C2/NB=8 shape, on par with the split tile kernel (85-90 ms); the fixed-time generator, without it, wins
     if (variant < 0) variant = tile_ok ? 2 : (regw_ok ? 1 : 0);
     switch (variant) {
         case 2: SSN_TRY(ssn::launch_tile<T>(a, st, 0)); break;

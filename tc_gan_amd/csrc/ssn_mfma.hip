@@ -595,9 +595,11 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
 // step counts, so matrix and serial waves leave the loop in the same phase.
 template <int MK>
 __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) {
-    constexpr int RS = MK + 4;
+    using KS = KSplit<MK>;
+    constexpr bool KSP = KS::enabled;
+    constexpr int RS = KSP ? KS::RS : MK + 4;
     __shared__ __align__(16) float rbuf[2][8][RS];
-    __shared__ __align__(16) float abuf[2][4][64][4];
+    __shared__ __align__(16) mf4 abuf[2][KSP ? KS::SLOTS * 4 : 4 * 64];    // hand-off, as in the generator kernels
     __shared__ __align__(16) int flags[3][8];
     const int M = a.M, N = a.N, max_iter = a.st.max_iter;
     const int ngroups = (a.NB + 7) / 8;
@@ -622,9 +624,14 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
         code[s] = 1; nsteps[s] = max_iter;
         if (s0 + s >= a.NB) frozen |= 1u << s;
     }
-    auto verdict = [&](auto G, int it) {           // flags of (group G, step it) -> frozen / code / nsteps
+    // The flag words are READ at the start of a phase and APPLIED at its end (after the phase's work, before the
+    // barrier): the LDS round trip would otherwise sit in front of the MFMA chain / serial part of every phase.
+    auto flags_read = [&](auto G, int it) {        // flags of (group G, step it)
         constexpr int g = decltype(G)::value;
-        const int4 f4 = *reinterpret_cast<const int4*>(&flags[it % 3][4 * g]);
+        return *reinterpret_cast<const int4*>(&flags[it % 3][4 * g]);
+    };
+    auto verdict = [&](auto G, int it, const int4& f4) {     // -> frozen / code / nsteps
+        constexpr int g = decltype(G)::value;
         const int f[4] = {__builtin_amdgcn_readfirstlane(f4.x), __builtin_amdgcn_readfirstlane(f4.y),
                           __builtin_amdgcn_readfirstlane(f4.z), __builtin_amdgcn_readfirstlane(f4.w)};
 #pragma unroll
@@ -644,18 +651,52 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
     // The two roles run the SAME phase structure (same barriers, same exits) in separate loops, so that the
     // registers of one role (200 for the slab) are not live in the other.
     if (matrix) {
-        float wr[MK];
-        slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
-        __syncthreads();
-        for (int it = 0; it <= max_iter; ++it) {
-            if (it >= 1) verdict(G0, it - 1);                                   // phase 2 it
-            if (frozen == 0xffu) break;
-            if (it < max_iter) *reinterpret_cast<mf4*>(&abuf[0][wave][lane][0]) = slab_chain<MK>(wr, &rbuf[it & 1][j][0]);
+        if constexpr (KSP) {
+            float wr[4][KS::KP];
+            ksplit_load<MK, false>(a.W + (size_t)b * M * M, M, wave, lane, wr);
+            using LdsF = const __attribute__((address_space(3))) float*;
+            const unsigned rb0 = (unsigned)(size_t)(LdsF)&rbuf[0][0][0];
+            unsigned xoff[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
+            auto chain = [&](int g, int it) {
+                const unsigned base = rb0 + (unsigned)((((it & 1) * 8 + 4 * g) * RS) * 4);
+                unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
+                mf4* const out[4] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j],
+                                     &abuf[g][KS::slot(wave, 2, blk) * 4 + j], &abuf[g][KS::slot(wave, 3, blk) * 4 + j]};
+                ksplit_chain<MK>(wr, xa, out);
+            };
             __syncthreads();
-            if (it >= 1) verdict(G1, it - 1);                                   // phase 2 it + 1
-            if (frozen == 0xffu) break;
-            if (it < max_iter) *reinterpret_cast<mf4*>(&abuf[1][wave][lane][0]) = slab_chain<MK>(wr, &rbuf[it & 1][4 + j][0]);
+            for (int it = 0; it <= max_iter; ++it) {
+                int4 f4 = {0, 0, 0, 0};
+                if (it >= 1) f4 = flags_read(G0, it - 1);                       // phase 2 it
+                if (it < max_iter) chain(0, it);
+                if (it >= 1) verdict(G0, it - 1, f4);
+                if (frozen == 0xffu) break;
+                __syncthreads();
+                if (it >= 1) f4 = flags_read(G1, it - 1);                       // phase 2 it + 1
+                if (it < max_iter) chain(1, it);
+                if (it >= 1) verdict(G1, it - 1, f4);
+                if (frozen == 0xffu) break;
+                __syncthreads();
+            }
+        } else {
+            float wr[MK];
+            slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
             __syncthreads();
+            for (int it = 0; it <= max_iter; ++it) {
+                int4 f4 = {0, 0, 0, 0};
+                if (it >= 1) f4 = flags_read(G0, it - 1);                       // phase 2 it
+                if (it < max_iter) abuf[0][wave * 64 + lane] = slab_chain<MK>(wr, &rbuf[it & 1][j][0]);
+                if (it >= 1) verdict(G0, it - 1, f4);
+                if (frozen == 0xffu) break;
+                __syncthreads();
+                if (it >= 1) f4 = flags_read(G1, it - 1);                       // phase 2 it + 1
+                if (it < max_iter) abuf[1][wave * 64 + lane] = slab_chain<MK>(wr, &rbuf[it & 1][4 + j][0]);
+                if (it >= 1) verdict(G1, it - 1, f4);
+                if (frozen == 0xffu) break;
+                __syncthreads();
+            }
         }
         return;
     }
@@ -681,7 +722,9 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
     const IoSelect io(a.io);
     auto serial = [&](auto G, int it) {            // serial part of (group G, step it)
         constexpr int g = decltype(G)::value;
-        const mf4 acc = *reinterpret_cast<const mf4*>(&abuf[g][sw][lane][0]);
+        mf4 acc;
+        if constexpr (KSP) acc = ksplit_gather<MK>(&abuf[g][0], 16 * sw + blk, j);
+        else acc = abuf[g][sw * 64 + lane];
         const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
         const bool upd = live[g] && !((frozen >> (4 * g + j)) & 1u);
         float uu[4], ff[4], dummy[4];
@@ -708,13 +751,16 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
     };
     __syncthreads();
     for (int it = 0; it <= max_iter; ++it) {
-        if (it >= 1) verdict(G0, it - 1);                                       // phase 2 it: serial part of (1, it - 1)
-        if (frozen == 0xffu) break;
+        int4 f4 = {0, 0, 0, 0};
+        if (it >= 1) f4 = flags_read(G0, it - 1);                               // phase 2 it: serial part of (1, it - 1)
         if (it >= 1) serial(G1, it - 1);
-        __syncthreads();
-        if (it >= 1) verdict(G1, it - 1);                                       // phase 2 it + 1: serial part of (0, it)
+        if (it >= 1) verdict(G0, it - 1, f4);
         if (frozen == 0xffu) break;
+        __syncthreads();
+        if (it >= 1) f4 = flags_read(G1, it - 1);                               // phase 2 it + 1: serial part of (0, it)
         if (it < max_iter) serial(G0, it);
+        if (it >= 1) verdict(G1, it - 1, f4);
+        if (frozen == 0xffu) break;
         __syncthreads();
     }
 #pragma unroll
@@ -782,7 +828,7 @@ hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st) 
 
 template <int MK>
 static hipError_t launch_solve_mk(const SolveArgs<float>& a, hipStream_t st) {
-    const int waves = (a.M + 63) / 64;
+    const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
     const int ngroups = (a.NB + 7) / 8;
     hipLaunchKernelGGL((solve_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
     return hipGetLastError();
