@@ -146,6 +146,7 @@ double legacy_io(int io_type, double v, double r0, double r1, double v0, double 
     c.tanh_gain = n * r0 / ((r1 - r0) * v0);
     c.span = r1 - r0;
     c.span_gain = c.span * c.tanh_gain;
+    c.log2k = std::log2(k);
     double *dv = nullptr, out = std::numeric_limits<double>::quiet_NaN();
     if (hipMalloc(&dv, 2 * sizeof(double)) != hipSuccess) return out;
     if (hipMemcpy(dv, &v, sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&

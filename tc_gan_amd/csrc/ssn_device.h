@@ -20,6 +20,7 @@ struct IoConsts {
     T tanh_gain;   // n * soft / ((hard - soft) * v0)       ssnode.c:51
     T span;        // hard - soft        (host-side so that it arrives as a kernel argument in an SGPR
     T span_gain;   // span * tanh_gain    instead of being recomputed into a VGPR by every wave)
+    T log2k;       // log2(k): k v^n = 2^(n log2 v + log2 k) in the fp32 kernels
 };
 
 template <typename T>
@@ -45,6 +46,7 @@ inline IoConsts<T> make_io_consts(const ssn_solver_params& p) {
     c.tanh_gain = (T)(p.n * p.rate_soft_bound / ((p.rate_hard_bound - p.rate_soft_bound) * v0));
     c.span = c.hard - c.soft;
     c.span_gain = c.span * c.tanh_gain;
+    c.log2k = (T)log2(p.k);
     return c;
 }
 
@@ -81,6 +83,19 @@ __device__ __forceinline__ T io_eval(T v, const IoConsts<T>& c) {
     if (c.io_type == SSN_IO_POWER || v <= c.v0) return pow_rate(v, c.k, c.n);
     if (c.io_type == SSN_IO_LINEAR) return c.soft + c.lin_slope * (v - c.v0);
     return c.soft + c.span * tanh_pos(c.tanh_gain * (v - c.v0));
+}
+
+// fp32: the power law without the v > 0 test in front of it.  v = 0 -> 2^-inf = 0; v < 0 -> NaN, selected away;
+// NaN stays NaN.  Same values as the generic form to ~1e-7 relative.
+template <>
+__device__ __forceinline__ float io_eval<float>(float v, const IoConsts<float>& c) {
+    const float pw = __builtin_amdgcn_exp2f(fmaf(c.n, __builtin_amdgcn_logf(v), c.log2k));
+    float f = (v < 0.f) ? 0.f : pw;
+    if (c.io_type != SSN_IO_POWER && v > c.v0) {
+        f = (c.io_type == SSN_IO_LINEAR) ? c.soft + c.lin_slope * (v - c.v0)
+                                         : c.soft + c.span * tanh_pos(c.tanh_gain * (v - c.v0));
+    }
+    return f;
 }
 
 __device__ __forceinline__ float abs_t(float x) { return __builtin_fabsf(x); }

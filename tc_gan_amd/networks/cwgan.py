@@ -366,9 +366,9 @@ class ConditionalBPTTWassersteinGAN(object):
             self.reducer.mean_(grads, loss)
             off = 0
             for name in self._pnames:                                            # wgan.py:218-260
-                value = np.asarray(getattr(self.gen, name))
+                value = np.array(getattr(self.gen, name), dtype='float32')      # (copy: the source may be read-only)
                 p = self._gparams[name]
-                p.copy_(torch.as_tensor(value.ravel(), dtype=torch.float32))
+                p.copy_(torch.from_numpy(value.ravel()))
                 self.gen_updaters[name](p, grads[off:off + p.numel()], clip=self.param_bounds[name])
                 off += p.numel()
                 setattr(self.gen, name, p.cpu().numpy().astype('float64').reshape(value.shape))
