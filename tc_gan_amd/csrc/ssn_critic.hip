@@ -191,20 +191,43 @@ __global__ void __launch_bounds__(256) critic_outgrad_kernel(const float* __rest
     }
 }
 
-// column sums: out[n] (+)= sum_b X[b][n]    (bias gradients)
-__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int batch, int n,
-                                                     float beta) {
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int part = threadIdx.x >> 6;
-    __shared__ float red[4][64];
-    float s = 0.f;
-    if (col < n)
-        for (int b = part; b < batch; b += 4) s += X[(long)b * n + col];
-    red[part][threadIdx.x & 63] = s;
+// column sums: out[n] = sum_b X[b][n] + beta * out[n]    (bias gradients).  One workgroup per 64 columns: 16 lanes x
+// float4 per row, 64 row slots, fixed-order tree in LDS -- deterministic.  Accumulation in fp64: the bias gradient of
+// a unit that is active on equally many generated and data rows is a sum of +c and -c terms, exactly zero in the
+// reference's arithmetic; fp32 partial sums (3c, 5c, ...) round, leave ~1e-8 of noise, and Adam (eps 1e-8) turns
+// that noise into full-size steps of the bias.
+__global__ void __launch_bounds__(1024) colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int batch, int n,
+                                                      float beta) {
+    const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + 4 * cq;
+    __shared__ double red[64][64];
+    __shared__ double red2[16][64];
+    double s[4] = {0., 0., 0., 0.};
+    if (col + 3 < n && (n & 3) == 0) {
+#pragma unroll 4
+        for (int b = slot; b < batch; b += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(X + (long)b * n + col);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+    } else {
+        for (int b = slot; b < batch; b += 64)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n) s[e] += X[(long)b * n + col + e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[slot][4 * cq + e] = s[e];
     __syncthreads();
-    if (part == 0 && col < n) {
-        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        out[col] = t + (beta != 0.f ? beta * out[col] : 0.f);
+    {
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+        red2[g][c] = (red[4 * g][c] + red[4 * g + 1][c]) + (red[4 * g + 2][c] + red[4 * g + 3][c]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < n) {
+        double t = 0.;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red2[g][threadIdx.x];
+        float* o = out + blockIdx.x * 64 + threadIdx.x;
+        *o = (float)(t + (beta != 0.f ? (double)beta * (double)*o : 0.));
     }
 }
 
@@ -338,7 +361,7 @@ static hipError_t critic_backward_chain(const CriticNet& net, float* const* h, f
             g.C = grads + off_w; g.ldc = nout; g.M = nin; g.N = nout; g.K = batch;
             g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
             if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
-            hipLaunchKernelGGL(colsum_kernel, dim3((nout + 63) / 64), dim3(256), 0, st, v[l + 1], grads + off_b, batch, nout, 1.f);
+            hipLaunchKernelGGL(colsum_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, v[l + 1], grads + off_b, batch, nout, 1.f);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (l > 0 || want_input_grad) {
@@ -446,7 +469,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
         off += (long)nin * nout + nout;
     }
     // d/dw_out[k] += lmd * sum_b e_L[b][k]      (v_L = m_L * w_out, mask already applied in e_L)
-    hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(256), 0, st, ep[L], tmp, np, dims[L], 0.f);
+    hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(1024), 0, st, ep[L], tmp, np, dims[L], 0.f);
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(dims[L])), dim3(256), 0, st, grads + (net.nparams - dims[L]), tmp, lmd, (long)dims[L]);
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
     return hipGetLastError();
@@ -485,7 +508,7 @@ hipError_t critic_gemm(const float* A, long sam, long sak, const float* B, long 
     return gemm(g, bf16, st);
 }
 hipError_t critic_colsum(const float* X, float* out, int batch, int n, float beta, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64), dim3(256), 0, st, X, out, batch, n, beta);
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64), dim3(1024), 0, st, X, out, batch, n, beta);
     return hipGetLastError();
 }
 hipError_t critic_make_input(const float* x, const float* cond, float* h0, int batch, int nx, int hide, hipStream_t st) {

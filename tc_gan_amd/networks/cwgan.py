@@ -210,6 +210,8 @@ class ConditionalBPTTWassersteinGAN(object):
         self.rate_cost = rate_cost
         self.param_bounds = param_bounds          # {'J': (min, max), ...}  (wgan.py:244-251)
         self.rng = as_randomstate(seed)
+        self._predrawn = None          # host draws of the NEXT critic step, made early (see train_generator)
+        self._rng_before_predraw = None
         self.reducer = GradientAllReducer()
         assert self.probes_per_model < gen.num_neurons
         assert num_models % self.reducer.world == 0, 'num_models must be divisible by the number of ranks'
@@ -273,10 +275,16 @@ class ConditionalBPTTWassersteinGAN(object):
     # is already queued on the stream when the host blocks on this step's scalars: `_prepare_disc` draws from the
     # host RNG (same order as the reference: minibatch, eps, zs) and launches the forward; `_finish_disc` runs the
     # critic update and reads loss / accuracy / penalties back with ONE device-to-host copy.
-    def _prepare_disc(self):
+    def _draw_disc(self):
+        """The host RNG draws of one critic step, in the reference's order (minibatch, eps, zs)."""
         batch = self.next_minibatch()
         eps_full = self.rng.rand(batch.batchsize, 1)
         noise = self._draw_noise(batch)
+        return batch, eps_full, noise
+
+    def _prepare_disc(self):
+        drawn, self._predrawn, self._rng_before_predraw = self._predrawn, None, None
+        batch, eps_full, noise = drawn if drawn is not None else self._draw_disc()
         with self.gen_forward_watch:
             gen_out, local = self.gen_forward(batch, noise)
         return Namespace(batch=batch, eps_full=eps_full, gen_out=gen_out, local=local,
@@ -353,6 +361,13 @@ class ConditionalBPTTWassersteinGAN(object):
 
     def train_generator(self, info, batch, prepared=None):
         gen_out, local = prepared if prepared is not None else self._prepare_gen(batch)
+        # The host draws of the NEXT critic step (per-model `rng.choice` loops: ~5 ms for 1024 models) are made now,
+        # while the trajectory-saving forward is still running on the GPU -- after the parameter update the GPU would
+        # sit idle for them.  Same RandomState order: nothing else draws between here and that step.  A checkpoint
+        # taken in between stores the RandomState from BEFORE these draws (state_dict), so a resumed run repeats them.
+        if self.critic_iters > 0 and self._predrawn is None:
+            self._rng_before_predraw = self.rng.get_state()
+            self._predrawn = self._draw_disc()
         with self.gen_train_watch:
             cd = to_device(np.ascontiguousarray(local.conditions), torch.float32)
             xg = gen_out.prober_tuning_curve.to(torch.float32)
@@ -421,7 +436,8 @@ class ConditionalBPTTWassersteinGAN(object):
     def state_dict(self):
         """Everything a bit-identical continuation needs: generator and critic parameters, the optimizer states,
         the host RandomState (shared with the minibatch sampler) and the device noise generator."""
-        kind, keys, pos, has_gauss, cached = self.rng.get_state()
+        kind, keys, pos, has_gauss, cached = (self._rng_before_predraw if self._predrawn is not None
+                                              else self.rng.get_state())
         d = dict(gen={name: np.array(value) for name, value in self.gen.get_all_params()},
                  disc=self.disc.get_flat(), disc_updater=self.disc_updater.state_dict(),
                  gen_updaters={name: self.gen_updaters[name].state_dict() for name in self._pnames},
@@ -431,6 +447,7 @@ class ConditionalBPTTWassersteinGAN(object):
         return d
 
     def load_state_dict(self, d):
+        self._predrawn = self._rng_before_predraw = None
         self.gen.set_params(d['gen'])
         self.disc.set_flat(np.asarray(d['disc']))
         self.disc_updater.load_state_dict(d['disc_updater'])

@@ -135,3 +135,25 @@ def test_layer_normalised_critic_loss_gradient_and_input_gradient(batch, nx, lay
     gx_o, = torch.autograd.grad(-og.critic_forward(params_o, x, tc, normalization=norm).mean(), x)
     gx, _ = c.input_grad(xg, cond, scale=-1.0 / batch)
     np.testing.assert_allclose(gx.cpu().numpy(), gx_o.numpy(), rtol=2e-3, atol=1e-6)
+
+
+def test_bias_gradients_that_cancel_are_exactly_zero():
+    """Units active on every row get +w/B from each generated row and -w/B from each data row: the reference's
+    sum is exactly zero.  fp32 partial sums of such terms round (3c, 5c, ... need extra mantissa bits) and leave
+    ~1e-8 of noise, which Adam (eps 1e-8) turns into full-size parameter steps; the column sums accumulate in fp64."""
+    batch, nx, layers = 24, 8, [16, 16]
+    c, params_o, xg, xd, xp, cond = _setup(batch, nx, layers, seed=5)
+    flat = c.get_flat().copy()
+    off = 0
+    bias_slices = []
+    dims = [nx + 3] + layers
+    for nin, nout in zip(dims[:-1], dims[1:]):
+        off += nin * nout
+        flat[off:off + nout] = 1000.0                     # every unit active on every row
+        bias_slices.append(slice(off, off + nout))
+        off += nout
+    c.set_flat(flat)
+    c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0)
+    got = c.grads.cpu().numpy()
+    for sl in bias_slices:
+        np.testing.assert_array_equal(got[sl], 0.0)
