@@ -132,8 +132,15 @@ class RandomChoiceSampler(object):
             probs /= probs.sum()
         else:
             probs = None
-        ids = np.asarray([cellids[self.rng.choice(len(cellids), probes_per_model, replace=False, p=probs)]
-                          for _ in range(num_models)])
+        if len(cellids) == 1:
+            # one (cell type, probe) pair: `choice(1, 1, replace=False)` is permutation(1)[:1] = [0] and draws nothing
+            # from the RandomState, so the per-model loop (5 us per model: 40 ms per critic step for the 8192 models
+            # of an 8-GPU job, on every rank) can be skipped without changing the stream
+            assert probes_per_model == 1
+            ids = np.broadcast_to(cellids[0], (num_models, 1, 2))
+        else:
+            ids = np.asarray([cellids[self.rng.choice(len(cellids), probes_per_model, replace=False, p=probs)]
+                              for _ in range(num_models)])
         ids_cell_type, ids_norm_probes = ids.transpose((2, 0, 1))
         return ids_cell_type, ids_norm_probes
 

@@ -153,3 +153,25 @@ def test_doctests(module):
     """The reference runs ``--doctest-modules`` (pytest.ini:2-3); the host modules keep their doctests."""
     res = doctest.testmod(importlib.import_module(module), optionflags=doctest.NORMALIZE_WHITESPACE)
     assert res.failed == 0
+
+
+def test_single_cell_minibatch_selection_keeps_the_random_stream():
+    """With one (cell type, probe) pair the per-model `choice` loop is skipped: same minibatch, same RandomState."""
+    import numpy as np
+    from tc_gan_amd.networks import cwgan
+    cls = [v for v in vars(cwgan).values() if isinstance(v, type) and hasattr(v, 'random_cells')][0]
+    nested = np.random.RandomState(0).rand(50, 1, 1, 2, 8)
+    cond_values = [[0], [0.0], [5.0, 20.0], np.linspace(0, 1, 8)]
+    a = cls(nested, cond_values, e_ratio=0.8, seed=np.random.RandomState(7))
+    b = cls(nested, cond_values, e_ratio=0.8, seed=np.random.RandomState(7))
+    mb_a = a.select_minibatch(16, 1)
+    # reference behaviour: the loop of rng.choice calls (cwgan.py:328-355)
+    shape = (16, 1)
+    ids_sample = b.rng.choice(len(nested), shape)
+    ids = np.asarray([[[0, 0]][0:1] for _ in range(16)])
+    for _ in range(16):
+        assert b.rng.choice(1, 1, replace=False)[0] == 0
+    ids_contrast = b.rng.choice(2, 16)
+    np.testing.assert_array_equal(mb_a.tc_md, nested[ids_sample, 0, 0, ids_contrast.reshape(-1, 1)])
+    sa, sb = a.rng.get_state(), b.rng.get_state()
+    assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1])
