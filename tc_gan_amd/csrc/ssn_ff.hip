@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) ff_forward_kernel(FFArgs a) {
             const int iz = g % a.box, iy = (g / a.box) % a.box, ix = g / (a.box * a.box);
             const float px = -3.f + step * ix, py = -3.f + step * iy, pz = -3.f + step * iz;
             const float sig = w4[t] * a.RF_d + a.RF_l;
-            const float inv2s2 = 0.5f / (sig * sig);
+            const float inv2s2 = 0.5f * __builtin_amdgcn_rcpf(sig * sig);
             const float wgt = a.J * c4[t] * s4[t];
 #pragma unroll
             for (int i = 0; i < NI_T; ++i) {
@@ -142,16 +142,19 @@ __global__ void __launch_bounds__(256) ff_forward_lattice_kernel(FFArgs a, FFLat
             if (t > 0) { if (++iz >= a.box) { iz = 0; if (++iy >= a.box) { iy = 0; ++ix; } } }
             const float px = -3.f + step * ix, py = -3.f + step * iy, pz = -3.f + step * iz;
             const float sig = w4[t] * a.RF_d + a.RF_l;
-            const float c2 = -0.72134752044448170f / (sig * sig);        // -log2(e) / (2 sig^2)
-            const V2 w2 = V2{a.J * c4[t] * s4[t], 1.f};
-            float ex[3], ey[3], ez[3];
+            const float c2 = -0.72134752044448170f * __builtin_amdgcn_rcpf(sig * sig);   // -log2(e) / (2 sig^2), 1 ulp
+            const float wj = a.J * c4[t] * s4[t];
+            float ex[3], ey[3], ez[3], ezw[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float dx = px - lat.x[k], dy = py - lat.y[k], dz = pz - lat.z[k];
                 ex[k] = __builtin_amdgcn_exp2f(dx * dx * c2);
                 ey[k] = __builtin_amdgcn_exp2f(dy * dy * c2);
                 ez[k] = __builtin_amdgcn_exp2f(dz * dz * c2);
+                ezw[k] = ez[k] * wj;
             }
+            // e = ex ey ez is never formed: sum e w += (ex ey) (ez w), sum e += (ex ey) ez -- 9 + 3 multiplies and
+            // 54 FMAs per point instead of 36 multiplies and 54 FMAs
 #pragma unroll
             for (int ia = 0; ia < 3; ++ia)
 #pragma unroll
@@ -159,9 +162,8 @@ __global__ void __launch_bounds__(256) ff_forward_lattice_kernel(FFArgs a, FFLat
                     const float exy = ex[ia] * ey[ib];
 #pragma unroll
                     for (int ic = 0; ic < 3; ++ic) {
-                        const float e = exy * ez[ic];
                         const int i = (ia * 3 + ib) * 3 + ic;
-                        acc2[i] = __builtin_elementwise_fma(V2{e, e}, w2, acc2[i]);
+                        acc2[i] = __builtin_elementwise_fma(V2{exy, exy}, V2{ezw[ic], ez[ic]}, acc2[i]);
                     }
                 }
         }
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256) ff_backward_kernel(FFArgs a, const float*
         const float px = -3.f + step * ix, py = -3.f + step * iy, pz = -3.f + step * iz;
         const float rw = rfw[g];
         const float sig = rw * a.RF_d + a.RF_l;
-        const float inv2s2 = 0.5f / (sig * sig), inv_s3 = 1.f / (sig * sig * sig);
+        const float inv2s2 = 0.5f * __builtin_amdgcn_rcpf(sig * sig), inv_s3 = __builtin_amdgcn_rcpf(sig * sig * sig);
         const float wgt = a.J * con[g] * str[g];
         float t = 0.f;
 #pragma unroll
