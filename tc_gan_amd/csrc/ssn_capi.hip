@@ -37,7 +37,7 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     a.io = ssn::make_io_consts<T>(*p);
     a.st = ssn::make_step_consts<T>(*p);
     hipStream_t st = (hipStream_t)stream;
-    // variant: -1 auto (tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
+    // variant: -1 auto (MFMA for large fp32 NB >= 4 batches, else tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
     // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs,
     // 5 fp32 MFMA kernel (NB >= 4)
     const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
@@ -47,9 +47,13 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
-    // auto does not pick the MFMA solver (variant 5): with the per-stimulus stop protocol on top it measures 85 ms
-    // at the C2/NB=8 shape, on par with the split tile kernel (85-90 ms); the fixed-time generator, without it, wins
-    if (variant < 0) variant = tile_ok ? 2 : (regw_ok ? 1 : 0);
+    // auto: the MFMA solver (variant 5) for fp32 with NB >= 4 stimuli per draw, 2N above the smallest ladder size and
+    // enough (draw, 8 stimuli) workgroups to fill the chip -- 71 ms at the C2/NB=8 shape against 85-90 ms for the
+    // split tile kernel (which runs one workgroup per (draw, stimulus) and so keeps small batches busier)
+    if (variant < 0) {
+        const bool big = (long)B * ((NB + 7) / 8) >= 192 && M > 104;
+        variant = (mfma_ok && big) ? 5 : (tile_ok ? 2 : (regw_ok ? 1 : 0));
+    }
     switch (variant) {
         case 2: SSN_TRY(ssn::launch_tile<T>(a, st, 0)); break;
         case 3: SSN_TRY(ssn::launch_tile<T>(a, st, 1)); break;

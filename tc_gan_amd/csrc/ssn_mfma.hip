@@ -616,34 +616,23 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
     if (threadIdx.x < 24) (&flags[0][0])[threadIdx.x] = 0;
     __syncthreads();
 
-    // ---- uniform bookkeeping, identical in every wave -------------------------------------------------
-    unsigned frozen = 0;                           // bit s: stimulus s0 + s has stopped (or does not exist)
-    int code[8], nsteps[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        code[s] = 1; nsteps[s] = max_iter;
-        if (s0 + s >= a.NB) frozen |= 1u << s;
-    }
-    // The flag words are READ at the start of a phase and APPLIED at its end (after the phase's work, before the
+    // ---- bookkeeping, identical in every wave: lane s (< 8) follows stimulus s0 + s --------------------
+    // (per-lane VALU + one ballot per phase; a scalar version costs ~40 dependent SALU instructions per stimulus group
+    // and phase, in order, in front of the matrix wave's next MFMA chain)
+    int my_code = 1, my_steps = max_iter;
+    bool my_frozen = lane >= 8 || s0 + lane >= a.NB;             // lanes without a stimulus count as stopped
+    unsigned frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;   // bit s: stimulus s0 + s has stopped
+    // The flag word is READ at the start of a phase and APPLIED at its end (after the phase's work, before the
     // barrier): the LDS round trip would otherwise sit in front of the MFMA chain / serial part of every phase.
-    auto flags_read = [&](auto G, int it) {        // flags of (group G, step it)
+    auto flags_read = [&](auto, int it) { return flags[it % 3][lane & 7]; };
+    auto verdict = [&](auto G, int it, int f) {                  // flags of (group G, step it) -> my_* / frozen
         constexpr int g = decltype(G)::value;
-        return *reinterpret_cast<const int4*>(&flags[it % 3][4 * g]);
-    };
-    auto verdict = [&](auto G, int it, const int4& f4) {     // -> frozen / code / nsteps
-        constexpr int g = decltype(G)::value;
-        const int f[4] = {__builtin_amdgcn_readfirstlane(f4.x), __builtin_amdgcn_readfirstlane(f4.y),
-                          __builtin_amdgcn_readfirstlane(f4.z), __builtin_amdgcn_readfirstlane(f4.w)};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int s = 4 * g + q;
-            const bool fnc = f[q] & 0xffff, fhb = f[q] >> 16;
-            if (!((frozen >> s) & 1u) && (!fnc || fhb)) {
-                code[s] = fnc ? 2 : 0;
-                nsteps[s] = it + 1;
-                frozen |= 1u << s;
-            }
-        }
+        const bool fnc = (f & 0xffff) != 0, fhb = (f >> 16) != 0;
+        const bool stop = lane < 8 && (lane >> 2) == g && !my_frozen && (!fnc || fhb);
+        my_code = stop ? (fnc ? 2 : 0) : my_code;
+        my_steps = stop ? it + 1 : my_steps;
+        my_frozen = my_frozen || stop;
+        frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
     };
     constexpr std::integral_constant<int, 0> G0{};
     constexpr std::integral_constant<int, 1> G1{};
@@ -668,7 +657,7 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
             };
             __syncthreads();
             for (int it = 0; it <= max_iter; ++it) {
-                int4 f4 = {0, 0, 0, 0};
+                int f4 = 0;
                 if (it >= 1) f4 = flags_read(G0, it - 1);                       // phase 2 it
                 if (it < max_iter) chain(0, it);
                 if (it >= 1) verdict(G0, it - 1, f4);
@@ -685,7 +674,7 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
             slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
             __syncthreads();
             for (int it = 0; it <= max_iter; ++it) {
-                int4 f4 = {0, 0, 0, 0};
+                int f4 = 0;
                 if (it >= 1) f4 = flags_read(G0, it - 1);                       // phase 2 it
                 if (it < max_iter) abuf[0][wave * 64 + lane] = slab_chain<MK>(wr, &rbuf[it & 1][j][0]);
                 if (it >= 1) verdict(G0, it - 1, f4);
@@ -720,38 +709,40 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
         if (live[g] && er < M) *reinterpret_cast<mf4*>(&rbuf[0][4 * g + j][er]) = (mf4){r4[0], r4[1], r4[2], r4[3]};
     }
     const IoSelect io(a.io);
+    bool rowok[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rowok[v] = er + v < M;
     auto serial = [&](auto G, int it) {            // serial part of (group G, step it)
         constexpr int g = decltype(G)::value;
         mf4 acc;
         if constexpr (KSP) acc = ksplit_gather<MK>(&abuf[g][0], 16 * sw + blk, j);
         else acc = abuf[g][sw * 64 + lane];
         const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
-        const bool upd = live[g] && !((frozen >> (4 * g + j)) & 1u);
-        float uu[4], ff[4], dummy[4];
+        float uu[4], ff[4], dummy[4], r1[4], dabs[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) uu[v] = accs[v] + ex[g][v];
         io.template eval4<false>(uu, ff, dummy);
-        bool nc = false, hb = false;
-        float rnew[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float r1 = rc[g][v] + (-rc[g][v] + ff[v]) * eps[v];          // ssnode.c:64-67
-            const bool row = upd && er + v < M;
-            nc = nc || (row && fabsf(r1 - rc[g][v]) >= a.st.atol);
-            hb = hb || (row && a.st.check_hard && r1 >= a.st.hard_stop);
-            rp[g][v] = row ? rc[g][v] : rp[g][v];
-            rc[g][v] = row ? r1 : rc[g][v];
-            rnew[v] = (er + v < M) ? rc[g][v] : 0.f;
+            r1[v] = rc[g][v] + (-rc[g][v] + ff[v]) * eps[v];                   // ssnode.c:64-67
+            dabs[v] = rowok[v] ? fabsf(r1[v] - rc[g][v]) : -1.f;               // rows beyond M never "not converged"
         }
-        short* fw = reinterpret_cast<short*>(&flags[it % 3][4 * g + j]);
-        if (nc) fw[0] = 1;
-        if (hb) fw[1] = 1;
-        if (upd && er < M) *reinterpret_cast<mf4*>(&rbuf[(it + 1) & 1][4 * g + j][er]) = (mf4){rnew[0], rnew[1], rnew[2], rnew[3]};
         if (sw == 0 && lane < 4) flags[(it + 1) % 3][4 * g + lane] = 0;
+        // one lane-divergent region for everything a stopped (or absent) stimulus must not do
+        if (live[g] && !((frozen >> (4 * g + j)) & 1u) && er < M) {
+            const float dmax = fmaxf(fmaxf(dabs[0], dabs[1]), fmaxf(dabs[2], dabs[3]));
+            const float rmax = fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3]));   // rows beyond M hold 0
+            short* fw = reinterpret_cast<short*>(&flags[it % 3][4 * g + j]);
+            if (dmax >= a.st.atol) fw[0] = 1;
+            if (a.st.check_hard && rmax >= a.st.hard_stop) fw[1] = 1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { rp[g][v] = rc[g][v]; rc[g][v] = rowok[v] ? r1[v] : rc[g][v]; }
+            *reinterpret_cast<mf4*>(&rbuf[(it + 1) & 1][4 * g + j][er]) = (mf4){rc[g][0], rc[g][1], rc[g][2], rc[g][3]};
+        }
     };
     __syncthreads();
     for (int it = 0; it <= max_iter; ++it) {
-        int4 f4 = {0, 0, 0, 0};
+        int f4 = 0;
         if (it >= 1) f4 = flags_read(G0, it - 1);                               // phase 2 it: serial part of (1, it - 1)
         if (it >= 1) serial(G1, it - 1);
         if (it >= 1) verdict(G0, it - 1, f4);
@@ -774,13 +765,11 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
             a.r[unit * M + er + v] = rc[g][v];
             if (a.r_prev) a.r_prev[unit * M + er + v] = rp[g][v];
         }
-        if (sw == 0 && blk == 0) {
-            int c = 1, n = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) if (q == s) { c = code[q]; n = nsteps[q]; }
-            a.codes[unit] = c;
-            if (a.steps) a.steps[unit] = n;
-        }
+    }
+    if (sw == 0 && lane < 8 && s0 + lane < a.NB) {
+        const size_t unit = (size_t)b * a.NB + s0 + lane;
+        a.codes[unit] = my_code;
+        if (a.steps) a.steps[unit] = my_steps;
     }
 }
 

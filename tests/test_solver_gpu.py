@@ -217,6 +217,13 @@ def test_variants_agree_and_edge_shapes(oracle_lib):
     for bb in range(B):
         want, _, _ = _oracle_batch(oracle_lib, Ws[bb:bb + 1], extb[bb], 'asym_tanh', 100, 0.0, r0=r0[bb:bb + 1])
         np.testing.assert_allclose(a.x[bb:bb + 1], want, rtol=RTOL64)
+    # a batch large enough for the library to pick the MFMA solver by itself: same answers as the tile kernel
+    Wl, extl = _inputs(70, 200, 8, seed=11)
+    auto = fixed_points_batch(Wl, extl, P['k'], P['n'], max_iter=40, atol=0.0, dtype='float32')
+    tile = fixed_points_batch(Wl, extl, P['k'], P['n'], max_iter=40, atol=0.0, dtype='float32', variant=2)
+    np.testing.assert_array_equal(auto.codes, tile.codes)
+    np.testing.assert_array_equal(auto.steps, tile.steps)
+    np.testing.assert_allclose(auto.x, tile.x, rtol=1e-4, atol=1e-6)
     # empty batch, zero iterations
     e = fixed_points_batch(np.zeros((0, 4, 4)), np.ones((2, 4)), P['k'], P['n'])
     assert e.x.shape == (0, 2, 4)
