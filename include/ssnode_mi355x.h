@@ -112,7 +112,10 @@ int ssn_solve_batch_f64(const double *W, const double *ext, int ext_per_draw,
                         int B, int NB, int M, const ssn_solver_params *p, void *stream);
 /* Force a kernel variant (testing / A-B benchmarking): 0 = generic streaming
  * kernel, 1 = register-stationary DPP kernel, 2 = register-stationary tile kernel
- * (error if the size has no instantiation), negative = automatic. */
+ * (shape chosen by the library), 3 = tile kernel with split VGPR/LDS residency,
+ * 4 = tile kernel with the whole tile in VGPRs, 5 = fp32 MFMA kernel (NB >= 4);
+ * error if the size has no instantiation; negative = automatic (MFMA kernel for
+ * large fp32 batches with NB >= 4, otherwise tile > DPP > streaming). */
 int ssn_solve_batch_f32_variant(int variant, const float *W, const float *ext, int ext_per_draw,
                                 float *r, float *r_prev, int *codes, int *steps,
                                 int B, int NB, int M, const ssn_solver_params *p, void *stream);

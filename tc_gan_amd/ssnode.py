@@ -281,7 +281,8 @@ def fixed_points_batch(
     exts : (NB, 2N), shared by every draw, or (B, NB, 2N)
     r0 : None (zeros), (2N,), or (B, NB, 2N)
     dtype : 'float64' (reference arithmetic) or 'float32' (fast path)
-    variant : None (auto), 0 streaming, 1 register-stationary DPP, 2 tile, 3 tile with 5 rows per lane, 4 tile with 7
+    variant : None (auto), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by the library), 3 tile with
+        split VGPR/LDS residency, 4 tile with the whole tile in VGPRs, 5 fp32 MFMA kernel (NB >= 4)
 
     Returns `BatchResult` with ``x`` (B, NB, 2N) newest states, ``codes`` and
     ``steps`` (B, NB) -- codes as the C solver: 0 converged, 1 max_iter,
