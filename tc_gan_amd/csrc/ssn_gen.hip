@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) gen_backward_kernel(GenB
             // opaque per iteration: otherwise trj + lo is hoisted as a loop-invariant 64-bit VGPR pair per stream
             // (registers this kernel does not have) instead of SGPR base + 32-bit VGPR offset addressing
             asm volatile("" : "+v"(lo[s]));
-            xmm[s] = (live[s] && tau >= 3) ? (trj + (size_t)(tau - 3) * M)[lo[s]] : (T)0;
+            // (x_{tau-2} is only used inside the penalty window, by the steps tau-1 .. tau-3 >= skip + 1)
+            xmm[s] = (live[s] && tau >= 3 && tau >= a.skip + 3) ? (trj + (size_t)(tau - 3) * M)[lo[s]] : (T)0;
             dfn[s] = (live[s] && tau >= 2) ? (dlt + (size_t)(tau - 2) * M)[lo[s]] : (T)0;
         }
 #pragma unroll

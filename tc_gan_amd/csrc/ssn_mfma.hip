@@ -540,7 +540,9 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
         // HBM reads run TWO serial parts ahead (a serial part is too short to cover their latency): issued here,
         // consumed at the end of serial(tau - 1); what this call consumes was issued by serial(tau + 1)
         float nxm[4] = {0.f, 0.f, 0.f, 0.f}, ndf[4] = {0.f, 0.f, 0.f, 0.f};
-        if (tau >= 4) load4(rs_traj, at_step(g, tau - 4), nxm);
+        // x_{tau-3} is used by the serial parts of steps tau-2 .. tau-4, and only inside the penalty window
+        // (steps >= skip + 1): before the window the trajectory is not read at all
+        if (tau >= 4 && tau >= a.skip + 3) load4(rs_traj, at_step(g, tau - 4), nxm);
         if (tau >= 3) load4(rs_dlt, at_step(g, tau - 3), ndf);
         if (tau < T_) {
             mf4 acc;                                                                  // W^T delta_{tau+1}
