@@ -371,6 +371,28 @@ def _classify_round(x, codes, steps):
     return out, err
 
 
+def _solve_round(Ws, exts, dtype, kwargs):
+    """One round of candidate draws.  Under torch.distributed (world size G > 1, every rank running the same finder
+    on the same generator) the draws are dealt round-robin -- rank r solves draws r, r + G, ... -- and the per-draw
+    results are exchanged with one all-gather, so that every rank applies the "first `num` successes in submission
+    order" rule to the same complete round and returns the same sample (SURVEY section 8e)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return fixed_points_batch(Ws, exts, dtype=dtype, **kwargs)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = np.arange(rank, len(Ws), world)
+    local = fixed_points_batch(Ws[mine], exts, dtype=dtype, **kwargs)
+    parts = [None] * world
+    dist.all_gather_object(parts, (np.asarray(local.x), np.asarray(local.codes), np.asarray(local.steps)))
+    x = np.empty((len(Ws),) + parts[0][0].shape[1:], dtype=parts[0][0].dtype)
+    codes = np.empty((len(Ws),) + parts[0][1].shape[1:], dtype=parts[0][1].dtype)
+    steps = np.empty((len(Ws),) + parts[0][2].shape[1:], dtype=parts[0][2].dtype)
+    for r, (px, pc, ps) in enumerate(parts):
+        idx = np.arange(r, len(Ws), world)
+        x[idx], codes[idx], steps[idx] = px, pc, ps
+    return BatchResult(x, codes, steps, None)
+
+
 def find_fixed_points_batched(num, Z_W_gen, exts, resubmit_threshold=0,
                               deterministic=True, no_pool=False, check=False,
                               dtype='float64', round_size=None,
@@ -395,7 +417,7 @@ def find_fixed_points_batched(num, Z_W_gen, exts, resubmit_threshold=0,
             break
         consumed += len(batch)
         Ws = np.stack([np.asarray(W, dtype='double') for _, W in batch])
-        res = fixed_points_batch(Ws, exts, dtype=dtype, **common_kwargs)
+        res = _solve_round(Ws, exts, dtype, common_kwargs)
         verdicts, err = _classify_round(res.x, res.codes, res.steps)
         for b, (ok, code) in enumerate(verdicts):
             used += 1

@@ -62,6 +62,27 @@ def _train_moments(n_steps=3):
             np.concatenate([np.ravel(i.gen_moments) for i in infos]), np.array([i.loss for i in infos]))
 
 
+def _find_fixed_points():
+    """Rejection sampling of fixed points (truth data): some draws fail at the rate bound, so the accepted set
+    depends on the global submission order."""
+    from oracle import ssn_numpy as on          # weights / stimuli only
+    from tc_gan_amd.ssnode import find_fixed_points
+    N = 24
+    jds = on.new_JDS()
+    rs = np.random.RandomState(3)
+
+    def gen():
+        while True:
+            z = rs.rand(2 * N, 2 * N)
+            # every third draw is scaled up so that its dynamics blow past the rate bound (rejected, code 2)
+            scale = 40.0 if rs.rand() < 0.35 else 1.0
+            yield z, on.generate_weight(N, jds['J'] * scale, jds['D'], jds['S'], z)
+    exts = on.stimulus_input([0.25, 1.0], np.linspace(-.5, .5, N), 1 / 32., [20.])
+    zs, xs, info = find_fixed_points(9, gen(), exts, k=0.01, n=2.2, io_type='asym_power', rate_stop_at=2000.,
+                                     max_iter=3000, atol=1e-6, dtype='float64')
+    return zs.ravel(), xs.ravel(), np.array([info.rejections, info.unused] + [info.counter.get(c, 0) for c in (1, 2)])
+
+
 def _worker(rank, world, port, out, what='gan'):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -69,7 +90,7 @@ def _worker(rank, world, port, out, what='gan'):
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = _train() if what == 'gan' else _train_moments()
+    res = {'gan': _train, 'moments': _train_moments, 'find': _find_fixed_points}[what]()
     out.put((rank,) + res)
     dist.barrier()
     dist.destroy_process_group()
@@ -114,3 +135,23 @@ def test_two_ranks_moment_matching_follows_the_single_process_run():
         np.testing.assert_allclose(res[r][2], moments1, rtol=2e-4, atol=1e-7)
         np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_two_ranks_find_the_same_fixed_point_sample():
+    sys.path.insert(0, ROOT)
+    zs1, xs1, counts1 = _find_fixed_points()
+    assert counts1[0] > 0                      # the case has rejections
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 27700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, 'find')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_array_equal(res[r][1], zs1)            # the same draws accepted, in the same order
+        np.testing.assert_allclose(res[r][2], xs1, rtol=1e-12)
+        np.testing.assert_array_equal(res[r][3], counts1)
