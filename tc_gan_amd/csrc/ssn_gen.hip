@@ -258,7 +258,9 @@ static int gen_pick_c(int M, int elem_bytes) {
     else                 { for (int c : ladder64) if (need <= c) return c; }
     return 0;
 }
-template <typename T> bool gen_supported(int M) { return (M % 2 == 0) && gen_pick_c(M, (int)sizeof(T)) != 0; }
+template <typename T> bool gen_supported(int M) {
+    return (M % 2 == 0) && (gen_pick_c(M, (int)sizeof(T)) != 0 || gen_stream_supported(M));
+}
 template bool gen_supported<float>(int);
 template bool gen_supported<double>(int);
 
@@ -300,16 +302,19 @@ static hipError_t launch_gen_c(const Args& a, hipStream_t st) {
             case 19: return launch_gen_nb<T, 19, FWD>(a, st);
             case 25: return launch_gen_nb<T, 25, FWD>(a, st);
             case 26: return launch_gen_nb<T, 26, FWD>(a, st);
-            default: return hipErrorInvalidValue;
+            default: break;
         }
     } else {
         switch (c) {
             case 4: return launch_gen_nb<T, 4, FWD>(a, st);
             case 8: return launch_gen_nb<T, 8, FWD>(a, st);
             case 13: return launch_gen_nb<T, 13, FWD>(a, st);
-            default: return hipErrorInvalidValue;
+            default: break;
         }
     }
+    // sizes without a register-resident instantiation: streaming kernels (ssn_gen_stream.hip)
+    if constexpr (FWD) return launch_gen_forward_stream<T>(a, st);
+    else return launch_gen_backward_stream<T>(a, st);
 }
 
 template <typename T> hipError_t launch_gen_forward(const GenFwdArgs<T>& a, hipStream_t st) { return launch_gen_c<T, true>(a, st); }

@@ -69,6 +69,10 @@ hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st);
 
 // ssn_gen.hip
 template <typename T> bool gen_supported(int M);
+// ssn_gen_stream.hip: any even 2N <= 2048 (fallback, W streamed from memory every step)
+bool gen_stream_supported(int M);
+template <typename T> hipError_t launch_gen_forward_stream(const GenFwdArgs<T>& a, hipStream_t st);
+template <typename T> hipError_t launch_gen_backward_stream(const GenBwdArgs<T>& a, hipStream_t st);
 template <typename T> hipError_t launch_gen_forward(const GenFwdArgs<T>& a, hipStream_t st);
 template <typename T> hipError_t launch_gen_backward(const GenBwdArgs<T>& a, hipStream_t st);
 template <typename T> hipError_t launch_jds_grad(const T* gW, const T* z, const T* jds12, double* out, int B, int N, hipStream_t st);
