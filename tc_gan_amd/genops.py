@@ -85,8 +85,9 @@ def weight_grad(delta, traj):
     return torch.bmm(delta.reshape(B, NB * T, M).transpose(1, 2), traj.reshape(B, NB * T, M))
 
 
-def jds_grad(gW, z, J, D, S):
-    """Chain rule through make_W_with_x: returns (gJ, gD, gS) as float64 numpy (2, 2) arrays."""
+def jds_grad(gW, z, J, D, S, as_tensor=False):
+    """Chain rule through make_W_with_x: returns (gJ, gD, gS) as float64 (2, 2) arrays -- numpy by default, CUDA
+    tensors with ``as_tensor=True`` (no host synchronisation)."""
     clib.require_gpu()
     B, M, _ = gW.shape
     N = M // 2
@@ -96,5 +97,8 @@ def jds_grad(gW, z, J, D, S):
     rc = getattr(libssnode, 'ssn_jds_grad_' + suffix)(gW.contiguous().data_ptr(), z.contiguous().data_ptr(),
                                                       arrs[0], arrs[1], arrs[2], out.data_ptr(), B, N, _stream())
     clib.check(rc, 'ssn_jds_grad_' + suffix)
-    tot = out.sum(dim=0).cpu().numpy()           # (4, 3), fixed summation order
+    tot = out.sum(dim=0)                         # (4, 3), fixed summation order
+    if as_tensor:
+        return tot[:, 0].reshape(2, 2), tot[:, 1].reshape(2, 2), tot[:, 2].reshape(2, 2)
+    tot = tot.cpu().numpy()
     return tot[:, 0].reshape(2, 2), tot[:, 1].reshape(2, 2), tot[:, 2].reshape(2, 2)

@@ -218,6 +218,7 @@ class ConditionalBPTTWassersteinGAN(object):
         self.param_bounds = param_bounds          # {'J': (min, max), ...}  (wgan.py:244-251)
         self.rng = as_randomstate(seed)
         self._predrawn = None          # host draws of the NEXT critic step, made early (see train_generator)
+        self._gparams_host = {}        # host values the device copies of the generator parameters correspond to
         self._rng_before_predraw = None
         self.reducer = GradientAllReducer()
         assert self.probes_per_model < gen.num_neurons
@@ -380,21 +381,33 @@ class ConditionalBPTTWassersteinGAN(object):
             xg = gen_out.prober_tuning_curve.to(torch.float32)
             nb = xg.shape[0]
             gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
-            gdict = self.gen.backward(gx, self.dynamics_cost, self.rate_cost)
+            gdict = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, as_tensor=True)
             loss = (-dmean.to(torch.float64) + self.dynamics_cost * gen_out.model_dynamics_penalty
                     + self.rate_cost * gen_out.model_rate_penalty).reshape(1).to(torch.float32)
-            grads = torch.as_tensor(np.concatenate([np.ravel(gdict[name]) for name in self._pnames]), device='cuda',
-                                    dtype=torch.float32)
+            grads = torch.cat([gdict[name].reshape(-1) for name in self._pnames]).to(torch.float32)
             self.reducer.mean_(grads, loss)
+            # Everything up to here is queued without a host wait; the device copies of the parameters are the
+            # working values (re-uploaded only when somebody changed the generator's attributes from outside), and ONE
+            # device-to-host copy at the end returns the new parameter values together with the loss.
             off = 0
             for name in self._pnames:                                            # wgan.py:218-260
-                value = np.array(getattr(self.gen, name), dtype='float32')      # (copy: the source may be read-only)
+                value = np.asarray(getattr(self.gen, name))
                 p = self._gparams[name]
-                p.copy_(torch.from_numpy(value.ravel()))
+                cached = self._gparams_host.get(name)
+                if cached is None or cached.shape != value.shape or not np.array_equal(cached, value):
+                    p.copy_(to_device(np.ascontiguousarray(value, dtype='float32').ravel()))
                 self.gen_updaters[name](p, grads[off:off + p.numel()], clip=self.param_bounds[name])
                 off += p.numel()
-                setattr(self.gen, name, p.cpu().numpy().astype('float64').reshape(value.shape))
-            info.gen_loss = float(loss[0])
+            host = torch.cat([self._gparams[name] for name in self._pnames] + [loss]).cpu().numpy()
+            off = 0
+            for name in self._pnames:
+                shape = np.shape(getattr(self.gen, name))
+                n = int(np.prod(shape, dtype=int))
+                new = host[off:off + n].astype('float64').reshape(shape)
+                setattr(self.gen, name, new)
+                self._gparams_host[name] = new.copy()
+                off += n
+            info.gen_loss = float(host[-1])
         info.gen_forward_time = self.gen_forward_watch.sum()
         info.gen_train_time = self.gen_train_watch.sum()
         info.gen_time = info.gen_train_time + info.gen_forward_time

@@ -237,32 +237,41 @@ class TuningCurveGenerator(object):
             self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr, zin=self._zin, ext_base=self._ext_base)
         return out
 
-    def backward(self, g_tuning_curve, dynamics_cost, rate_cost):
+    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False):
         """BPTT: gradient of  sum(g_tuning_curve * tuning_curve) + dynamics_cost * dynamics_penalty
         + rate_cost * rate_penalty  w.r.t. the generator parameters (dict: J, D, S[, V]), for the last
-        ``forward(save=True)`` call."""
+        ``forward(save=True)`` call.  float64 numpy arrays by default; with ``as_tensor=True`` float64 CUDA tensors
+        and no host synchronisation anywhere in the call (the GAN loop keeps queuing work behind it)."""
         sv = self._saved
         fwd = sv['fwd']
-        g_ta = torch.zeros_like(fwd['time_avg'])
-        g = g_tuning_curve.to(g_ta.dtype)
+        g = g_tuning_curve.to(fwd['time_avg'].dtype)
         if self.conditional:
             # scatter-add of the probe gather (several samples may probe the same model/neuron):
-            # tuning_curve[n, :] = time_avg[ids[n], :, probes[n]]
-            g_ta.permute(0, 2, 1).index_put_((sv['ids'], sv['probes']), g, accumulate=True)
+            # tuning_curve[n, :] = time_avg[ids[n], :, probes[n]].  index_add_ on the (model, neuron)-major view:
+            # atomics, no sort and no host wait (index_put_(accumulate=True) sorts the indices and synchronises)
+            B, NB, M = fwd['time_avg'].shape
+            g_mn = torch.zeros((B * M, NB), device=g.device, dtype=g.dtype)
+            g_mn.index_add_(0, sv['ids'] * M + sv['probes'], g)
+            g_ta = g_mn.reshape(B, M, NB).permute(0, 2, 1).contiguous()
         else:
+            g_ta = torch.zeros_like(fwd['time_avg'])
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
         res = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
                                   rate_cost / fwd['n_rate'], sv['gp'], want_g_ext=self.heteroin)
         delta, g_ext = res if self.heteroin else (res, None)
         gW = genops.weight_grad(delta, fwd['traj'])
-        gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S)
+        gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S, as_tensor=as_tensor)
         grads = dict(J=gJ, D=gD, S=gS)
         if self.heteroin:
             # ext = (1 + v_pop z_in) ext_base  ->  dL/dv_pop = sum over the population of g_ext * ext_base * z_in
             B, NB, M = g_ext.shape
             per = (g_ext.to(torch.float64) * sv['ext_base'].to(torch.float64) * sv['zin'].to(torch.float64)[:, None, :])
-            gv = per.reshape(B, NB, 2, M // 2).sum(dim=(0, 1, 3)).cpu().numpy()
-            grads['V'] = gv if self.ssn_type == 'heteroin' else np.asarray(gv.sum())
+            gv = per.reshape(B, NB, 2, M // 2).sum(dim=(0, 1, 3))
+            if as_tensor:
+                grads['V'] = gv if self.ssn_type == 'heteroin' else gv.sum().reshape(())
+            else:
+                gv = gv.cpu().numpy()
+                grads['V'] = gv if self.ssn_type == 'heteroin' else np.asarray(gv.sum())
         self._saved = None
         return grads
 
