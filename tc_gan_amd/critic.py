@@ -206,6 +206,17 @@ class Updater(object):
             self._state = tuple(torch.as_tensor(np.asarray(d[k]), device='cuda', dtype=torch.float32).contiguous()
                                 for k in ('m', 'v'))
 
+    def snapshot(self, params):
+        """Device copies of everything one update changes (no host wait): see `restore`."""
+        st = self._state
+        return (params.clone(), self.step, None if st is None else (st[0].clone(), st[1].clone()))
+
+    def restore(self, params, snap):
+        """Undo the updates made since `snapshot`."""
+        params.copy_(snap[0])
+        self.step = snap[1]
+        self._state = snap[2]
+
     def __call__(self, params, grads, clip=None):
         """In-place update of the flat device tensor `params` from `grads`."""
         if self._state is None or self._state[0].shape != params.shape:

@@ -314,12 +314,11 @@ class ConditionalBPTTWassersteinGAN(object):
         xp = eps * xd + (1 - eps) * xg.to(torch.float32)                      # cwgan.py:481
         ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
         ctx.skipped = False
-        bound = self.disc_rate_penalty_bound
-        if bound > 0 and float(pens[0]) > bound:                                # cwgan.py:493-498 (needs the value now)
-            ctx.skipped = True
-            ctx.host = torch.cat([pens, pens.new_full((2,), float('nan'))]).cpu()
-            ctx.event = None
-            return
+        # cwgan.py:493-498 skips the critic update when the rate penalty of the batch exceeds `disc_rate_penalty_bound`.
+        # Waiting for that value here would stall the queue at every critic step, so the update is made
+        # speculatively and rolled back in `_read_disc` (which learns the value before the next update is queued)
+        # in the rare case that the bound was exceeded.
+        ctx.snapshot = self.disc_updater.snapshot(self.disc.params) if self.disc_rate_penalty_bound > 0 else None
         with self.disc_train_watch:
             stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
             self.reducer.mean_(self.disc.grads, stats)
@@ -337,6 +336,11 @@ class ConditionalBPTTWassersteinGAN(object):
         if ctx.event is not None:
             ctx.event.synchronize()
         host = ctx.host.numpy()
+        if ctx.snapshot is not None and float(host[0]) > self.disc_rate_penalty_bound:
+            self.disc_updater.restore(self.disc.params, ctx.snapshot)            # the skipped step of cwgan.py:493-498
+            ctx.skipped = True
+            host = np.array([host[0], host[1], np.nan, np.nan], dtype='float32')
+        ctx.snapshot = None
         info.gen_out = ctx.gen_out
         info.xd, info.xg, info.xp = ctx.xd, ctx.xg, ctx.xp
         info.cd = info.cg = info.cp = ctx.cd

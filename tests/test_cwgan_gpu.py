@@ -129,6 +129,9 @@ def test_device_noise_mode_runs_and_rate_bound_skips_critic():
     info = next(gan.learning())
     assert info.is_discriminator and np.isnan(info.disc_loss) and np.isnan(info.accuracy)
     np.testing.assert_array_equal(gan.disc.get_flat(), before)
+    assert gan.disc_updater.step == 0              # the speculative update was rolled back, optimizer state included
+    st = gan.disc_updater._state
+    assert st is None or float(st[0].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize('ssn_type,V0', [('heteroin', [0.3, 0.1]), ('deg-heteroin', 0.4)])
