@@ -535,14 +535,18 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
         if (T_ >= 2) load4(rs_dlt, at_step(g, T_ - 2), pdf[g]); else { for (int v = 0; v < 4; ++v) pdf[g][v] = 0.f; }
     }
     // serial part of (group g, step tau): first = no matrix result yet (tau == T)
-    auto serial = [&](auto G, int tau) {
+    // WIN: step inside the penalty window (tau >= skip + 1): only there the trajectory enters (direct gradient of the
+    // three loss terms); before the window the serial part is the bare adjoint recurrence and x is neither read nor kept.
+    auto serial = [&](auto G, auto WIN, int tau) {
         constexpr int g = decltype(G)::value;
+        constexpr bool win_on = decltype(WIN)::value;
         // HBM reads run TWO serial parts ahead (a serial part is too short to cover their latency): issued here,
         // consumed at the end of serial(tau - 1); what this call consumes was issued by serial(tau + 1)
         float nxm[4] = {0.f, 0.f, 0.f, 0.f}, ndf[4] = {0.f, 0.f, 0.f, 0.f};
-        // x_{tau-3} is used by the serial parts of steps tau-2 .. tau-4, and only inside the penalty window
-        // (steps >= skip + 1): before the window the trajectory is not read at all
-        if (tau >= 4 && tau >= a.skip + 3) load4(rs_traj, at_step(g, tau - 4), nxm);
+        if constexpr (win_on) {
+            // x_{tau-3} is used by the serial parts of steps tau-2 .. tau-4, and only inside the window
+            if (tau >= 4 && tau >= a.skip + 3) load4(rs_traj, at_step(g, tau - 4), nxm);
+        }
         if (tau >= 3) load4(rs_dlt, at_step(g, tau - 3), ndf);
         if (tau < T_) {
             mf4 acc;                                                                  // W^T delta_{tau+1}
@@ -553,8 +557,8 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
         float delta[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            float gg = 0.f;                      // direct gradient of the loss w.r.t. x_tau (window: tau >= skip + 1)
-            if (tau >= a.skip + 1) {
+            float gg = 0.f;                      // direct gradient of the loss w.r.t. x_tau
+            if constexpr (win_on) {
                 gg = gta[g][v] + ((xc[g][v] > a.theta) ? a.c_rate : 0.f);
                 if (tau <= T_ - 1) gg -= 2.f * a.c_dyn * (xn[g][v] - xc[g][v]);
                 if (tau >= a.skip + 2) gg += 2.f * a.c_dyn * (xc[g][v] - xm[g][v]);
@@ -563,19 +567,31 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
             delta[v] = (er + v < M) ? eps[v] * dfc[g][v] * at : 0.f;
             carry[g][v] = fmaf(-eps[v], at, at);                                       // (1 - eps) a_t
             dsum[g][v] += delta[v];
-            xn[g][v] = xc[g][v]; xc[g][v] = xm[g][v]; xm[g][v] = pxm[g][v]; dfc[g][v] = pdf[g][v];
-            pxm[g][v] = nxm[v]; pdf[g][v] = ndf[v];
+            if constexpr (win_on) {
+                xn[g][v] = xc[g][v]; xc[g][v] = xm[g][v]; xm[g][v] = pxm[g][v]; pxm[g][v] = nxm[v];
+            }
+            dfc[g][v] = pdf[g][v];
+            pdf[g][v] = ndf[v];
         }
         if (live[g] && er < M) *reinterpret_cast<mf4*>(&dbuf[4 * g + j][er]) = (mf4){delta[0], delta[1], delta[2], delta[3]};
         if (tau >= 2) store4(rs_dlt, at_step(g, tau - 2), delta);                      // shifted: pairs with x_{tau-1}
     };
     constexpr std::integral_constant<int, 0> G0{};
     constexpr std::integral_constant<int, 1> G1{};
+    constexpr std::integral_constant<bool, false> W0{};
+    constexpr std::integral_constant<bool, true> W1{};
     __syncthreads();
-    for (int i = 0; i < T_; ++i) {
-        serial(G0, T_ - i);                           // phase 2 i
+    int tau = T_;
+    for (; tau >= a.skip + 1 && tau >= 1; --tau) {    // window steps first (time runs backwards)
+        serial(G0, W1, tau);                          // phase 2 (T - tau)
         __syncthreads();
-        serial(G1, T_ - i);                           // phase 2 i + 1
+        serial(G1, W1, tau);                          // phase 2 (T - tau) + 1
+        __syncthreads();
+    }
+    for (; tau >= 1; --tau) {
+        serial(G0, W0, tau);
+        __syncthreads();
+        serial(G1, W0, tau);
         __syncthreads();
     }
     if (a.g_ext) {
