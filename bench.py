@@ -196,7 +196,8 @@ def run_c3(args, rank, world, local_rank, paper=False):
         # fp32-input MFMA (v_mfma_f32_4x4x1) peak = fp32 vector peak = 157.3 TFLOP/s (MI355X_MICROARCH.md)
         'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
-                     'kernel': 'gen_forward_mfma_kernel (fp32 MFMA)' if not paper else 'gen_forward_kernel (tile, VALU)',
+                     'kernel': 'gen_forward_mfma_kernel (fp32 MFMA)' if not paper else
+                               'gen_forward_mfma_kernel (fp32 MFMA, one 4-stimulus group per workgroup)',
                      'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8,
                      'ssn_steps_per_s_in_loop': 7 * units * iters_per_s * world},
         'last_gen_loss': info.gen_loss,

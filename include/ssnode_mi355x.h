@@ -165,7 +165,8 @@ typedef struct ssn_gen_params {
     int io_type;                 /* SSN_IO_* */
     int seqlen;                  /* T: Euler steps from r = 0 */
     int skip_steps;              /* first output index of the measurement window */
-    int kernel;                  /* 0 library default, 1 VALU tile kernels, 2 MFMA kernels (fp32, NB >= 4) */
+    int kernel;                  /* 0 library default, 1 VALU tile kernels, 2 MFMA kernels (fp32, NB >= 4), 3 MFMA
+                                  * kernels with one 4-stimulus group per workgroup (few draws: more workgroups) */
     double k, n;
     double tau_E, tau_I, dt;     /* eps = dt / tau per neuron */
     double rate_soft_bound, rate_hard_bound;

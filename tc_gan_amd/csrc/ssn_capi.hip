@@ -169,6 +169,19 @@ ssn::IoConsts<T> gen_io_consts(const ssn_gen_params& g) {
     return ssn::make_io_consts<T>(p);
 }
 
+// MFMA generator kernels: 0 = not used, else the number of 4-stimulus groups per workgroup.  kernel: 0 automatic
+// (two groups when that already gives >= 192 workgroups, one group when only that fills the chip -- 128 draws x 8
+// stimuli of the paper's runs -- else the tile kernels, which run one workgroup per (draw, stimulus)), 1 tile kernels,
+// 2 MFMA with two groups per workgroup, 3 MFMA with one group per workgroup.
+static int mfma_groups_for(int kernel, bool mfma_ok, int B, int NB) {
+    if (kernel == 2) return 2;
+    if (kernel == 3) return 1;
+    if (kernel != 0 || !mfma_ok) return 0;
+    if ((long)B * ((NB + 7) / 8) >= 192) return 2;
+    if ((long)B * ((NB + 3) / 4) >= 192) return 1;
+    return 0;
+}
+
 template <typename T>
 int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_row, T* traj, T* df, int B, int NB,
                      int M, const ssn_gen_params* g, void* stream) {
@@ -185,13 +198,14 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
     a.eps_E = (T)(g->dt / g->tau_E); a.eps_I = (T)(g->dt / g->tau_I); a.theta = (T)g->rate_penalty_threshold;
     a.io = gen_io_consts<T>(*g);
     if constexpr (sizeof(T) == 4) {
-        const bool mfma_ok = ssn::gen_mfma_supported(M, NB);
-        if (g->kernel == 2 && !mfma_ok) {
+        // (trajectory stores address one draw's block with 32-bit byte offsets)
+        const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (!traj || (long)NB * g->seqlen * M < (1L << 29));
+        if ((g->kernel == 2 || g->kernel == 3) && !mfma_ok) {
             g_last_error = "ssn_gen_forward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
         }
-        // default: the MFMA kernel needs one workgroup per (draw, 8 stimuli) on most CUs to pay off
-        if (g->kernel == 2 || (g->kernel == 0 && mfma_ok && (long)B * ((NB + 7) / 8) >= 192)) {
+        if (const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB)) {
+            a.mfma_groups = groups;
             SSN_TRY(ssn::launch_gen_forward_mfma(a, (hipStream_t)stream));
             return 0;
         }
@@ -216,11 +230,12 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
     a.c_dyn = (T)c_dyn; a.c_rate = (T)c_rate;
     if constexpr (sizeof(T) == 4) {
         const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (long)NB * g->seqlen * M < (1L << 29);
-        if (g->kernel == 2 && !mfma_ok) {
+        if ((g->kernel == 2 || g->kernel == 3) && !mfma_ok) {
             g_last_error = "ssn_gen_backward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
         }
-        if (g->kernel == 2 || (g->kernel == 0 && mfma_ok && (long)B * ((NB + 7) / 8) >= 192)) {
+        if (const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB)) {
+            a.mfma_groups = groups;
             SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
             return 0;
         }

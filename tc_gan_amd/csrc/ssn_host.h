@@ -32,6 +32,7 @@ struct GenFwdArgs {
     int B, NB, M, seqlen, skip;
     T eps_E, eps_I, theta;
     IoConsts<T> io;
+    int mfma_groups = 2;   // MFMA kernels: stimulus groups of 4 per workgroup (2, or 1 to spread few draws over the chip)
 };
 // BPTT adjoint sweep (ssn_gen.hip)
 template <typename T>
@@ -43,6 +44,7 @@ struct GenBwdArgs {
     T* g_ext;              // [B][NB][M] or nullptr: dL/d ext = sum_t delta_t
     int B, NB, M, seqlen, skip;
     T eps_E, eps_I, theta, c_dyn, c_rate;
+    int mfma_groups = 2;
 };
 template <typename T>
 struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };

@@ -262,9 +262,10 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     // accumulator hand-off: slab form [group][matrix wave][lane], K-split form [group][slot][stimulus]
     __shared__ __align__(16) mf4 abuf[2][KSP ? KS::SLOTS * 4 : 4 * 64];
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
-    const int ngroups = (a.NB + 7) / 8;
+    const int gpw = a.mfma_groups;                // stimulus groups of 4 in this workgroup (2; 1: group 1 idle)
+    const int ngroups = (a.NB + 4 * gpw - 1) / (4 * gpw);
     const int b = blockIdx.x / ngroups;
-    const int s0 = (blockIdx.x % ngroups) * 8;
+    const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (int)(blockDim.x >> 7);        // matrix waves (= serial waves)
     const int blk = lane >> 2, j = lane & 3;
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
             for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             __syncthreads();
             for (int p = 0; p < nphase; ++p) {
-                if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
+                if (p < 2 * T_ && (p & 1) < gpw && !(SSN_MFMA_ABLATE & 2)) {
                     const int g = p & 1, it = p >> 1;
                     const unsigned base = rb0 + (unsigned)((((it & 1) * 8 + 4 * g) * RS) * 4);
                     unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
             slab_load<MK, false>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
             __syncthreads();
             for (int p = 0; p < nphase; ++p) {
-                if (p < 2 * T_ && !(SSN_MFMA_ABLATE & 2)) {
+                if (p < 2 * T_ && (p & 1) < gpw && !(SSN_MFMA_ABLATE & 2)) {
                     const int g = p & 1, it = p >> 1;
                     abuf[g][wave * 64 + lane] = slab_chain<MK>(wr, &rbuf[it & 1][4 * g + j][0]);
                 }
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int s = s0 + 4 * g + j;
-        live[g] = s < a.NB;
+        live[g] = s < a.NB && g < gpw;
         toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -394,13 +395,13 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     for (int it = 0; it < nskip; ++it) {
         if (!(SSN_MFMA_ABLATE & 1)) serial(G0, W0, it);     // phase 2 it + 1
         __syncthreads();
-        if (!(SSN_MFMA_ABLATE & 1)) serial(G1, W0, it);     // phase 2 it + 2
+        if (!(SSN_MFMA_ABLATE & 1) && gpw == 2) serial(G1, W0, it);     // phase 2 it + 2
         __syncthreads();
     }
     for (int it = nskip; it < T_; ++it) {
         if (!(SSN_MFMA_ABLATE & 1)) serial(G0, W1, it);
         __syncthreads();
-        if (!(SSN_MFMA_ABLATE & 1)) serial(G1, W1, it);
+        if (!(SSN_MFMA_ABLATE & 1) && gpw == 2) serial(G1, W1, it);
         __syncthreads();
     }
 
@@ -432,9 +433,10 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
     __shared__ __align__(16) float dbuf[8][RS];          // delta_tau per stimulus, contiguous in the neuron index
     __shared__ __align__(16) mf4 abuf[2][KSP ? KS::SLOTS * 4 : 4 * 64];    // hand-off, as in the forward kernel
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
-    const int ngroups = (a.NB + 7) / 8;
+    const int gpw = a.mfma_groups;
+    const int ngroups = (a.NB + 4 * gpw - 1) / (4 * gpw);
     const int b = blockIdx.x / ngroups;
-    const int s0 = (blockIdx.x % ngroups) * 8;
+    const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = (int)(blockDim.x >> 7);
     const int blk = lane >> 2, j = lane & 3;
@@ -452,7 +454,7 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
             for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             __syncthreads();
             for (int p = 0; p < nphase; ++p) {
-                if (p >= 1) {
+                if (p >= 1 && ((p - 1) & 1) < gpw) {
                     const int g = (p - 1) & 1;
                     const unsigned base = db0 + (unsigned)(4 * g * RS * 4);
                     unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
@@ -467,7 +469,7 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
             slab_load<MK, true>(a.W + (size_t)b * M * M, M, 64 * wave + lane, wr);
             __syncthreads();
             for (int p = 0; p < nphase; ++p) {
-                if (p >= 1) {
+                if (p >= 1 && ((p - 1) & 1) < gpw) {
                     const int g = (p - 1) & 1;
                     abuf[g][wave * 64 + lane] = slab_chain<MK>(wr, &dbuf[4 * g + j][0]);
                 }
@@ -518,7 +520,7 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int s = s0 + 4 * g + j;
-        live[g] = s < a.NB;
+        live[g] = s < a.NB && g < gpw;
         toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
         const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -585,13 +587,13 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
     for (; tau >= a.skip + 1 && tau >= 1; --tau) {    // window steps first (time runs backwards)
         serial(G0, W1, tau);                          // phase 2 (T - tau)
         __syncthreads();
-        serial(G1, W1, tau);                          // phase 2 (T - tau) + 1
+        if (gpw == 2) serial(G1, W1, tau);                          // phase 2 (T - tau) + 1
         __syncthreads();
     }
     for (; tau >= 1; --tau) {
         serial(G0, W0, tau);
         __syncthreads();
-        serial(G1, W0, tau);
+        if (gpw == 2) serial(G1, W0, tau);
         __syncthreads();
     }
     if (a.g_ext) {
@@ -801,7 +803,7 @@ bool gen_mfma_supported(int M, int NB) { return (M % 2 == 0) && NB >= 4 && mfma_
 template <int MK>
 static hipError_t launch_fwd_mk(const GenFwdArgs<float>& a, hipStream_t st) {
     const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
-    const int ngroups = (a.NB + 7) / 8;
+    const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
     if (a.traj) hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, true>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
     else hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, false>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
     return hipGetLastError();
@@ -819,7 +821,7 @@ hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st) {
 template <int MK>
 static hipError_t launch_bwd_mk(const GenBwdArgs<float>& a, hipStream_t st) {
     const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
-    const int ngroups = (a.NB + 7) / 8;
+    const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
     hipLaunchKernelGGL((gen_backward_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
     return hipGetLastError();
 }

@@ -23,7 +23,8 @@ def make_gen_params(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=
                     skip_steps=1000, rate_soft_bound=200., rate_hard_bound=1000.,
                     rate_penalty_threshold=200., kernel=0):
     """Defaults: networks/wgan.py:39-63 (tau_E=10, tau_I=1, dt=0.1, seqlen=1200, skip_steps=1000).
-    kernel: 0 library default (MFMA kernels for fp32 with NB >= 4, VALU tile kernels otherwise), 1 tile, 2 MFMA."""
+    kernel: 0 library default (MFMA kernels for fp32 with NB >= 4 and enough draws, VALU tile kernels otherwise),
+    1 tile, 2 MFMA (two 4-stimulus groups per workgroup), 3 MFMA (one group per workgroup)."""
     return clib.GenParams(io_type=clib.IO_CODES[io_type], seqlen=int(seqlen), skip_steps=int(skip_steps),
                           kernel=int(kernel), k=float(k), n=float(n), tau_E=float(tau_E), tau_I=float(tau_I),
                           dt=float(dt), rate_soft_bound=float(rate_soft_bound),
