@@ -391,7 +391,8 @@ def main():
                    'neurons': M, 'batch_per_gpu': B, 'stimuli_per_draw': NB, 'euler_steps': T,
                    'kernel': {5: 'solve_mfma_kernel', 4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
                    'parallelism': 'draws sharded over %d GPU(s), no data-path collective' % world},
-        'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
+        # fp32 VALU peak = fp32 MFMA (v_mfma_f32_4x4x1) peak = 157.3 TFLOP/s (MI355X_MICROARCH.md)
+        'roofline': {'bound': 'mfma' if int(fast) == 5 else 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
                      'kernel_ms': kernel_ms, 'flops_per_unit': flops_per_unit,
                      'algorithmic_hbm_bytes': B * (4 * M * M + 12 * M * NB)},
