@@ -120,3 +120,35 @@ def test_compare_with_ssnode(num_sites, batchsize, seqlen, tol):
                                batchsize=batchsize, probes=[0], include_time_avg=True)
     out = gen.forward(stimulator_bandwidths=bw, stimulator_contrasts=con, model_zs=zs)
     np.testing.assert_allclose(out.model_time_avg.cpu().numpy(), fps, rtol=tol, atol=tol)
+
+
+def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
+    """C3 sizes (2N = 200, 8 stimuli, seqlen 1200 / skip 1000; 256 draws instead of 1024 to bound the 4 GB of
+    trajectory per kernel): the fp32-MFMA kernels (two groups per workgroup and one), and the VALU tile kernels compute
+    the same recurrence in different summation orders -- outputs and adjoint results must agree to fp32 accuracy."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    N, B, NB, T, skip = 100, 256, 8, 1200, 1000
+    rs = np.random.RandomState(7)
+    jds = on.new_JDS()
+    z = torch.rand((B, 2 * N, 2 * N), device='cuda', generator=torch.Generator(device='cuda').manual_seed(3))
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    bws = np.tile(np.asarray(P['bandwidths'])[None, :], (B, 1))
+    ext = stimuli.stimulus_batch(bws, np.full_like(bws, 20.0), P['smoothness'], N, dtype='float32')
+    gta = torch.as_tensor(rs.rand(B, NB, 2 * N), device='cuda', dtype=torch.float32)
+    res = {}
+    for kernel in (1, 2, 3):
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=kernel, **GEN)
+        out = genops.gen_forward(W, ext, gp, save=True)
+        delta = genops.gen_backward(W, out['traj'], out['df'], gta, 1e-3, 1e-3, gp)
+        gW = genops.weight_grad(delta, out['traj'])
+        res[kernel] = (out['time_avg'].cpu().numpy(), float(out['dynamics_penalty']), float(out['rate_penalty']),
+                       gW.cpu().numpy())
+        del out, delta, gW
+        torch.cuda.empty_cache()
+    assert np.isfinite(res[1][0]).all() and res[1][0].max() > 1.0
+    for kernel in (2, 3):
+        np.testing.assert_allclose(res[kernel][0], res[1][0], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(res[kernel][1], res[1][1], rtol=1e-3)
+        np.testing.assert_allclose(res[kernel][2], res[1][2], rtol=1e-4)
+        scale = np.abs(res[1][3]).max()
+        np.testing.assert_allclose(res[kernel][3], res[1][3], rtol=1e-3, atol=1e-4 * scale)
