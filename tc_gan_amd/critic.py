@@ -98,6 +98,31 @@ class Critic(object):
     def get_param_names(self):
         return [kind for kind, _ in self.param_shapes()]
 
+    # -- parameter statistics without a host wait (recorders.py:275-311 logs them after EVERY critic step) --------
+    def param_sqnorms_device(self):
+        """Sum of squares per parameter tensor (device tensor, `param_shapes` order; three small kernels)."""
+        if getattr(self, '_seg_ids', None) is None:
+            sizes = [int(np.prod(shape)) for _, shape in self.param_shapes()]
+            self._seg_sizes = np.asarray(sizes, dtype='float64')
+            self._seg_ids = torch.repeat_interleave(torch.arange(len(sizes), device=self.device),
+                                                    torch.as_tensor(sizes, device=self.device))
+        out = torch.zeros(len(self._seg_sizes), device=self.device, dtype=torch.float32)
+        out.index_add_(0, self._seg_ids, self.params * self.params)
+        return out
+
+    def cache_param_nnorms(self, sqnorms_host):
+        """Store ||p|| / size per tensor for the NEXT `param_nnorms()` call (None: no valid cache)."""
+        self._nnorm_cache = (None if sqnorms_host is None else
+                             list(np.sqrt(np.asarray(sqnorms_host, dtype='float64')) / self._seg_sizes))
+
+    def param_nnorms(self):
+        """Normalised norm of every parameter tensor; uses the values the GAN loop fetched together with the step's
+        scalars when there are any (one shot), else reads the parameters back."""
+        cached, self._nnorm_cache = getattr(self, '_nnorm_cache', None), None
+        if cached is not None:
+            return cached
+        return [float(np.linalg.norm(arr.flatten()) / arr.size) for arr in self.get_param_values()]
+
     # -- passes ----------------------------------------------------------------------
     def _workspace(self, bgd, bp):
         key = (bgd, bp)

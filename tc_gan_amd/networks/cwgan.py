@@ -325,8 +325,10 @@ class ConditionalBPTTWassersteinGAN(object):
             self.disc_updater(self.disc.params, self.disc.grads)
         acc = torch.stack([self.disc.forward(xg, cd).mean() - self.disc.forward(xd, cd).mean()])
         self.reducer.mean_(acc)
-        ctx.host = torch.empty(4, dtype=torch.float32, pin_memory=True)
-        ctx.host.copy_(torch.cat([pens, stats[3:4].to(torch.float32), acc.to(torch.float32)]), non_blocking=True)
+        # the four scalars of the step + the per-tensor sums of squares of the updated critic (disc_param_stats)
+        tail = torch.cat([pens, stats[3:4].to(torch.float32), acc.to(torch.float32), self.disc.param_sqnorms_device()])
+        ctx.host = torch.empty(tail.numel(), dtype=torch.float32, pin_memory=True)
+        ctx.host.copy_(tail, non_blocking=True)
         ctx.event = torch.cuda.Event()
         ctx.event.record()
         ctx.disc_time = self.disc_train_watch.times[-1]
@@ -340,6 +342,9 @@ class ConditionalBPTTWassersteinGAN(object):
             self.disc_updater.restore(self.disc.params, ctx.snapshot)            # the skipped step of cwgan.py:493-498
             ctx.skipped = True
             host = np.array([host[0], host[1], np.nan, np.nan], dtype='float32')
+            self.disc.cache_param_nnorms(None)
+        else:
+            self.disc.cache_param_nnorms(host[4:])
         ctx.snapshot = None
         info.gen_out = ctx.gen_out
         info.xd, info.xg, info.xp = ctx.xd, ctx.xg, ctx.xp

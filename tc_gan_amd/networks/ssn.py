@@ -185,8 +185,8 @@ class TuningCurveGenerator(object):
         amp = None
         self._zin = None
         if self.heteroin:
-            zin = torch.as_tensor(model_zs_in).to('cuda', self.tdtype)
-            vs = torch.as_tensor(neu_array(self.vpop, self.num_sites), device='cuda', dtype=self.tdtype)
+            zin = to_device(model_zs_in, self.tdtype)                     # (pinned staging: no wait for queued kernels)
+            vs = to_device(np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'), self.tdtype)
             amp = 1 + vs[None, :] * zin                                   # ssn.py:679-684
             self._zin = zin
         ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)
@@ -207,7 +207,9 @@ class TuningCurveGenerator(object):
             ids = to_device(np.asarray(prober_model_ids).astype(np.int64))
             pr = to_device(probes)
             return time_avg[ids, :, pr], ids, pr                                       # cwgan.py:98
-        pr = torch.as_tensor(self.probes, device='cuda')
+        if getattr(self, '_probes_dev', None) is None or self._probes_dev[0] is not self.probes:
+            self._probes_dev = (self.probes, to_device(np.asarray(self.probes)))
+        pr = self._probes_dev[1]
         tc = time_avg[:, :, pr].reshape(time_avg.shape[0], -1)                         # ssn.py:846-848
         return tc, None, pr
 

@@ -147,7 +147,10 @@ class DiscParamStatsRecorder(HDF5Recorder):
             counter[n] += 1
 
     def record(self, gen_step, disc_step):
-        nnorms = [np.linalg.norm(arr.flatten()) / arr.size for arr in self.discriminator.get_param_values()]
+        if hasattr(self.discriminator, 'param_nnorms'):
+            nnorms = self.discriminator.param_nnorms()       # fetched with the step's scalars: no host wait here
+        else:
+            nnorms = [np.linalg.norm(arr.flatten()) / arr.size for arr in self.discriminator.get_param_values()]
         self._saverow([gen_step, disc_step] + nnorms)
         return nnorms
 
