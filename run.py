@@ -27,7 +27,8 @@ def main(argv=None):
         module = os.path.relpath(os.path.realpath(module), os.path.dirname(os.path.abspath(__file__)))[:-3].replace(os.sep, '.')
     if module.startswith('tc_gan.'):
         module = 'tc_gan_amd.' + module[len('tc_gan.'):]
-    from tc_gan_amd.execution import KnownError
+    from tc_gan_amd.execution import KnownError, init_distributed
+    init_distributed()          # torchrun / torch.distributed.run: one process per GPU, data parallel over weight draws
     loaded = importlib.import_module(module)
     if not hasattr(loaded, 'main'):
         print('Module', module, 'do not have main function.')

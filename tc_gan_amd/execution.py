@@ -38,6 +38,35 @@ class SuccessExit(KnownError):
         super(SuccessExit, self).__init__(message, exit_code=0)
 
 
+def init_distributed(_environ=os.environ):
+    """Join the torch.distributed job this process was launched in (``torchrun --nproc-per-node G run.py ...``): one
+    process per GPU, RCCL (backend "nccl") unless TCGAN_DIST_BACKEND says otherwise (``gloo`` lets several ranks share
+    one card, for tests).  No-op for a plain single-process run.  The models of a minibatch are then sharded over the
+    ranks and every update does one all-reduce (networks/cwgan.py); every rank writes its own (identical) log, ranks
+    above 0 under ``<datastore>/rank<r>``."""
+    world = int(_environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return True
+    backend = _environ.get('TCGAN_DIST_BACKEND', 'nccl')
+    local = int(_environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local)
+    _environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group(backend, rank=int(_environ.get('RANK', '0')), world_size=world)
+    return True
+
+
+def distributed_rank():
+    try:
+        import torch.distributed as dist
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    except Exception:
+        return 0
+
+
 def makedirs_exist_ok(name):
     os.makedirs(name, exist_ok=True)
 
@@ -275,6 +304,8 @@ def pre_learn(packages, datastore, datastore_template, load_config, extra_info={
         preprocess(run_config)
     if not datastore:
         datastore = format_datastore(datastore_template, run_config)
+    if distributed_rank() > 0:
+        datastore = os.path.join(datastore, 'rank%d' % distributed_rank())
     makedirs_exist_ok(datastore)
     with open(os.path.join(datastore, 'info.json'), 'w') as fp:
         json.dump(_jsonable(dict(run_config=run_config, extra_info=extra_info,

@@ -92,3 +92,31 @@ def test_cli_checkpoint_and_resume(tmp_path, monkeypatch):
     tables = _load_tables(str(tmp_path / 'second'), 'store')
     assert list(tables['learning']['gen_step']) == [2, 3]
     assert json.load(open(tmp_path / 'second' / 'exit.json'))['good']
+
+
+def test_two_rank_cli_run_follows_the_single_process_run(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 run.py tc_gan.run.bptt_cwgan -- ...` (gloo, both ranks on
+    the one card of the test box): models sharded over the ranks, one all-reduce per update, every rank logging the
+    same run -- which is the run a single process makes with the same seeds (host-side noise)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ['tc_gan.run.bptt_cwgan', '--', '--iterations', '2', '--truth_size', '4', '--num-models', '4',
+              '--n_bandwidths', '4', '--WGAN_n_critic0', '2', '--WGAN_n_critic', '2', '--seqlen', '30',
+              '--skip-steps', '20', '--disc-layers', '[16]', '--disc-precision', 'fp32', '--quiet',
+              '--dataset-provider', 'fixedtime', '--J0', '0.1', '--D0', '0.05', '--S0', '0.1']
+    env = dict(os.environ, TCGAN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('WORLD_SIZE', None)
+    subprocess.run([sys.executable, os.path.join(root, 'run.py')] + common + ['--datastore', str(tmp_path / 'one')],
+                   check=True, env=env, cwd=str(tmp_path), timeout=300)
+    port = str(26700 + os.getpid() % 1000)
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                    '--master-addr', '127.0.0.1', '--master-port', port, os.path.join(root, 'run.py')] + common +
+                   ['--datastore', str(tmp_path / 'two')], check=True, env=env, cwd=str(tmp_path), timeout=300)
+    one = _load_tables(str(tmp_path / 'one'), 'store')
+    for sub in ('two', os.path.join('two', 'rank1')):
+        two = _load_tables(str(tmp_path / sub), 'store')
+        for name in one['generator'].dtype.names:
+            np.testing.assert_allclose(two['generator'][name], one['generator'][name], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(two['learning']['Dloss'], one['learning']['Dloss'], rtol=2e-4, atol=2e-5)
+        assert json.load(open(tmp_path / sub / 'exit.json'))['good'] is True
