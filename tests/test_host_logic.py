@@ -175,3 +175,10 @@ def test_single_cell_minibatch_selection_keeps_the_random_stream():
     np.testing.assert_array_equal(mb_a.tc_md, nested[ids_sample, 0, 0, ids_contrast.reshape(-1, 1)])
     sa, sb = a.rng.get_state(), b.rng.get_state()
     assert sa[2] == sb[2] and np.array_equal(sa[1], sb[1])
+
+
+def test_init_distributed_is_a_no_op_for_a_single_process():
+    from tc_gan_amd.execution import distributed_rank, init_distributed
+    assert init_distributed({'WORLD_SIZE': '1'}) is False
+    assert init_distributed({}) is False
+    assert distributed_rank() == 0
