@@ -190,9 +190,16 @@ class Critic(object):
             _stream()), 'ssn_critic_input_grad')
         return gx, self.stats[0]
 
+    def accuracy_device(self, xg, cg, xd, cd):
+        """mean D(xg) - mean D(xd) (cwgan.py:139-147) as a 1-element device tensor: ONE forward over the stacked rows
+        (every output row depends on its own input row only), no host wait."""
+        xg, cg, xd, cd = self._f32(xg), self._f32(cg), self._f32(xd), self._f32(cd)
+        d = self.forward(torch.cat([xg, xd]), torch.cat([cg, cd]))
+        ng = xg.shape[0]
+        return (d[:ng].mean() - d[ng:].mean()).reshape(1)
+
     def accuracy(self, xg, cg, xd, cd):
-        """mean D(xg) - mean D(xd) (cwgan.py:139-147)."""
-        return float(self.forward(xg, cg).mean() - self.forward(xd, cd).mean())
+        return float(self.accuracy_device(xg, cg, xd, cd)[0])
 
 
 class Updater(object):

@@ -323,7 +323,7 @@ class ConditionalBPTTWassersteinGAN(object):
             stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
             self.reducer.mean_(self.disc.grads, stats)
             self.disc_updater(self.disc.params, self.disc.grads)
-        acc = torch.stack([self.disc.forward(xg, cd).mean() - self.disc.forward(xd, cd).mean()])
+        acc = self.disc.accuracy_device(xg, cd, xd, cd)
         self.reducer.mean_(acc)
         # the four scalars of the step + the per-tensor sums of squares of the updated critic (disc_param_stats)
         tail = torch.cat([pens, stats[3:4].to(torch.float32), acc.to(torch.float32), self.disc.param_sqnorms_device()])
