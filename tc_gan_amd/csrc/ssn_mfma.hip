@@ -11,7 +11,8 @@
 // tools/microbench/mfma_matvec_rate.hip: 4195 cycles per step for 256 rows x 200 columns x 8 stimuli on one CU
 // = 524 cycles per (draw, stimulus) step, against ~1000 for the split tile shape.
 //
-// Workgroup = 2 * ceil(M / 64) waves for one (draw, group of 8 stimuli) = two MFMA groups of 4 stimuli, SPECIALISED:
+// Workgroup = 2 * ceil(M / 64) waves (slab form; K-split form: 3 * ceil(M / 64), see KSplit) for one (draw, group of
+// 8 stimuli) = two MFMA groups of 4 stimuli, SPECIALISED:
 //   * "matrix" waves 0 .. wm-1 hold the W slabs and do nothing but MFMA chains (4 interleaved partial chains per group),
 //   * "serial" waves wm .. 2 wm - 1 (same lane -> (rows, stimulus) map, a few dozen registers) run the serial part of
 //     every step: nonlinearity, Euler update, windowed reductions, trajectory stores, state write.
@@ -161,26 +162,32 @@ __device__ __forceinline__ mf4 slab_chain(const float (&wr)[MK], const float* xs
 // slot by slot and the serial lane of (quad, stimulus) adds them (P 16-byte reads).
 template <int MK>
 struct KSplit {
-    static constexpr int WM = (MK + 63) / 64;                  // matrix waves
-    static constexpr int SLOTS = WM * 64;
+    static constexpr int SW = (MK + 63) / 64;                  // serial waves (64 lanes x 4 rows each)
+    static constexpr int SLOTS = SW * 64 * 4 / 4;              // (wave, chain, block) slots: 4 chains of 16 blocks per 64 rows
     static constexpr int NQ = MK / 4;                          // row quads
     static constexpr int P = SLOTS / NQ;                       // column parts per quad
     static constexpr int KP = ((MK + P - 1) / P + 3) / 4 * 4;  // columns per part (16-byte B-operand reads)
     static constexpr int NS4 = KP / 4;
     static constexpr bool enabled = 4 * KP < MK;               // shorter chains than the slab form
+    // The 4 chains per SIMD are issued by TWO matrix waves of 2 chains each (CH = 2, WM = 2 SW matrix waves): one wave
+    // alone leaves the matrix pipe idle while it waits for its B operands from LDS (129 vs 143 TFLOP/s in
+    // tools/microbench/mfma_matvec_rate.hip); 80 W registers per wave, 3 waves per SIMD with the serial wave.
+    static constexpr int CH = 2;
+    static constexpr int WM = SW * 4 / CH;                     // matrix waves
+    static constexpr int THREADS = (WM + SW) * 64;
     static constexpr int RS = (P * KP > MK ? P * KP : MK) + 8; // state row stride: the (stimulus, part) reads of one
                                                                // wave instruction on disjoint banks (MK = 200, 152)
     // slot of (wave, chain, block) -> (part, quad); slots >= NQ * P idle (part P: all columns out of range)
-    __device__ static __forceinline__ int slot(int wave, int c, int blk) { return (wave * 4 + c) * 16 + blk; }
+    __device__ static __forceinline__ int slot(int wave, int c, int blk) { return (wave * CH + c) * 16 + blk; }
 };
 
 // wr[c][s] = A[4 q_c + i][p_c KP + s] (TRANSPOSED: A[p_c KP + s][4 q_c + i]) for lane (blk, i), zero outside M x M
 template <int MK, bool TRANSPOSED>
-__device__ __forceinline__ void ksplit_load(const float* A, int M, int wave, int lane, float (&wr)[4][KSplit<MK>::KP]) {
+__device__ __forceinline__ void ksplit_load(const float* A, int M, int wave, int lane, float (&wr)[KSplit<MK>::CH][KSplit<MK>::KP]) {
     using KS = KSplit<MK>;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, M * M * 4, 0x00020000);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < KS::CH; ++c) {
         const int u = KS::slot(wave, c, lane >> 2);
         const int part = u / KS::NQ, row = 4 * (u % KS::NQ) + (lane & 3);
         const int k0 = part * KS::KP;
@@ -204,39 +211,41 @@ __device__ __forceinline__ void ksplit_load(const float* A, int M, int wave, int
     }
 }
 
-// The four chains of one phase: chain c multiplies its slot's 4 x KP block with x[k0_c .. k0_c + KP) of the lane's
-// stimulus row (LDS byte address xa[c]) and stores the 4 partial sums to out[c] (LDS).  Read/MFMA order pinned as in
-// slab_chain: the B operands of step group s4 + DEPTH are requested before the 16 MFMAs of group s4.
+// The chains of one wave in one phase: chain c multiplies its slot's 4 x KP block with x[k0_c .. k0_c + KP) of the
+// lane's stimulus row (LDS byte address xa[c]) and stores the 4 partial sums to out[c] (LDS).  Read/MFMA order pinned as
+// in slab_chain: the B operands of step group s4 + DEPTH are requested before the MFMAs of group s4.
 template <int MK>
-__device__ __forceinline__ void ksplit_chain(const float (&wr)[4][KSplit<MK>::KP], unsigned (&xa)[4], mf4* const (&out)[4]) {
+__device__ __forceinline__ void ksplit_chain(const float (&wr)[KSplit<MK>::CH][KSplit<MK>::KP], unsigned (&xa)[KSplit<MK>::CH],
+                                             mf4* const (&out)[KSplit<MK>::CH]) {
     using KS = KSplit<MK>;
-    constexpr int NS4 = KS::NS4, DEPTH = 2;
+    constexpr int NS4 = KS::NS4, CH = KS::CH, DEPTH = 3;
     using LdsV4 = const __attribute__((address_space(3))) mf4*;
-    mf4 acc[4];
-    mf4 bq[NS4][4];
+    mf4 acc[CH];
+    mf4 bq[NS4][CH];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = (mf4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < CH; ++c) acc[c] = (mf4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s4 = 0; s4 < DEPTH && s4 < NS4; ++s4)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) bq[s4][c] = *(LdsV4)(size_t)(xa[c] + 16u * s4);
-    asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));
+        for (int c = 0; c < CH; ++c) bq[s4][c] = *(LdsV4)(size_t)(xa[c] + 16u * s4);
+#pragma unroll
+    for (int c = 0; c < CH; ++c) asm volatile("" : "+v"(xa[c]));
 #pragma unroll
     for (int s4 = 0; s4 < NS4; ++s4) {
         if (s4 + DEPTH < NS4) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bq[s4 + DEPTH][c] = *(LdsV4)(size_t)(xa[c] + 16u * (s4 + DEPTH));
+            for (int c = 0; c < CH; ++c) bq[s4 + DEPTH][c] = *(LdsV4)(size_t)(xa[c] + 16u * (s4 + DEPTH));
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < CH; ++c)
                 acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wr[c][4 * s4 + e], bq[s4][c][e], acc[c], 0, 0, 0);
-        asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]),
-                          "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+#pragma unroll
+        for (int c = 0; c < CH; ++c) asm volatile("" : "+v"(xa[c]), "+v"(acc[c]));
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) *out[c] = acc[c];
+    for (int c = 0; c < CH; ++c) *out[c] = acc[c];
 }
 
 // serial side: complete sums of (quad q, stimulus j) = the P partial sums of slots p NQ + q
@@ -254,7 +263,7 @@ __device__ __forceinline__ mf4 ksplit_gather(const mf4* ab /* [SLOTS][4] of one 
 }
 
 template <int MK, bool SAVE>
-__global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<float> a) {
+__global__ void __launch_bounds__(KSplit<MK>::enabled ? KSplit<MK>::THREADS : 512, KSplit<MK>::enabled ? 3 : 2) gen_forward_mfma_kernel(GenFwdArgs<float> a) {
     using KS = KSplit<MK>;
     constexpr bool KSP = KS::enabled;
     constexpr int RS = KSP ? KS::RS : MK + 4;     // LDS row stride: the 4 stimuli of a group on disjoint banks
@@ -267,7 +276,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     const int b = blockIdx.x / ngroups;
     const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (int)(blockDim.x >> 7);        // matrix waves (= serial waves)
+    const int wm = KSplit<MK>::enabled ? KSplit<MK>::WM : (int)(blockDim.x >> 7);     // matrix waves
     const int blk = lane >> 2, j = lane & 3;
     const int nphase = 2 * T_ + 1;
     for (int c = threadIdx.x; c < 2 * 8 * RS; c += blockDim.x) (&rbuf[0][0][0])[c] = 0.f;
@@ -275,21 +284,21 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
     if (wave < wm) {
         // ================================ matrix wave ================================
         if constexpr (KSP) {
-            float wr[4][KS::KP];
+            float wr[KS::CH][KS::KP];
             ksplit_load<MK, false>(a.W + (size_t)b * M * M, M, wave, lane, wr);
             using LdsF = const __attribute__((address_space(3))) float*;
             const unsigned rb0 = (unsigned)(size_t)(LdsF)&rbuf[0][0][0];
-            unsigned xoff[4];                     // byte offset of (my stimulus row, first column of chain c's part)
+            unsigned xoff[KS::CH];                // byte offset of (my stimulus row, first column of chain c's part)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
+            for (int c = 0; c < KS::CH; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             __syncthreads();
             for (int p = 0; p < nphase; ++p) {
                 if (p < 2 * T_ && (p & 1) < gpw && !(SSN_MFMA_ABLATE & 2)) {
                     const int g = p & 1, it = p >> 1;
                     const unsigned base = rb0 + (unsigned)((((it & 1) * 8 + 4 * g) * RS) * 4);
-                    unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
-                    mf4* const out[4] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j],
-                                         &abuf[g][KS::slot(wave, 2, blk) * 4 + j], &abuf[g][KS::slot(wave, 3, blk) * 4 + j]};
+                    static_assert(KS::CH == 2, "operand lists below are written out for two chains per wave");
+                    unsigned xa[2] = {base + xoff[0], base + xoff[1]};
+                    mf4* const out[2] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j]};
                     ksplit_chain<MK>(wr, xa, out);
                 }
                 __syncthreads();
@@ -426,7 +435,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_mfma_kernel(GenFwdArgs<flo
 // serial(tau - 1) [carry = (1 - eps) a_tau + W^T delta_tau] ...; group 0 serial phases are the even ones, group 1 the
 // odd ones, the matrix waves serve the other group in every phase.
 template <int MK>
-__global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<float> a) {
+__global__ void __launch_bounds__(KSplit<MK>::enabled ? KSplit<MK>::THREADS : 512, KSplit<MK>::enabled ? 3 : 2) gen_backward_mfma_kernel(GenBwdArgs<float> a) {
     using KS = KSplit<MK>;
     constexpr bool KSP = KS::enabled;
     constexpr int RS = KSP ? KS::RS : MK + 4;
@@ -438,28 +447,28 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
     const int b = blockIdx.x / ngroups;
     const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (int)(blockDim.x >> 7);
+    const int wm = KSplit<MK>::enabled ? KSplit<MK>::WM : (int)(blockDim.x >> 7);
     const int blk = lane >> 2, j = lane & 3;
     const int nphase = 2 * T_;
     for (int c = threadIdx.x; c < 8 * RS; c += blockDim.x) (&dbuf[0][0])[c] = 0.f;
 
     if (wave < wm) {
         if constexpr (KSP) {
-            float wr[4][KS::KP];
+            float wr[KS::CH][KS::KP];
             ksplit_load<MK, true>(a.W + (size_t)b * M * M, M, wave, lane, wr);
             using LdsF = const __attribute__((address_space(3))) float*;
             const unsigned db0 = (unsigned)(size_t)(LdsF)&dbuf[0][0];
-            unsigned xoff[4];
+            unsigned xoff[KS::CH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
+            for (int c = 0; c < KS::CH; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             __syncthreads();
             for (int p = 0; p < nphase; ++p) {
                 if (p >= 1 && ((p - 1) & 1) < gpw) {
                     const int g = (p - 1) & 1;
                     const unsigned base = db0 + (unsigned)(4 * g * RS * 4);
-                    unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
-                    mf4* const out[4] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j],
-                                         &abuf[g][KS::slot(wave, 2, blk) * 4 + j], &abuf[g][KS::slot(wave, 3, blk) * 4 + j]};
+                    static_assert(KS::CH == 2, "operand lists below are written out for two chains per wave");
+                    unsigned xa[2] = {base + xoff[0], base + xoff[1]};
+                    mf4* const out[2] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j]};
                     ksplit_chain<MK>(wr, xa, out);
                 }
                 __syncthreads();
@@ -614,7 +623,7 @@ __global__ void __launch_bounds__(512, 2) gen_backward_mfma_kernel(GenBwdArgs<fl
 // phase in which serial(g, it) ran; in the NEXT phase EVERY wave reads them and updates the same frozen mask / codes /
 // step counts, so matrix and serial waves leave the loop in the same phase.
 template <int MK>
-__global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) {
+__global__ void __launch_bounds__(KSplit<MK>::enabled ? KSplit<MK>::THREADS : 512, KSplit<MK>::enabled ? 3 : 2) solve_mfma_kernel(SolveArgs<float> a) {
     using KS = KSplit<MK>;
     constexpr bool KSP = KS::enabled;
     constexpr int RS = KSP ? KS::RS : MK + 4;
@@ -626,7 +635,7 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
     const int b = blockIdx.x / ngroups;
     const int s0 = (blockIdx.x % ngroups) * 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (int)(blockDim.x >> 7);
+    const int wm = KSplit<MK>::enabled ? KSplit<MK>::WM : (int)(blockDim.x >> 7);
     const int blk = lane >> 2, j = lane & 3;
     const bool matrix = wave < wm;
     const int sw = wave - wm;
@@ -661,18 +670,18 @@ __global__ void __launch_bounds__(512, 2) solve_mfma_kernel(SolveArgs<float> a) 
     // registers of one role (200 for the slab) are not live in the other.
     if (matrix) {
         if constexpr (KSP) {
-            float wr[4][KS::KP];
+            float wr[KS::CH][KS::KP];
             ksplit_load<MK, false>(a.W + (size_t)b * M * M, M, wave, lane, wr);
             using LdsF = const __attribute__((address_space(3))) float*;
             const unsigned rb0 = (unsigned)(size_t)(LdsF)&rbuf[0][0][0];
-            unsigned xoff[4];
+            unsigned xoff[KS::CH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
+            for (int c = 0; c < KS::CH; ++c) xoff[c] = (unsigned)((j * RS + (KS::slot(wave, c, blk) / KS::NQ) * KS::KP) * 4);
             auto chain = [&](int g, int it) {
                 const unsigned base = rb0 + (unsigned)((((it & 1) * 8 + 4 * g) * RS) * 4);
-                unsigned xa[4] = {base + xoff[0], base + xoff[1], base + xoff[2], base + xoff[3]};
-                mf4* const out[4] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j],
-                                     &abuf[g][KS::slot(wave, 2, blk) * 4 + j], &abuf[g][KS::slot(wave, 3, blk) * 4 + j]};
+                static_assert(KS::CH == 2, "operand lists below are written out for two chains per wave");
+                unsigned xa[2] = {base + xoff[0], base + xoff[1]};
+                mf4* const out[2] = {&abuf[g][KS::slot(wave, 0, blk) * 4 + j], &abuf[g][KS::slot(wave, 1, blk) * 4 + j]};
                 ksplit_chain<MK>(wr, xa, out);
             };
             __syncthreads();
@@ -802,10 +811,10 @@ bool gen_mfma_supported(int M, int NB) { return (M % 2 == 0) && NB >= 4 && mfma_
 
 template <int MK>
 static hipError_t launch_fwd_mk(const GenFwdArgs<float>& a, hipStream_t st) {
-    const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
+    const int threads = KSplit<MK>::enabled ? KSplit<MK>::THREADS : 128 * ((a.M + 63) / 64);
     const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
-    if (a.traj) hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, true>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
-    else hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, false>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    if (a.traj) hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, true>), dim3(a.B * ngroups), dim3(threads), 0, st, a);
+    else hipLaunchKernelGGL((gen_forward_mfma_kernel<MK, false>), dim3(a.B * ngroups), dim3(threads), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st) {
@@ -820,9 +829,9 @@ hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st) {
 
 template <int MK>
 static hipError_t launch_bwd_mk(const GenBwdArgs<float>& a, hipStream_t st) {
-    const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
+    const int threads = KSplit<MK>::enabled ? KSplit<MK>::THREADS : 128 * ((a.M + 63) / 64);
     const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
-    hipLaunchKernelGGL((gen_backward_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    hipLaunchKernelGGL((gen_backward_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(threads), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st) {
@@ -837,9 +846,9 @@ hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st) 
 
 template <int MK>
 static hipError_t launch_solve_mk(const SolveArgs<float>& a, hipStream_t st) {
-    const int waves = KSplit<MK>::enabled ? KSplit<MK>::WM : (a.M + 63) / 64;
+    const int threads = KSplit<MK>::enabled ? KSplit<MK>::THREADS : 128 * ((a.M + 63) / 64);
     const int ngroups = (a.NB + 7) / 8;
-    hipLaunchKernelGGL((solve_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(128 * waves), 0, st, a);
+    hipLaunchKernelGGL((solve_mfma_kernel<MK>), dim3(a.B * ngroups), dim3(threads), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st) {
