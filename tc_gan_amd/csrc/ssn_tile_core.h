@@ -87,11 +87,18 @@ template <>
 __device__ __forceinline__ float reduce8_to_lane<float>(const float (&acc)[8], int cg) {
     const bool bB = cg & 2, bC = cg & 1;
     float n4[4], n2[2];
+    // A DPP read of a VGPR needs two wait states after the VALU write of that VGPR and the hardware does not
+    // interlock; the compiler inserts them for its own DPP instructions but cannot see into inline asm.  One s_nop
+    // that "redefines" all eight inputs puts every producing FMA in front of it, and with it two wait states in front
+    // of every DPP read below.
+    float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5], a6 = acc[6], a7 = acc[7];
+    asm volatile("s_nop 1" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    const float lo[4] = {a0, a1, a2, a3}, hi[4] = {a4, a5, a6, a7};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float r;
-        asm("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(acc[k]));
-        asm("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(r) : "v"(acc[k + 4]));
+        asm("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(lo[k]));
+        asm("v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa" : "+v"(r) : "v"(hi[k]));
         n4[k] = r;
     }
 #pragma unroll
