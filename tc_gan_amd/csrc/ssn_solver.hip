@@ -105,7 +105,10 @@ template <int BASE, int NW>
 __device__ __forceinline__ void chunk_fma(float& acc, float rv, const float (&w)[NW]) {
     // not `volatile`: the statement is a pure function of its operands, so the scheduler may hoist
     // the LDS reads of later chunks above it (with `volatile` every chunk waited for its own read).
+    // (s_nop 1: a DPP read needs two wait states after a VALU write of its source and the compiler cannot see into
+    // the asm; rv normally comes straight from an LDS read, but a copy through v_mov is the compiler's choice)
     asm(
+        "s_nop 1\n\t"
         "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
         "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
