@@ -31,7 +31,7 @@ def _problem(N, B, NB, seed, T, skip, theta):
     # K-split operand layout with a partly filled ladder size (2N = 180 in the 200 build, 2N = 130 in the 152 build)
     (90, 2, 8, 'float32', 2), (65, 1, 6, 'float32', 2),
     # sizes beyond the register-resident instantiations (2N > 208 fp32, > 104 fp64): streaming kernels
-    (110, 1, 2, 'float32', 0), (60, 2, 2, 'float64', 0), (129, 1, 4, 'float32', 0),
+    (110, 1, 2, 'float32', 0), (60, 2, 2, 'float64', 0), (129, 1, 4, 'float32', 0), (201, 1, 2, 'float32', 0),
     # MFMA kernels with one 4-stimulus group per workgroup (kernel 3)
     (100, 2, 8, 'float32', 3), (101, 1, 6, 'float32', 3), (50, 2, 9, 'float32', 3)])
 def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
@@ -61,7 +61,8 @@ def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
     # fp32 with NB >= 4: MFMA forward + adjoint kernels (2), tile kernels (1)
     (100, 1, 8, 'float32', 2), (100, 1, 8, 'float32', 1), (50, 2, 5, 'float32', 2), (101, 1, 4, 'float32', 2),
     (20, 2, 9, 'float32', 2), (76, 1, 8, 'float32', 2), (90, 1, 5, 'float32', 2),
-    (110, 1, 2, 'float32', 0), (60, 2, 2, 'float64', 0), (100, 1, 8, 'float32', 3), (76, 2, 5, 'float32', 3)])
+    (110, 1, 2, 'float32', 0), (60, 2, 2, 'float64', 0), (100, 1, 8, 'float32', 3), (76, 2, 5, 'float32', 3),
+    (201, 1, 1, 'float32', 0)])
 def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype, kernel):
     """dL/dJ, dL/dD, dL/dS for L = sum(G * time_avg) + c_d * dyn_pen + c_r * rate_pen."""
     from tc_gan_amd import genops, stimuli, weight_gen
