@@ -47,35 +47,29 @@ def new_jds():
     return J + D / 2 - D / 4, D / 2, S
 
 
-def cpu_baseline(N, NB, T, sample_B, threads):
-    """Time the reference's C solver (oracle/_ref/libssnode.so, built from
-    tc_gan/ext/ssnode.c unmodified) driven as ssnode.find_fixed_points_parallel drives it
-    (ssnode.py:423-510): a pool of Python threads, one task per weight draw, each blocking
-    in ctypes with the GIL released.  Falls back to the oracle's C restatement ("port")
-    when the prebuilt reference library is absent."""
+def _bind_solve(fn):
+    """ctypes signature of solve_dynamics_asym_*_euler (tc_gan/clib.py:16-26)."""
+    dp = ctypes.POINTER(ctypes.c_double)
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int, dp, dp, ctypes.c_double, ctypes.c_double, dp, dp, ctypes.c_double, ctypes.c_double,
+                   ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    return fn
+
+
+def time_threaded_solves(fn, Ws, exts, N, T, threads):
+    """The reference's call pattern (ssnode.find_fixed_points_parallel, ssnode.py:423-510): a pool of Python
+    threads, one task per weight draw, one blocking ctypes call per stimulus (largest bandwidth first) with the GIL
+    released.  `fn` = a bound solve_dynamics_asym_tanh_euler.  Returns the best of 2 wall times after a warm-up."""
     from multiprocessing.dummy import Pool
-    from oracle import ssn_numpy as on
-    ref = on.load_reference_lib()
-    kind = 'reference' if ref is not None else 'port'
-    J, D, S = new_jds()
     M = 2 * N
-    rs = np.random.RandomState(0)
-    Ws = [on.generate_weight(N, J, D, S, rs.rand(M, M)) for _ in range(sample_B)]
-    bws = [1.0] if NB == 1 else on.DEFAULT_PARAMS['bandwidths'][:NB]
-    exts = on.stimulus_input(bws, np.linspace(-.5, .5, N), on.DEFAULT_PARAMS['smoothness'], [20.])
-    P = on.DEFAULT_PARAMS
-    lib = None if ref is not None else on.load_oracle_lib()
+    dp = ctypes.POINTER(ctypes.c_double)
 
     def task(W):
         for ext in exts[::-1]:
             r0 = np.zeros(M)
             r1 = np.empty(M)
-            if ref is not None:
-                ref.solve_dynamics_asym_tanh_euler(N, on.ptr(W), on.ptr(ext), P['k'], P['n'], on.ptr(r0), on.ptr(r1),
-                                                   P['tau'][0], P['tau'][1], 8e-4, T, 0.0, 200., 1000.)
-            else:
-                lib.oracle_solve_euler(2, N, on.ptr(W), on.ptr(ext), P['k'], P['n'], on.ptr(r0), on.ptr(r1),
-                                       P['tau'][0], P['tau'][1], 8e-4, T, 0.0, 200., 1000., None)
+            fn(N, W.ctypes.data_as(dp), ext.ctypes.data_as(dp), 0.01, 2.2, r0.ctypes.data_as(dp), r1.ctypes.data_as(dp),
+               0.01589, 0.002, 8e-4, T, 0.0, 200., 1000.)
         return r0[0]
 
     pool = Pool(threads)
@@ -87,6 +81,30 @@ def cpu_baseline(N, NB, T, sample_B, threads):
         best = min(best, time.perf_counter() - t0)
     pool.close()
     pool.join()
+    return best
+
+
+def cpu_baseline(N, NB, T, sample_B, threads):
+    """Time the reference's C solver (oracle/_ref/libssnode.so, built from tc_gan/ext/ssnode.c unmodified) driven as
+    ssnode.find_fixed_points_parallel drives it.  Falls back to the oracle's C restatement ("port") when the
+    prebuilt reference library is absent.  This is the only leg of bench.py that touches oracle/."""
+    from oracle import ssn_numpy as on
+    ref = on.load_reference_lib()
+    kind = 'reference' if ref is not None else 'port'
+    J, D, S = new_jds()
+    M = 2 * N
+    rs = np.random.RandomState(0)
+    Ws = [on.generate_weight(N, J, D, S, rs.rand(M, M)) for _ in range(sample_B)]
+    bws = [1.0] if NB == 1 else on.DEFAULT_PARAMS['bandwidths'][:NB]
+    exts = on.stimulus_input(bws, np.linspace(-.5, .5, N), on.DEFAULT_PARAMS['smoothness'], [20.])
+    if ref is not None:
+        fn = _bind_solve(ref.solve_dynamics_asym_tanh_euler)
+    else:
+        lib = on.load_oracle_lib()
+
+        def fn(N_, W, ext, k, n, r0, r1, tE, tI, dt, T_, atol, soft, hard):
+            return lib.oracle_solve_euler(2, N_, W, ext, k, n, r0, r1, tE, tI, dt, T_, atol, soft, hard, None)
+    best = time_threaded_solves(fn, Ws, exts, N, T, threads)
     units = float(M) * sample_B * NB * T
     return dict(value=units / best, unit='neuron*batch*Euler-steps/s', cores=threads, kind=kind,
                 sample='%d of the workload\'s weight draws x %d stimuli x %d steps, 2N=%d, fp64, '
@@ -115,7 +133,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
                gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
-                         nonlinearity='rectify', precision='bf16'))
+                         nonlinearity='rectify', precision=args.disc_precision))
     if paper:
         cfg.update(tau_E=2, ssn_type='deg-heteroin', V=0.1)
         cfg['gen'].update(learning_rate=1e-4, update_name='rmsprop', dynamics_cost=0.0, rate_cost=100.0)
@@ -202,10 +220,8 @@ def run_c3(args, rank, world, local_rank, paper=False):
                      'ssn_steps_per_s_in_loop': 7 * units * iters_per_s * world},
         'last_gen_loss': info.gen_loss,
     }
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    out['world_size'] = world
+    return out
 
 
 def run_c5(args, rank, world, local_rank):
@@ -256,10 +272,65 @@ def run_c5(args, rank, world, local_rank):
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
                         'traffic': None, 'kernel': 'ff_forward_kernel', 'kernel_ms': kernel_ms,
                         'algorithmic_hbm_bytes': bytes_alg}}
-    if rank == 0:
-        print(json.dumps(res))
-    if world > 1:
-        dist.destroy_process_group()
+    res['world_size'] = world
+    return res
+
+
+def run_c1_dropin(args):
+    """BASELINE config 1 through the boundary a maintainer gets by copying libssnode.so into tc_gan/ext/:
+    `find_fixed_points_parallel`'s pattern (ssnode.py:423-510) -- a pool of 16 Python threads, one task per
+    weight draw, one `solve_dynamics_asym_tanh_euler` call per (draw, stimulus), host fp64 buffers -- timed on the
+    GPU library and, beside it, on the reference's own C build.  PCIe, launch and synchronisation are all inside
+    the timed region (this is the host-buffer entry point); `roofline` is null: a one-workgroup fp64 solve per
+    call is latency-bound by construction."""
+    from tc_gan_amd import stimuli, weight_gen
+    from tc_gan_amd.clib import libssnode
+    N, B, NB, T, desc = WORKLOADS['c1']
+    M = 2 * N
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    fn = _bind_solve(libssnode.solve_dynamics_asym_tanh_euler)
+    sample = args.cpu_sample or B * max(args.steps, 1)
+    J, D, S = new_jds()
+    rs = np.random.RandomState(0)
+    Ws = list(weight_gen.generate_weight_batch(N, J, D, S, rs.rand(sample, M, M), dtype='float64').cpu().numpy())
+    exts = stimuli.input([1.0], np.linspace(-.5, .5, N), 0.25 / 8, [20.])
+    t_pool = time_threaded_solves(fn, Ws, exts, N, T, threads)
+    t_one = time_threaded_solves(fn, Ws[:64], exts, N, T, 1)
+    units = float(M) * NB * T
+    value = units * sample / t_pool
+    out = {'metric': 'SSN-steps/sec', 'value': value, 'unit': 'neuron*batch*Euler-steps/s', 'n_gpus': 1,
+           'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t_pool / sample * B * 1e3, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+           'config': {'workload': desc + ', via the drop-in symbols: %d host threads, one solve_dynamics_asym_tanh_euler '
+                                         'call per (draw, stimulus), host buffers (PCIe, launch and sync inside the timed '
+                                         'region)' % threads,
+                      'calls': sample * NB, 'us_per_call_pool': t_pool / (sample * NB) * 1e6,
+                      'us_per_call_single_thread': t_one / (min(sample, 64) * NB) * 1e6,
+                      'single_thread_value': units * min(sample, 64) / t_one},
+           'roofline': None}
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(N, NB, T, sample, threads)
+        out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, as children of a parent that
+    never touches the GPU (no HIP call, no torch.cuda call before the spawn; the parent is never replaced by
+    another program).  The children are the driver's own command form (`python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`); rank 0's single JSON
+    line goes to our stdout unchanged and we exit with the launcher's code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -272,19 +343,29 @@ def main():
                     '3 tile/split residency, 4 tile/all-register, 5 fp32 MFMA (NB >= 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
+    ap.add_argument('--secondary-steps', type=int, default=5,
+                    help='GAN iterations of the C3 run whose line rides along as `secondary` with the default (C2) '
+                         'workload, so that one command covers both halves of BASELINE.json.metric (0 = off)')
+    ap.add_argument('--disc-precision', default='bf16', choices=['bf16', 'fp32'],
+                    help='c3: critic GEMM operand precision (BASELINE config 3 names bf16 MFMA)')
+    ap.add_argument('--via', default='batched', choices=['batched', 'dropin'],
+                    help="c1 only: 'dropin' times the reference's call pattern (one solve_dynamics_* call per "
+                         "(draw, stimulus) from a 16-thread pool) through the zero-change drop-in symbols")
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))            # before anything touches the GPU
 
     import torch
     import torch.distributed as dist
     from tc_gan_amd import clib
-    from tc_gan_amd.clib import libssnode
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if rank == 0:
-            print('warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE' % (args.gpus, world), file=sys.stderr)
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a line whose '
+                 'n_gpus is not the number of ranks that ran' % (args.gpus, world))
     # BENCH_DIST_BACKEND=gloo lets several ranks share ONE card to rehearse the N>1 code path (never a result)
     backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
@@ -293,13 +374,43 @@ def main():
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     if args.workload == 'c3paper':
-        return run_c3(args, rank, world, local_rank, paper=True)
-    if args.workload == 'c3':
-        return run_c3(args, rank, world, local_rank)
-    if args.workload == 'c5':
-        return run_c5(args, rank, world, local_rank)
+        out = run_c3(args, rank, world, local_rank, paper=True)
+    elif args.workload == 'c3':
+        out = run_c3(args, rank, world, local_rank)
+    elif args.workload == 'c5':
+        out = run_c5(args, rank, world, local_rank)
+    elif args.workload == 'c1' and args.via == 'dropin':
+        out = run_c1_dropin(args)
+    else:
+        out = run_solver(args, rank, world, local_rank)
+        if args.workload == 'c2' and args.secondary_steps > 0:
+            # the second half of BASELINE.json.metric ("GAN iters/sec"): a short C3 run in the same job
+            sub = argparse.Namespace(**vars(args))
+            sub.steps, sub.warmup = args.secondary_steps, 2
+            sec = run_c3(sub, rank, world, local_rank)
+            out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+                                                    'higher_is_better', 'scaling', 'dtype', 'data', 'config', 'roofline',
+                                                    'last_gen_loss')}
+    # what actually ran: the process group's own size and backend (1 / none for a single process)
+    out['world_size'] = dist.get_world_size() if world > 1 else 1
+    out['dist_backend'] = dist.get_backend() if world > 1 else None
+    assert out['n_gpus'] == args.gpus == out['world_size']
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_solver(args, rank, world, local_rank):
+    import torch
+    import torch.distributed as dist
+    from tc_gan_amd import clib
+    from tc_gan_amd.clib import libssnode
     N, B, NB, T, desc = WORKLOADS[args.workload]
     M = 2 * N
     J, D, S = new_jds()
@@ -397,16 +508,16 @@ def main():
                      'kernel_ms': kernel_ms, 'flops_per_unit': flops_per_unit,
                      'algorithmic_hbm_bytes': B * (4 * M * M + 12 * M * NB)},
     }
+    out['world_size'] = world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(len(os.sched_getaffinity(0)), 16)           # the 1-GPU box's CPU share
         # ~10-20 s of host work at C2: the whole batch (4096 draws, ~5 s per pass on 16 threads), warm-up + best of 2
         sample = args.cpu_sample or (64 if args.workload == 'c1' else min(B, max(threads * 8, 4096 // NB)))
         out['cpu_baseline'] = cpu_baseline(N, NB, T, sample, threads)
         out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    return out
+
+
 
 
 if __name__ == '__main__':

@@ -4,6 +4,9 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
+#include <mutex>
+#include <utility>
 #include <string>
 #include <vector>
 #include "ssn_host.h"
@@ -65,80 +68,310 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     return 0;
 }
 
+// ---- host-buffer entry points: per-call arenas --------------------------------------------------
+// The reference calls its solver from up to cpu_count() Python threads at once (ssnode.py:436-459), one
+// small solve per call.  Each call borrows an Arena -- a non-blocking stream, a device buffer and a pinned
+// host staging buffer, all grown on demand and kept -- from a process-wide pool and gives it back on
+// return: no hipMalloc / hipFree / hipDeviceSynchronize per call, calls of different threads overlap on the
+// device (one stream each), and no state is shared between concurrent calls.  Arenas are never freed (the
+// pool outlives every caller; tearing HIP objects down from thread or process exit hooks is not safe).
+struct Arena {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char* dev = nullptr;   size_t dev_bytes = 0;
+    char* host = nullptr;  size_t host_bytes = 0;
+
+    hipError_t reserve(size_t need_dev, size_t need_host) {
+        if (!stream) {
+            hipError_t e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+            if (e != hipSuccess) return e;
+        }
+        if (need_dev > dev_bytes) {
+            if (dev) { hipStreamSynchronize(stream); hipFree(dev); dev = nullptr; dev_bytes = 0; }
+            const size_t n = need_dev < (1u << 20) ? (1u << 20) : need_dev + need_dev / 4;
+            hipError_t e = hipMalloc((void**)&dev, n);
+            if (e != hipSuccess) return e;
+            dev_bytes = n;
+        }
+        if (need_host > host_bytes) {
+            if (host) { hipStreamSynchronize(stream); hipHostFree(host); host = nullptr; host_bytes = 0; }
+            const size_t n = need_host < (1u << 20) ? (1u << 20) : need_host + need_host / 4;
+            hipError_t e = hipHostMalloc((void**)&host, n, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            host_bytes = n;
+        }
+        return hipSuccess;
+    }
+};
+
+class ArenaPool {
+    std::mutex mu_;
+    std::vector<Arena*> idle_;
+public:
+    Arena* acquire(int device) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (size_t i = idle_.size(); i-- > 0;)
+                if (idle_[i]->device == device) {
+                    Arena* a = idle_[i];
+                    idle_.erase(idle_.begin() + (long)i);
+                    return a;
+                }
+        }
+        Arena* a = new Arena();
+        a->device = device;
+        return a;
+    }
+    void release(Arena* a) {
+        std::lock_guard<std::mutex> g(mu_);
+        idle_.push_back(a);
+    }
+};
+ArenaPool& arena_pool() {
+    static ArenaPool* pool = new ArenaPool();      // leaked on purpose, see above
+    return *pool;
+}
+struct ArenaLease {
+    Arena* a = nullptr;
+    hipError_t open() {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        a = arena_pool().acquire(dev);
+        return hipSuccess;
+    }
+    ~ArenaLease() { if (a) arena_pool().release(a); }
+};
+inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// Host buffers below this size go through the pinned staging buffer (one memcpy, then truly asynchronous
+// copies); larger ones are handed to hipMemcpyAsync as they are (the runtime stages pageable memory itself).
+constexpr size_t kStageLimit = 8u << 20;
+
 template <typename T>
 int solve_batch_host_impl(const T* W, const T* ext, int ext_per_draw, T* r, T* r_prev, int* codes, int* steps,
                           int B, int NB, int M, const ssn_solver_params* p) {
     if (B == 0 || NB == 0) return 0;
+    if (!p || !W || !ext || !r || !codes || B < 0 || NB < 0 || M <= 0 || (M & 1)) {
+        g_last_error = "ssn_solve_batch_host: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
     const size_t nW = (size_t)B * M * M * sizeof(T);
     const size_t nE = (size_t)(ext_per_draw ? B : 1) * NB * M * sizeof(T);
     const size_t nR = (size_t)B * NB * M * sizeof(T);
     const size_t nC = (size_t)B * NB * sizeof(int);
-    T *dW = nullptr, *dE = nullptr, *dR = nullptr, *dP = nullptr;
-    int *dC = nullptr, *dS = nullptr;
-    int rc = 0;
-    auto cleanup = [&]() {
-        hipFree(dW); hipFree(dE); hipFree(dR); hipFree(dP); hipFree(dC); hipFree(dS);
-    };
-#define SSN_TRYC(expr)                                                    \
-    do {                                                                  \
-        hipError_t e__ = (expr);                                          \
-        if (e__ != hipSuccess) { cleanup(); return fail(e__, #expr); }    \
-    } while (0)
-    SSN_TRYC(hipMalloc(&dW, nW));
-    SSN_TRYC(hipMalloc(&dE, nE));
-    SSN_TRYC(hipMalloc(&dR, nR));
-    SSN_TRYC(hipMalloc(&dP, nR));
-    SSN_TRYC(hipMalloc(&dC, nC));
-    SSN_TRYC(hipMalloc(&dS, nC));
-    SSN_TRYC(hipMemcpy(dW, W, nW, hipMemcpyHostToDevice));
-    SSN_TRYC(hipMemcpy(dE, ext, nE, hipMemcpyHostToDevice));
-    SSN_TRYC(hipMemcpy(dR, r, nR, hipMemcpyHostToDevice));
-    rc = solve_batch_impl<T>(-1, dW, dE, ext_per_draw, dR, dP, dC, dS, B, NB, M, p, nullptr);
-    if (rc) { cleanup(); return rc; }
-    SSN_TRYC(hipDeviceSynchronize());
-    SSN_TRYC(hipMemcpy(r, dR, nR, hipMemcpyDeviceToHost));
-    if (r_prev) SSN_TRYC(hipMemcpy(r_prev, dP, nR, hipMemcpyDeviceToHost));
-    SSN_TRYC(hipMemcpy(codes, dC, nC, hipMemcpyDeviceToHost));
-    if (steps) SSN_TRYC(hipMemcpy(steps, dS, nC, hipMemcpyDeviceToHost));
-    cleanup();
+    // device image: [W | ext | r | r_prev | codes | steps]; the host staging image has the same offsets
+    const size_t oW = 0, oE = oW + align256(nW), oR = oE + align256(nE), oP = oR + align256(nR),
+                 oC = oP + align256(nR), oS = oC + align256(nC), total = oS + align256(nC);
+    const bool staged = total <= kStageLimit;
+    ArenaLease lease;
+    SSN_TRY(lease.open());
+    Arena& A = *lease.a;
+    SSN_TRY(A.reserve(total, staged ? total : 0));
+    hipStream_t st = A.stream;
+    T *dW = (T*)(A.dev + oW), *dE = (T*)(A.dev + oE), *dR = (T*)(A.dev + oR), *dP = (T*)(A.dev + oP);
+    int *dC = (int*)(A.dev + oC), *dS = (int*)(A.dev + oS);
+    if (staged) {
+        std::memcpy(A.host + oW, W, nW);
+        std::memcpy(A.host + oE, ext, nE);
+        std::memcpy(A.host + oR, r, nR);
+        // one upload for the three inputs (they are contiguous in both images up to the end of r)
+        SSN_TRY(hipMemcpyAsync(A.dev, A.host, oR + nR, hipMemcpyHostToDevice, st));
+    } else {
+        SSN_TRY(hipMemcpyAsync(dW, W, nW, hipMemcpyHostToDevice, st));
+        SSN_TRY(hipMemcpyAsync(dE, ext, nE, hipMemcpyHostToDevice, st));
+        SSN_TRY(hipMemcpyAsync(dR, r, nR, hipMemcpyHostToDevice, st));
+    }
+    int rc = solve_batch_impl<T>(-1, dW, dE, ext_per_draw, dR, dP, dC, dS, B, NB, M, p, st);
+    if (rc) return rc;
+    if (staged) {
+        // one download: [r | r_prev | codes | steps]
+        SSN_TRY(hipMemcpyAsync(A.host + oR, A.dev + oR, total - oR, hipMemcpyDeviceToHost, st));
+        SSN_TRY(hipStreamSynchronize(st));
+        std::memcpy(r, A.host + oR, nR);
+        if (r_prev) std::memcpy(r_prev, A.host + oP, nR);
+        std::memcpy(codes, A.host + oC, nC);
+        if (steps) std::memcpy(steps, A.host + oS, nC);
+    } else {
+        SSN_TRY(hipMemcpyAsync(r, dR, nR, hipMemcpyDeviceToHost, st));
+        if (r_prev) SSN_TRY(hipMemcpyAsync(r_prev, dP, nR, hipMemcpyDeviceToHost, st));
+        SSN_TRY(hipMemcpyAsync(codes, dC, nC, hipMemcpyDeviceToHost, st));
+        if (steps) SSN_TRY(hipMemcpyAsync(steps, dS, nC, hipMemcpyDeviceToHost, st));
+        SSN_TRY(hipStreamSynchronize(st));
+    }
     return 0;
-#undef SSN_TRYC
 }
 
-// The reference's single-solve entry point on the GPU (fp64 kernel, one workgroup),
-// leaving the caller's two buffers as ssnode.c's pointer-swapping loop would.
+// ---- the reference's single-solve entry point ----------------------------------------------------
+// One call = one (W, ext) pair = one workgroup of the fp64 kernel: latency-bound (~1 us per Euler step), and the
+// runtime multiplexes streams onto a handful of hardware queues, so 16 caller threads with a stream each still run
+// only ~4 solves at a time.  Calls that are in flight together are therefore COMBINED: a caller enqueues its request;
+// whoever finds no leader active becomes the leader, takes every queued request with the same size and parameters,
+// runs them as ONE batched launch (B = number of callers, one workgroup each) and hands the results back.  While a
+// batch runs, the other threads' next calls queue up and form the next batch.  A lone caller is a batch of one.
+// Results do not depend on the batching: every (draw, stimulus) pair is solved by its own workgroup with its own stop
+// logic (tests/test_solver_gpu.py: batch-independence is bitwise).
+struct SolveReq {
+    int device, N;
+    const double *W, *ext;
+    double *r0, *r1;
+    ssn_solver_params p;
+    int code = -1, steps = 0, rc = 0;
+    bool done = false;
+    bool same_shape(const SolveReq& o) const {
+        return device == o.device && N == o.N && p.io_type == o.p.io_type && p.max_iter == o.p.max_iter && p.k == o.p.k &&
+               p.n == o.p.n && p.tau_E == o.p.tau_E && p.tau_I == o.p.tau_I && p.dt == o.p.dt && p.atol == o.p.atol &&
+               p.rate_soft_bound == o.p.rate_soft_bound && p.rate_hard_bound == o.p.rate_hard_bound;
+    }
+};
+
+// Solve a group of same-shaped requests in one launch.  Returns 0 or an SSN_ERR code (applies to the whole group).
+int solve_group(const std::vector<SolveReq*>& grp) {
+    const int B = (int)grp.size(), M = 2 * grp[0]->N;
+    const size_t nW1 = (size_t)M * M * sizeof(double), nV1 = (size_t)M * sizeof(double);
+    const size_t oW = 0, oE = oW + align256(B * nW1), oR = oE + align256(B * nV1), oP = oR + align256(B * nV1),
+                 oC = oP + align256(B * nV1), oS = oC + align256(B * sizeof(int)), total = oS + align256(B * sizeof(int));
+    const bool staged = total <= kStageLimit;
+    // the group runs on ITS callers' device; the leader's own current device is put back on return
+    struct DeviceScope {
+        int prev = -1; bool changed = false;
+        explicit DeviceScope(int want) { if (hipGetDevice(&prev) == hipSuccess && prev != want) changed = hipSetDevice(want) == hipSuccess; }
+        ~DeviceScope() { if (changed) (void)hipSetDevice(prev); }
+    } scope(grp[0]->device);
+    ArenaLease lease;
+    SSN_TRY(lease.open());
+    Arena& A = *lease.a;
+    SSN_TRY(A.reserve(total, staged ? total : 0));
+    hipStream_t st = A.stream;
+    double *dW = (double*)(A.dev + oW), *dE = (double*)(A.dev + oE), *dR = (double*)(A.dev + oR), *dP = (double*)(A.dev + oP);
+    int *dC = (int*)(A.dev + oC), *dS = (int*)(A.dev + oS);
+    if (staged) {
+        for (int b = 0; b < B; ++b) {
+            std::memcpy(A.host + oW + b * nW1, grp[b]->W, nW1);
+            std::memcpy(A.host + oE + b * nV1, grp[b]->ext, nV1);
+            std::memcpy(A.host + oR + b * nV1, grp[b]->r0, nV1);
+        }
+        SSN_TRY(hipMemcpyAsync(A.dev, A.host, oR + B * nV1, hipMemcpyHostToDevice, st));
+    } else {
+        for (int b = 0; b < B; ++b) {
+            SSN_TRY(hipMemcpyAsync((char*)dW + b * nW1, grp[b]->W, nW1, hipMemcpyHostToDevice, st));
+            SSN_TRY(hipMemcpyAsync((char*)dE + b * nV1, grp[b]->ext, nV1, hipMemcpyHostToDevice, st));
+            SSN_TRY(hipMemcpyAsync((char*)dR + b * nV1, grp[b]->r0, nV1, hipMemcpyHostToDevice, st));
+        }
+    }
+    int rc = solve_batch_impl<double>(-1, dW, dE, /*ext_per_draw=*/1, dR, dP, dC, dS, B, 1, M, &grp[0]->p, st);
+    if (rc) return rc;
+    std::vector<int> cs(2 * (size_t)B);
+    if (staged) {
+        SSN_TRY(hipMemcpyAsync(A.host + oR, A.dev + oR, total - oR, hipMemcpyDeviceToHost, st));
+        SSN_TRY(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) {
+            std::memcpy(grp[b]->r0, A.host + oR + b * nV1, nV1);     // newest state
+            std::memcpy(grp[b]->r1, A.host + oP + b * nV1, nV1);     // state one step before
+            cs[b] = ((const int*)(A.host + oC))[b];
+            cs[B + b] = ((const int*)(A.host + oS))[b];
+        }
+    } else {
+        for (int b = 0; b < B; ++b) {
+            SSN_TRY(hipMemcpyAsync(grp[b]->r0, (char*)dR + b * nV1, nV1, hipMemcpyDeviceToHost, st));
+            SSN_TRY(hipMemcpyAsync(grp[b]->r1, (char*)dP + b * nV1, nV1, hipMemcpyDeviceToHost, st));
+        }
+        SSN_TRY(hipMemcpyAsync(cs.data(), dC, B * sizeof(int), hipMemcpyDeviceToHost, st));
+        SSN_TRY(hipMemcpyAsync(cs.data() + B, dS, B * sizeof(int), hipMemcpyDeviceToHost, st));
+        SSN_TRY(hipStreamSynchronize(st));
+    }
+    for (int b = 0; b < B; ++b) {
+        SolveReq& q = *grp[b];
+        q.code = cs[b]; q.steps = cs[B + b];
+        // Now r0 = newest, r1 = previous.  Which caller buffer plays "r0" after `swaps` role exchanges
+        // (ssnode.c:104-106) decides where the reference would have left them.
+        if (q.code == 0) {
+            // converged: the newest state is copied into the current "r0" role, so BOTH buffers hold it
+            std::memcpy(q.r1, q.r0, nV1);
+        } else {
+            // code 2: return before the exchange -> swaps = steps-1, newest is in the "r1" role.
+            // code 1: all max_iter exchanges done -> newest is in the "r0" role after `steps` swaps.
+            const int swaps = (q.code == 2) ? q.steps - 1 : q.steps;
+            const bool r0_role_is_caller_r0 = (swaps % 2 == 0);
+            const bool newest_in_r0_role = (q.code == 1);
+            if (newest_in_r0_role != r0_role_is_caller_r0)
+                for (int i = 0; i < M; ++i) std::swap(q.r0[i], q.r1[i]);
+        }
+    }
+    return 0;
+}
+
+class SolveCombiner {
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool leader_active_ = false;
+    std::vector<SolveReq*> pending_;
+    static constexpr size_t kMaxGroup = 256;
+public:
+    int submit(SolveReq& q) {
+        std::unique_lock<std::mutex> lk(mu_);
+        pending_.push_back(&q);
+        while (!q.done) {
+            if (leader_active_) { cv_.wait(lk); continue; }
+            // become the leader for one batch: the oldest request and everything queued that matches it
+            leader_active_ = true;
+            std::vector<SolveReq*> grp, rest;
+            for (SolveReq* r : pending_)
+                (grp.size() < kMaxGroup && (grp.empty() || r->same_shape(*grp[0])) ? grp : rest).push_back(r);
+            pending_.swap(rest);
+            lk.unlock();
+            int rc = solve_group(grp);
+            const std::string err = g_last_error;      // the leader's thread-local message, for every member
+            lk.lock();
+            for (SolveReq* r : grp) { r->rc = rc; r->done = true; }
+            (void)err;
+            leader_active_ = false;
+            cv_.notify_all();
+        }
+        return q.rc;
+    }
+};
+SolveCombiner& combiner() {
+    static SolveCombiner* c = new SolveCombiner();     // leaked on purpose, like the arena pool
+    return *c;
+}
+
+// Leaves the caller's two buffers as ssnode.c's pointer-swapping loop would (DESIGN.md "buffer parity").
 int legacy_solve(int io_type, int N, double* W, double* ext, double k, double n, double* r0, double* r1,
                  double tau_E, double tau_I, double dt, int max_iter, double atol, double soft, double hard) {
     if (N <= 0 || !W || !ext || !r0 || !r1) {
         g_last_error = "solve_dynamics: invalid argument";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
-    ssn_solver_params p;
-    p.io_type = io_type; p.max_iter = max_iter < 0 ? 0 : max_iter; p.k = k; p.n = n; p.tau_E = tau_E;
-    p.tau_I = tau_I; p.dt = dt; p.atol = atol; p.rate_soft_bound = soft; p.rate_hard_bound = hard;
-    const int M = 2 * N;
-    if (p.max_iter == 0) return 1;   // ssnode.c: loop body never runs, buffers untouched
-    std::vector<double> newest(r0, r0 + M), prev(M);
-    int code = -1, steps = 0;
-    int rc = solve_batch_host_impl<double>(W, ext, 0, newest.data(), prev.data(), &code, &steps, 1, 1, M, &p);
-    if (rc) return rc;
-    // Which caller buffer plays "r0" after `swaps` role exchanges (ssnode.c:104-106).
-    if (code == 0) {
-        // converged at step `steps`: swaps = steps-1; the newest state is copied into the current "r0"
-        // buffer, so BOTH roles hold it; the other caller buffer keeps what it had as "r1" = newest too.
-        std::memcpy(r0, newest.data(), M * sizeof(double));
-        std::memcpy(r1, newest.data(), M * sizeof(double));
-    } else {
-        // code 2: return before the exchange -> swaps = steps-1, newest is in the "r1" role.
-        // code 1: all max_iter exchanges done -> newest is in the "r0" role after `steps` swaps.
-        const int swaps = (code == 2) ? steps - 1 : steps;
-        const bool r0_role_is_caller_r0 = (swaps % 2 == 0);
-        const bool newest_in_r0_role = (code == 1);
-        const bool newest_to_caller_r0 = (newest_in_r0_role == r0_role_is_caller_r0);
-        std::memcpy(newest_to_caller_r0 ? r0 : r1, newest.data(), M * sizeof(double));
-        std::memcpy(newest_to_caller_r0 ? r1 : r0, prev.data(), M * sizeof(double));
-    }
-    return code;
+    if (max_iter <= 0) return 1;   // ssnode.c: loop body never runs, buffers untouched
+    SolveReq q;
+    q.N = N; q.W = W; q.ext = ext; q.r0 = r0; q.r1 = r1;
+    q.p.io_type = io_type; q.p.max_iter = max_iter; q.p.k = k; q.p.n = n; q.p.tau_E = tau_E;
+    q.p.tau_I = tau_I; q.p.dt = dt; q.p.atol = atol; q.p.rate_soft_bound = soft; q.p.rate_hard_bound = hard;
+    SSN_TRY(hipGetDevice(&q.device));
+    const int rc = combiner().submit(q);
+    if (rc) { if (g_last_error.empty()) g_last_error = "solve_dynamics: batched launch failed"; return rc; }
+    return q.code;
+}
+
+// Scalar helpers of the drop-in surface: `count` doubles in, `count_out` doubles out, one small kernel
+// between them, on a borrowed arena (no allocation per call).
+template <typename Launch>
+bool scalar_roundtrip(const double* in, size_t n_in, double* out, size_t n_out, Launch&& launch) {
+    ArenaLease lease;
+    if (lease.open() != hipSuccess) return false;
+    Arena& A = *lease.a;
+    const size_t bytes = (n_in + n_out) * sizeof(double);
+    if (A.reserve(bytes, bytes) != hipSuccess) return false;
+    double* h = (double*)A.host;
+    double* d = (double*)A.dev;
+    std::memcpy(h, in, n_in * sizeof(double));
+    if (hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, A.stream) != hipSuccess) return false;
+    if (launch(d, d + n_in, A.stream) != hipSuccess) return false;
+    if (hipMemcpyAsync(h + n_in, d + n_in, n_out * sizeof(double), hipMemcpyDeviceToHost, A.stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(A.stream) != hipSuccess) return false;
+    std::memcpy(out, h + n_in, n_out * sizeof(double));
+    return true;
 }
 
 double legacy_io(int io_type, double v, double r0, double r1, double v0, double k, double n) {
@@ -151,13 +384,10 @@ double legacy_io(int io_type, double v, double r0, double r1, double v0, double 
     c.span = r1 - r0;
     c.span_gain = c.span * c.tanh_gain;
     c.log2k = std::log2(k);
-    double *dv = nullptr, out = std::numeric_limits<double>::quiet_NaN();
-    if (hipMalloc(&dv, 2 * sizeof(double)) != hipSuccess) return out;
-    if (hipMemcpy(dv, &v, sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-        ssn::launch_io_eval<double>(dv, dv + 1, 1, c, nullptr) == hipSuccess &&
-        hipDeviceSynchronize() == hipSuccess)
-        hipMemcpy(&out, dv + 1, sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dv);
+    double out = std::numeric_limits<double>::quiet_NaN();
+    scalar_roundtrip(&v, 1, &out, 1, [&](double* dv, double* dout, hipStream_t st) {
+        return ssn::launch_io_eval<double>(dv, dout, 1, c, st);
+    });
     return out;
 }
 
@@ -582,27 +812,23 @@ double rate_to_volt(double rate, double k, double n) {
     std::memset(&p, 0, sizeof(p));
     p.io_type = SSN_IO_POWER; p.k = 1.0; p.n = 1.0 / n; p.rate_soft_bound = 1.0; p.rate_hard_bound = 2.0;
     const double x = rate / k;
-    double *dv = nullptr, out = std::numeric_limits<double>::quiet_NaN();
-    if (hipMalloc(&dv, 2 * sizeof(double)) != hipSuccess) return out;
-    if (hipMemcpy(dv, &x, sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-        ssn::launch_io_eval<double>(dv, dv + 1, 1, ssn::make_io_consts<double>(p), nullptr) == hipSuccess &&
-        hipDeviceSynchronize() == hipSuccess)
-        hipMemcpy(&out, dv + 1, sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(dv);
+    double out = std::numeric_limits<double>::quiet_NaN();
+    const ssn::IoConsts<double> c = ssn::make_io_consts<double>(p);
+    scalar_roundtrip(&x, 1, &out, 1, [&](double* dv, double* dout, hipStream_t st) {
+        return ssn::launch_io_eval<double>(dv, dout, 1, c, st);
+    });
     return out;
 }
 
 double dot(int dim, const double* x, const double* y) {
-    double out = std::numeric_limits<double>::quiet_NaN();
     if (dim <= 0) return 0.0;
-    double* d = nullptr;
-    if (hipMalloc(&d, (2 * (size_t)dim + 1) * sizeof(double)) != hipSuccess) return out;
-    if (hipMemcpy(d, x, dim * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-        hipMemcpy(d + dim, y, dim * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-        ssn::launch_dot<double>(d, d + dim, d + 2 * dim, dim, nullptr) == hipSuccess &&
-        hipDeviceSynchronize() == hipSuccess)
-        hipMemcpy(&out, d + 2 * dim, sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(d);
+    double out = std::numeric_limits<double>::quiet_NaN();
+    std::vector<double> xy(2 * (size_t)dim);
+    std::memcpy(xy.data(), x, dim * sizeof(double));
+    std::memcpy(xy.data() + dim, y, dim * sizeof(double));
+    scalar_roundtrip(xy.data(), xy.size(), &out, 1, [&](double* d, double* dout, hipStream_t st) {
+        return ssn::launch_dot<double>(d, d + dim, dout, dim, st);
+    });
     return out;
 }
 

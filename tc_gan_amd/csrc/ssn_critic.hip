@@ -49,6 +49,7 @@ struct GemmArgs {
     const float* mask; long ldm;       // [M][ldm] > 0 (MASK): C = acc * (mask > 0)
     int epilogue;
     int kchunk;                        // K range per blockIdx.z (split-K; PLAIN with beta == 1 only)
+    float* partial;                    // split-K: slice z writes its tile sums to partial[z][m*N + n] (no atomics)
 };
 
 template <bool BF16>
@@ -135,28 +136,103 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
             float* c = g.C + m * g.ldc + n;
             if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : 0.f; }
             else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : 0.f; }
-            else if (gridDim.z > 1) { atomicAdd(c, g.alpha * v); continue; }      // split-K partial (beta == 1)
+            else if (gridDim.z > 1) { g.partial[((long)blockIdx.z * g.M + m) * g.N + n] = v; continue; }   // split-K partial
             else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
             *c = v;
         }
     }
 }
 
+// ---- deterministic split-K ---------------------------------------------------------------------------------------
+// Weight-gradient GEMMs contract over the batch (K = 1024..3072) into a small M x N: few output tiles, long K loop, so
+// K is split over blockIdx.z to fill the chip.  The slices do NOT add into C with atomics (the order of fp32 atomic
+// adds changes from run to run, and Adam turns a last-bit difference of a near-zero gradient into a full-size step:
+// two identical-seed GAN runs drifted apart within a few updates).  Each slice stores its sums to a scratch slab and ONE
+// reduction kernel per critic update adds the slabs of every split GEMM of that update in slice order:
+// C += alpha * (p_0 + p_1 + ...).  The plan lives on the calling thread between begin and flush.
+struct SplitKEntry { float* C; const float* partial; long mn; int splits; float alpha; };
+constexpr int kMaxSplitK = 24;
+struct SplitKPlan { float* scratch; size_t cap, used; int n; SplitKEntry e[kMaxSplitK]; };
+static thread_local SplitKPlan tl_plan{nullptr, 0, 0, 0, {}};
+// entries that accumulate into the same C (the [xg; xd] chain and the penalty chain both add into one weight's gradient)
+// form one group, handled by the same threads one entry after the other, in the order the GEMMs were issued
+struct SplitKReduceArgs { SplitKEntry e[kMaxSplitK]; int group_of[kMaxSplitK][4]; int group_len[kMaxSplitK]; };
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(SplitKReduceArgs a) {
+    const int grp = blockIdx.y, len = a.group_len[grp];
+    const long mn = a.e[a.group_of[grp][0]].mn;
+    float* C = a.e[a.group_of[grp][0]].C;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < mn; i += gridDim.x * 256L) {
+        float c = C[i];
+        for (int k = 0; k < len; ++k) {
+            const SplitKEntry& en = a.e[a.group_of[grp][k]];
+            float s = en.partial[i];
+            for (int z = 1; z < en.splits; ++z) s += en.partial[z * mn + i];
+            c += en.alpha * s;
+        }
+        C[i] = c;
+    }
+}
+
+static int choose_splits(int M, int N, int K) {
+    const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+    if (K < 512 || tiles >= 256) return 1;
+    int splits = (512 + tiles - 1) / tiles;
+    const int maxs = K / 128;
+    if (splits > maxs) splits = maxs;
+    return splits < 1 ? 1 : splits;
+}
+// upper bound of the scratch one critic update needs: two weight-gradient GEMMs per layer and per output vector
+size_t critic_splitk_scratch_floats(const int* dims, int nlayers, int rows) {
+    size_t n = 0;
+    for (int l = 0; l < nlayers; ++l) n += 2 * (size_t)choose_splits(dims[l], dims[l + 1], rows) * dims[l] * dims[l + 1];
+    n += 2 * (size_t)choose_splits(dims[nlayers], 1, rows) * dims[nlayers];
+    return n + 64;
+}
+void critic_splitk_begin(float* scratch, size_t cap) { tl_plan.scratch = scratch; tl_plan.cap = cap; tl_plan.used = 0; tl_plan.n = 0; }
+hipError_t critic_splitk_flush(hipStream_t st) {
+    hipError_t e = hipSuccess;
+    if (tl_plan.n > 0) {
+        SplitKReduceArgs a;
+        int groups = 0;
+        long most = 0;
+        for (int i = 0; i < tl_plan.n; ++i) {
+            a.e[i] = tl_plan.e[i];
+            if (a.e[i].mn > most) most = a.e[i].mn;
+            int g = 0;
+            while (g < groups && a.e[a.group_of[g][0]].C != a.e[i].C) ++g;
+            if (g == groups) a.group_len[groups++] = 0;
+            a.group_of[g][a.group_len[g]++] = i;
+        }
+        long bx = (most + 255) / 256;
+        if (bx > 256) bx = 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)bx, groups), dim3(256), 0, st, a);
+        e = hipGetLastError();
+    }
+    tl_plan.scratch = nullptr; tl_plan.cap = tl_plan.used = 0; tl_plan.n = 0;
+    return e;
+}
+
 static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    // Weight-gradient GEMMs contract over the batch (K = 1024..2048) into a small M x N: few output tiles,
-    // long K loop.  Split K over blockIdx.z (fp32 atomics into the accumulating gradient) to fill the chip.
     int splits = 1;
-    const int tiles = ((g.N + 63) / 64) * ((g.M + 63) / 64);
-    if (g.epilogue == EPI_PLAIN && g.beta == 1.f && g.K >= 512 && tiles < 256) {
-        splits = (512 + tiles - 1) / tiles;
-        const int maxs = g.K / 128;
-        if (splits > maxs) splits = maxs;
-        if (splits < 1) splits = 1;
+    if (g.epilogue == EPI_PLAIN && g.beta == 1.f && g.ldc == g.N && tl_plan.scratch && tl_plan.n < kMaxSplitK) {
+        splits = choose_splits(g.M, g.N, g.K);
+        int same = 0;
+        for (int i = 0; i < tl_plan.n; ++i) same += tl_plan.e[i].C == g.C;
+        // no room, or a 5th split GEMM into one C: run it unsplit.  An unsplit GEMM adds into C directly, BEFORE the
+        // slabs of earlier split ones are added at the flush -- a fixed order either way.
+        if (same >= 4 || tl_plan.used + (size_t)splits * g.M * g.N > tl_plan.cap) splits = 1;
     }
     const int bk = bf16 ? 32 : 16;
     g.kchunk = ((g.K + splits - 1) / splits + bk - 1) / bk * bk;
     splits = (g.K + g.kchunk - 1) / g.kchunk;
+    g.partial = nullptr;
+    if (splits > 1) {
+        g.partial = tl_plan.scratch + tl_plan.used;
+        tl_plan.e[tl_plan.n++] = SplitKEntry{g.C, g.partial, (long)g.M * g.N, splits, g.alpha};
+        tl_plan.used += (size_t)splits * g.M * g.N;
+    }
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
     if (bf16) hipLaunchKernelGGL((gemm_mfma_kernel<true>), grid, dim3(256), 0, st, g);
     else      hipLaunchKernelGGL((gemm_mfma_kernel<false>), grid, dim3(256), 0, st, g);
@@ -381,7 +457,8 @@ size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int b
     // (1) h_0..h_L and v_0..v_L for the [xg; xd] rows + upstream; (2) h, v, e for the xp rows + D(xp); + scratch
     long per_row = 0, maxd = 0;
     for (int l = 0; l <= nlayers; ++l) { per_row += dims[l]; if (dims[l] > maxd) maxd = dims[l]; }
-    return (size_t)(2L * batch_gd * per_row + batch_gd + 3L * batch_p * per_row + batch_p + maxd + 64);
+    return (size_t)(2L * batch_gd * per_row + batch_gd + 3L * batch_p * per_row + batch_p + maxd + 64) +
+           critic_splitk_scratch_floats(dims, nlayers, batch_gd + batch_p);
 }
 
 // D values for a batch (inference / accuracy): out[batch]
@@ -414,6 +491,14 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     for (int l = 0; l <= L; ++l) { h[l] = p; p += (long)bgd * dims[l]; }
     for (int l = 0; l <= L; ++l) { v[l] = p; p += (long)bgd * dims[l]; }
     float* up = p; p += bgd;
+    float *hp[10], *vp[10], *ep[10];
+    for (int l = 0; l <= L; ++l) { hp[l] = p; p += (long)np * dims[l]; }
+    for (int l = 0; l <= L; ++l) { vp[l] = p; p += (long)np * dims[l]; }
+    for (int l = 0; l <= L; ++l) { ep[l] = p; p += (long)np * dims[l]; }
+    float* dp = p; p += np;
+    float* tmp = p; p += dims[L];
+    critic_splitk_begin(p, critic_splitk_scratch_floats(dims, nlayers, bgd + np));     // the rest of the workspace
+    struct PlanScope { ~PlanScope() { critic_splitk_begin(nullptr, 0); } } plan_scope;    // closed on every return path
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type);
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type);
     if ((e = critic_forward_pass(net, h, dvals, bgd, bf16, st)) != hipSuccess) return e;
@@ -432,12 +517,6 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st)) != hipSuccess) return e;
 
     // ---------------- (2) gradient penalty on xp ------------------------------------------------
-    float *hp[10], *vp[10], *ep[10];
-    for (int l = 0; l <= L; ++l) { hp[l] = p; p += (long)np * dims[l]; }
-    for (int l = 0; l <= L; ++l) { vp[l] = p; p += (long)np * dims[l]; }
-    for (int l = 0; l <= L; ++l) { ep[l] = p; p += (long)np * dims[l]; }
-    float* dp = p; p += np;
-    float* tmp = p; p += dims[L];
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type);
     if ((e = critic_forward_pass(net, hp, dp, np, bf16, st)) != hipSuccess) return e;
     // input gradient g = dD/dh0 per sample: v_L = m_L * w_out, chain down to vp[0]
@@ -472,7 +551,8 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(1024), 0, st, ep[L], tmp, np, dims[L], 0.f);
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(dims[L])), dim3(256), 0, st, grads + (net.nparams - dims[L]), tmp, lmd, (long)dims[L]);
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
-    return hipGetLastError();
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    return critic_splitk_flush(st);                   // grads += the split GEMMs' slabs, in slice order
 }
 
 // Gradient of  -mean D(x)  w.r.t. the tuning-curve part of the input (generator side, wgan.py:236):

@@ -27,6 +27,9 @@ hipError_t critic_make_input(const float* x, const float* cond, float* h0, int b
 hipError_t critic_gp_head(const float* g, float* ghat, float* pen, int batch, int n0, int nx, hipStream_t st);
 hipError_t critic_two_means(const float* d, float* out, int ng, int nd, hipStream_t st);
 hipError_t critic_loss_combine(float* stats, float lmd, hipStream_t st);
+size_t critic_splitk_scratch_floats(const int* dims, int nlayers, int rows);
+void critic_splitk_begin(float* scratch, size_t cap);
+hipError_t critic_splitk_flush(hipStream_t st);
 hipError_t critic_gather_scale(const float* v0, float* gx, int batch, int n0, int nx, float s, hipStream_t st);
 
 constexpr float LN_EPS = 1e-4f;
@@ -223,7 +226,8 @@ size_t critic_norm_workspace_floats(const int* dims, int nlayers, int batch_gd, 
     long per_row = 0, maxd = 0;
     for (int l = 0; l <= nlayers; ++l) { per_row += dims[l]; if (dims[l] > maxd) maxd = dims[l]; }
     const long acts = 5 * per_row + (nlayers + 1);
-    return (size_t)((long)batch_gd * (acts + 2) + (long)batch_p * (acts + 6 * per_row + (nlayers + 1) + 2) + 2 * maxd + 64);
+    return (size_t)((long)batch_gd * (acts + 2) + (long)batch_p * (acts + 6 * per_row + (nlayers + 1) + 2) + 2 * maxd + 64) +
+           critic_splitk_scratch_floats(dims, nlayers, batch_gd + batch_p);
 }
 
 hipError_t critic_norm_forward(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
@@ -287,6 +291,8 @@ hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int
         dpre[l] = carve(p, (long)np * dims[l]); da[l] = carve(p, (long)np * dims[l]); dsA[l] = carve(p, np);
     }
     // (dh_{l-1} of sweep 2 is written into dc[l-1], which is free by then)
+    critic_splitk_begin(p, critic_splitk_scratch_floats(dims, nlayers, rows));      // the rest of the workspace
+    struct PlanScope { ~PlanScope() { critic_splitk_begin(nullptr, 0); } } plan_scope;    // closed on every return path
     if ((e = critic_make_input(xg, cg, A.h[0], ng, nx, hide, st)) != hipSuccess) return e;
     if ((e = critic_make_input(xd, cd, A.h[0] + (long)ng * dims[0], nd, nx, hide, st)) != hipSuccess) return e;
     if ((e = critic_make_input(xp, cp, P.h[0], np, nx, hide, st)) != hipSuccess) return e;
@@ -324,7 +330,8 @@ hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int
             dh_cur = dc[l - 1];
         }
     }
-    return critic_loss_combine(stats, lmd, st);
+    if ((e = critic_loss_combine(stats, lmd, st)) != hipSuccess) return e;
+    return critic_splitk_flush(st);                   // grads += the split GEMMs' slabs, in slice order
 }
 
 }  // namespace ssn

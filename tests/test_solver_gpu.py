@@ -79,6 +79,56 @@ def test_legacy_symbols_match_reference_end_states_and_buffer_parity():
         np.testing.assert_allclose(r1, g['r1_%d' % c['id']], rtol=RTOL64, atol=1e-12)
 
 
+def test_legacy_symbols_are_reentrant_from_16_threads():
+    """The reference calls the solver from cpu_count() Python threads with disjoint buffers and the GIL released
+    (ssnode.py:436-459).  Every golden case, submitted 4 times over from a 16-thread pool in shuffled order,
+    together with interleaved scalar helper calls: each call must return exactly what a lone call returns (codes and
+    both caller buffers vs the reference build's fixtures)."""
+    from multiprocessing.dummy import Pool
+    from tc_gan_amd.clib import libssnode, double_ptr
+    g = golden('solver_cases.npz')
+    jds = on.new_JDS()
+    jobs = []
+    for c in g['cases']:
+        N = int(c['N'])
+        key = 'W_%d' % c['id']
+        if key in g.files:
+            W, ext = g[key], g['ext_%d' % c['id']]
+        else:
+            z = np.random.RandomState(int(c['seed'])).rand(2 * N, 2 * N)
+            W = on.generate_weight(N, jds['J'], jds['D'], jds['S'], z)
+            ext = on.stimulus_input([float(c['bw'])], np.linspace(-.5, .5, N), P['smoothness'], [20.])[0]
+        jobs.append((c, np.ascontiguousarray(W), np.ascontiguousarray(ext)))
+    jobs = jobs * 4
+    np.random.RandomState(3).shuffle(jobs)
+    io_want = float(on.io_fun(1.7, 'asym_tanh', P['k'], P['n'], 200., 1000.))
+
+    def run(job):
+        c, W, ext = job
+        N = int(c['N'])
+        r0 = np.zeros(2 * N); r1 = np.full(2 * N, np.nan)
+        name = {'asym_power': 'power', 'asym_linear': 'linear', 'asym_tanh': 'tanh'}[str(c['io_type'])]
+        code = getattr(libssnode, 'solve_dynamics_asym_%s_euler' % name)(
+            N, W.ctypes.data_as(double_ptr), ext.ctypes.data_as(double_ptr), P['k'], P['n'],
+            r0.ctypes.data_as(double_ptr), r1.ctypes.data_as(double_ptr), P['tau'][0], P['tau'][1],
+            float(c['dt']), int(c['max_iter']), float(c['atol']), float(c['soft']), float(c['hard']))
+        io = libssnode.io_atanh(1.7, 200., 1000., on.rate_to_volt(200., P['k'], P['n']), P['k'], P['n'])
+        return int(c['id']), code, r0, r1, io
+
+    pool = Pool(16)
+    try:
+        results = pool.map(run, jobs, chunksize=1)
+    finally:
+        pool.close(); pool.join()
+    cases = {int(c['id']): c for c in g['cases']}
+    assert len(results) == len(jobs)
+    for cid, code, r0, r1, io in results:
+        assert code == int(cases[cid]['code'])
+        np.testing.assert_allclose(r0, g['r0_%d' % cid], rtol=RTOL64, atol=1e-12)
+        np.testing.assert_allclose(r1, g['r1_%d' % cid], rtol=RTOL64, atol=1e-12)
+        np.testing.assert_allclose(io, io_want, rtol=1e-12)
+
+
 def test_legacy_io_symbols_vs_reference_tables():
     # reference tolerance tests/test_ssn.py:21,63: atol 1e-12
     from tc_gan_amd.clib import libssnode
