@@ -112,28 +112,22 @@ def cpu_baseline(N, NB, T, sample_B, threads):
                        (sample_B, NB, T, M, threads, best))
 
 
-def run_c3(args, rank, world, local_rank, paper=False):
-    """``paper=True``: the shape of the reference's published run (scripts/fig4/gan/run.json): 2N=202, 128 models,
-    seqlen 240 / skip 200, tau_E=2, deg-heteroin SSN, 4x128 critic with LayerNorm on layers 2-4, rmsprop.
-    Default: BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
-    updates (each with a fresh generator forward) + one generator BPTT update; 1024 weight draws x 8
-    bandwidths per GPU, 2N=200, seqlen 1200 / skip 1000, 3x512 critic on bf16 MFMA, adam-wgan.
-    N>1: num_models = 1024*N sharded 1024 per rank, one RCCL all-reduce per update (weak scaling);
-    value = N x iterations/s, i.e. 1024-model GAN iterations per second over the whole job."""
-    import torch
-    import torch.distributed as dist
+def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iters_init=5, critic_iters=5, models=None):
+    """The GAN of BASELINE config 3/4 (or, `paper=True`, of scripts/fig4/gan/run.json) with its truth data set:
+    returns (gan, (N, models_per_rank, NB, T, skip), bandwidths).  Shared by the bench and by the full-size parity test."""
     from tc_gan_amd.networks.cwgan import make_gan
     J, D, S = new_jds()
-    N, models, NB, T, skip = (101, 128, 8, 240, 200) if paper else (100, 1024, 8, 1200, 1000)
+    N, default_models, NB, T, skip = (101, 128, 8, 240, 200) if paper else (100, 1024, 8, 1200, 1000)
+    models = models or default_models
     bandwidths = [0, 0.0625, 0.125, 0.1875, 0.25, 0.5, 0.75, 1]
     cfg = dict(num_sites=N, num_models=models * world, probes_per_model=1, norm_probes=[0.0],
                include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
-               seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=5, critic_iters=5,
+               seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=critic_iters_init, critic_iters=critic_iters,
                lipschitz_cost=10.0, z_device_seed=4321 + rank,
                gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
-                         nonlinearity='rectify', precision=args.disc_precision))
+                         nonlinearity='rectify', precision=disc_precision))
     if paper:
         cfg.update(tau_E=2, ssn_type='deg-heteroin', V=0.1)
         cfg['gen'].update(learning_rate=1e-4, update_name='rmsprop', dynamics_cost=0.0, rate_cost=100.0)
@@ -150,6 +144,20 @@ def run_c3(args, rank, world, local_rank, paper=False):
                               prober_cell_types=np.zeros(models))
         truth.append(out.prober_tuning_curve.cpu().numpy())
     gan.set_dataset(np.concatenate(truth))
+    return gan, (N, models, NB, T, skip), bandwidths
+
+
+def run_c3(args, rank, world, local_rank, paper=False):
+    """``paper=True``: the shape of the reference's published run (scripts/fig4/gan/run.json): 2N=202, 128 models,
+    seqlen 240 / skip 200, tau_E=2, deg-heteroin SSN, 4x128 critic with LayerNorm on layers 2-4, rmsprop.
+    Default: BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
+    updates (each with a fresh generator forward) + one generator BPTT update; 1024 weight draws x 8
+    bandwidths per GPU, 2N=200, seqlen 1200 / skip 1000, 3x512 critic on bf16 MFMA, adam-wgan.
+    N>1: num_models = 1024*N sharded 1024 per rank, one RCCL all-reduce per update (weak scaling);
+    value = N x iterations/s, i.e. 1024-model GAN iterations per second over the whole job."""
+    import torch
+    import torch.distributed as dist
+    gan, (N, models, NB, T, skip), bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision)
     it = gan.learning()
 
     def one_iter():

@@ -157,3 +157,94 @@ def test_bias_gradients_that_cancel_are_exactly_zero():
     got = c.grads.cpu().numpy()
     for sl in bias_slices:
         np.testing.assert_array_equal(got[sl], 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's own known answers for this layer (the only reference-held pins of a14 / a11), restated on the
+# device kernels.  networks/tests/test_updater.py:24-59 and networks/tests/test_layer_normalization.py:9-65.
+# ---------------------------------------------------------------------------------------------------------------
+def _update_single_param(updater, before):
+    """test_updater.py:9-21: loss = param.mean() * 0, so the gradient is exactly zero and only the regularisers act."""
+    p = torch.tensor(np.asarray(before, dtype='float32'), device='cuda')
+    g = torch.zeros_like(p)
+    updater(p, g)
+    return p.cpu().numpy()
+
+
+def test_reference_updater_known_answers():
+    from tc_gan_amd.critic import Updater
+    before = np.array([1, 2, 3])
+    # test_l2_decay_no_loss: default update ('adam-wgan'), decoupled decay p -= lr * decay * p
+    after = _update_single_param(Updater(learning_rate=1, reg_l2_decay=0.2), before)
+    np.testing.assert_allclose(after, before * (1 - 0.2), rtol=1e-6)
+    # test_l1_decay_no_loss
+    after = _update_single_param(Updater(learning_rate=1, reg_l1_decay=0.5), np.array([1, -1]))
+    np.testing.assert_allclose(after, [0.5, -0.5], rtol=1e-6)
+    # test_l2_penalty_no_loss: sgd on loss + l2 * sum(p^2)  ->  p (1 - 2 l2)
+    after = _update_single_param(Updater(learning_rate=1, update_name='sgd', reg_l2_penalty=0.2), before)
+    np.testing.assert_allclose(after, before * (1 - 2 * 0.2), rtol=1e-6)
+    # test_l1_penalty_no_loss
+    after = _update_single_param(Updater(learning_rate=1, update_name='sgd', reg_l1_penalty=0.5), np.array([1, -1]))
+    np.testing.assert_allclose(after, [0.5, -0.5], rtol=1e-6)
+
+
+def _np_norm_layer(x, epsilon=0):
+    """test_layer_normalization.py:9-13."""
+    kwds = dict(axis=tuple(range(1, len(x.shape))), keepdims=True)
+    mean = x.mean(**kwds)
+    std = np.sqrt(x.var(**kwds) + epsilon)
+    return (x - mean) / std
+
+
+def _hidden_activations(critic, x):
+    """Hidden layer 1 of a one-layer critic, column by column: D = h_1 . w_out with w_out = e_k.  The critic's input is
+    [x[:, :-3], contrast, |norm_probe|, cell_type]: the last three columns of `x` go in as the condition."""
+    flat = critic.get_flat()
+    nout = critic.dims[1]
+    cols = []
+    for k in range(nout):
+        flat[-nout:] = 0.0
+        flat[-nout + k] = 1.0
+        critic.set_flat(flat)
+        cols.append(critic.forward(x[:, :-3], x[:, -3:]).cpu().numpy())
+    return np.stack(cols, axis=1)
+
+
+@pytest.mark.parametrize('batchsize,in_dim,out_dim', [(2, 3 + 3, 4), (10, 30, 20), (5, 11, 128)])
+def test_reference_layer_normalized_dense_layer_known_answer(batchsize, in_dim, out_dim):
+    """test_layer_normalized_dense_layer (test_layer_normalization.py:41-65): relu(norm(x W) + b) against numpy, with the
+    layer's own epsilon (LayerNormLayer inherits BatchNormLayer's 1e-4; the first reference test compares with
+    np_norm_layer(x, l1.epsilon), the second sets it to 0 -- both forms are checked, the second to the accuracy that
+    eps = 1e-4 allows)."""
+    from tc_gan_amd.critic import Critic
+    rs = np.random.RandomState(0)
+    x = rs.randn(batchsize, in_dim)
+    x[:, -2] = np.abs(x[:, -2])                        # the |norm_probe| column enters through abs()
+    W = rs.randn(in_dim, out_dim)
+    b = rs.randn(out_dim)
+    c = Critic(in_dim - 3, [out_dim], precision='fp32', normalization='layer')
+    c.set_flat(np.concatenate([W.ravel(), b, np.zeros(out_dim)]))
+    actual = _hidden_activations(c, x.astype('float32'))
+    a = np.tensordot(x.astype('float32').astype('float64'), W.astype('float32').astype('float64'), axes=1)
+    desired = np.maximum(_np_norm_layer(a, 1e-4) + b.astype('float32'), 0)
+    assert (desired > 0).any()
+    np.testing.assert_allclose(actual, desired, rtol=2e-5, atol=2e-5)
+    desired0 = np.maximum(_np_norm_layer(a) + b, 0)    # epsilon = 0 form: differs by O(eps / var)
+    np.testing.assert_allclose(actual, desired0, rtol=0, atol=2e-4 * np.abs(desired0).max() / min(1.0, a.var(axis=1).min()))
+
+
+def test_reference_layer_norm_layer_known_answer():
+    """test_layer_norm_layer (test_layer_normalization.py:16-38): the bare LayerNorm output (x - mean)/sqrt(var + eps).
+    With W = identity the dense layer is transparent; +b = 0; relu splits into the positive and (by negating the
+    input) the negative part."""
+    from tc_gan_amd.critic import Critic
+    rs = np.random.RandomState(0)
+    n = 12
+    x = rs.randn(6, n).astype('float32')
+    x[:, -2] = np.abs(x[:, -2])
+    c = Critic(n - 3, [n], precision='fp32', normalization='layer')
+    c.set_flat(np.concatenate([np.eye(n).ravel(), np.zeros(n), np.zeros(n)]))
+    pos = _hidden_activations(c, x)
+    c.set_flat(np.concatenate([-np.eye(n).ravel(), np.zeros(n), np.zeros(n)]))
+    neg = _hidden_activations(c, x)
+    np.testing.assert_allclose(pos - neg, _np_norm_layer(x.astype('float64'), 1e-4), rtol=2e-5, atol=2e-6)

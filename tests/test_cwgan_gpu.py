@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import gan_torch as og
+from oracle import sampler_numpy as osn
 from oracle import ssn_numpy as on
 
 pytestmark = pytest.mark.gpu
@@ -20,6 +21,15 @@ TEST_PARAMS = dict(            # small version of networks/tests/test_wgan.py TE
     disc=dict(learning_rate=0.01, update_name='sgd', layers=[16, 16], normalization='none',
               nonlinearity='rectify', precision='fp32'),
 )
+
+
+def _oracle_minibatch(rng, data, gan, num_models, probes_per_model):
+    """One minibatch as the reference draws it, from oracle/sampler_numpy.py (loop-form restatement of
+    cwgan.py:322-391, checked against the product's sampler stream for stream in tests/test_oracle_sampler.py)."""
+    grid = osn.gridify(data, num_contrasts=len(gan.contrasts), num_bandwidths=len(gan.bandwidths), num_cell_types=2,
+                       num_probes=len(gan.norm_probes))
+    return osn.select_minibatch(rng, grid, [0, 1], gan.norm_probes, gan.contrasts, gan.bandwidths, gan.e_ratio,
+                                num_models, probes_per_model)
 
 
 def _fake_data(gan, truth_size, rs):
@@ -58,7 +68,7 @@ def test_schedule_and_info_fields():
 def test_one_critic_and_generator_update_vs_oracle(norm):
     """Same seeds -> same minibatch, eps, zs (host RandomState order of cwgan.py:471-523); compare the
     critic loss, the post-update critic parameters, the generator loss and the post-update (J, D, S)."""
-    from tc_gan_amd.networks.cwgan import make_gan, RandomChoiceSampler
+    from tc_gan_amd.networks.cwgan import make_gan
     cfg = dict(TEST_PARAMS, critic_iters_init=1, critic_iters=1)
     cfg['disc'] = dict(cfg['disc'], normalization=norm)
     ckw = dict(normalization=norm)
@@ -72,13 +82,12 @@ def test_one_critic_and_generator_update_vs_oracle(norm):
 
     # ---- oracle replay with an identical RandomState --------------------------------------------------
     rng = np.random.RandomState(0)
-    sampler = RandomChoiceSampler.from_grid_data(data, bandwidths=gan.bandwidths, contrasts=gan.contrasts,
-                                                 norm_probes=gan.norm_probes, e_ratio=gan.e_ratio,
-                                                 include_inhibitory_neurons=True, seed=rng)
-    batch = sampler.select_minibatch(4, 2)
-    eps = og.t64(rng.rand(batch.batchsize, 1))
+    # the minibatch comes from the loop-form restatement of cwgan.py:322-391 (oracle/sampler_numpy.py), NOT from
+    # the product's sampler: the replay shares the seed with the run and nothing else
+    batch = _oracle_minibatch(rng, data, gan, 4, 2)
+    eps = og.t64(rng.rand(len(batch['tuning_curves']), 1))
     N = 10
-    kw = batch.gen_kwargs
+    kw = osn.gen_kwargs(batch)
     zs = og.t64(rng.rand(4, 2 * N, 2 * N))
     gen_common = dict(num_sites=N, smoothness=on.DEFAULT_PARAMS['smoothness'], io_type='asym_tanh', k=0.01, n=2.2,
                       tau_E=10., tau_I=1., dt=0.1, seqlen=40, skip_steps=30, rate_penalty_threshold=5.0,
@@ -88,8 +97,8 @@ def test_one_critic_and_generator_update_vs_oracle(norm):
                                kw['prober_model_ids'], kw['prober_norm_probes'], kw['prober_cell_types'], p0,
                                critic_kw=ckw, **gen_common)
     xg = aux['tuning_curve'].detach()
-    xd = og.t64(batch.tuning_curves)
-    cd = og.t64(batch.conditions)
+    xd = og.t64(batch['tuning_curves'])
+    cd = og.t64(batch['conditions'])
     np.testing.assert_allclose(dinfo.xg.cpu().numpy(), xg.numpy(), rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(dinfo.xd.cpu().numpy(), xd.numpy(), rtol=1e-6)
     xp = eps * xd + (1 - eps) * xg
@@ -138,7 +147,7 @@ def test_device_noise_mode_runs_and_rate_bound_skips_critic():
 def test_heteroin_generator_update_vs_oracle(ssn_type, V0):
     """Heterogeneous-input SSNs (networks/ssn.py:645-772): parameter order [V, J, D, S], noise order
     zs then zs_in, and the V gradient through dL/d ext, against the oracle with the same host RNG stream."""
-    from tc_gan_amd.networks.cwgan import make_gan, RandomChoiceSampler
+    from tc_gan_amd.networks.cwgan import make_gan
     cfg = dict(TEST_PARAMS, critic_iters_init=1, critic_iters=1, ssn_type=ssn_type, V0=V0)
     cfg['gen'] = dict(cfg['gen'], V_min=0, V_max=1)
     gan, _ = make_gan(cfg)
@@ -154,16 +163,13 @@ def test_heteroin_generator_update_vs_oracle(ssn_type, V0):
     ginfo = next(it)
     # oracle replay
     rng = np.random.RandomState(0)
-    sampler = RandomChoiceSampler.from_grid_data(data, bandwidths=gan.bandwidths, contrasts=gan.contrasts,
-                                                 norm_probes=gan.norm_probes, e_ratio=gan.e_ratio,
-                                                 include_inhibitory_neurons=True, seed=rng)
-    batch = sampler.select_minibatch(4, 2)
-    rng.rand(batch.batchsize, 1)                       # eps
+    batch = _oracle_minibatch(rng, data, gan, 4, 2)    # oracle/sampler_numpy.py, not the product's sampler
+    rng.rand(len(batch['tuning_curves']), 1)           # eps
     N = 10
     rng.rand(4, 2 * N, 2 * N); rng.choice(2, (4, 2 * N))      # critic step noise: zs, zs_in
     zs = og.t64(rng.rand(4, 2 * N, 2 * N))
     zs_in = rng.choice(2, (4, 2 * N)) * 2 - 1
-    kw = batch.gen_kwargs
+    kw = osn.gen_kwargs(batch)
     Jg, Dg, Sg = (og.t64(JDS[k]).clone().requires_grad_(True) for k in 'JDS')
     Vg = og.t64(V0).clone().requires_grad_(True)
     gloss, _ = og.generator_loss(Jg, Dg, Sg, zs, kw['stimulator_bandwidths'], kw['stimulator_contrasts'],
