@@ -123,7 +123,7 @@ def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iter
     cfg = dict(num_sites=N, num_models=models * world, probes_per_model=1, norm_probes=[0.0],
                include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
                seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=critic_iters_init, critic_iters=critic_iters,
-               lipschitz_cost=10.0, z_device_seed=4321 + rank,
+               lipschitz_cost=10.0, z_device_seed=4321,      # one Philox stream, sharded over the ranks by make_gan
                gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',

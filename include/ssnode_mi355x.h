@@ -334,6 +334,15 @@ int ssn_stimulus_amp_f64(const double *bandwidths, const double *contrasts, doub
 int ssn_io_eval_f32(const float *v, float *out, long count, const ssn_solver_params *p, void *stream);
 int ssn_io_eval_f64(const double *v, double *out, long count, const ssn_solver_params *p, void *stream);
 
+/* Device-side noise for the generator's z (replaces the host `rng.rand(batch, 2N, 2N)` of
+ * tc_gan/networks/ssn.py:434-439 in the opt-in performance mode; the reference has no such mode, parity runs keep
+ * host noise).  out[i] = u(seed, offset + i) in [0, 1) with 24 random bits, from Philox4x32-10 (Salmon, Moraes,
+ * Dror, Shaw, SC'11; known-answer vectors checked in tests/test_noise.py): element g of the stream is word g % 4 of
+ * the block with counter (g / 4, 0, 0, 0) and key (seed lo, seed hi).  Any slice can be generated by itself, so the
+ * ranks of a data-parallel job each fill their own rows of ONE global stream.  `out` is a device pointer. */
+int ssn_philox_uniform_f32(unsigned long long seed, unsigned long long offset, float *out, unsigned long long n, void *stream);
+int ssn_philox_uniform_f64(unsigned long long seed, unsigned long long offset, double *out, unsigned long long n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

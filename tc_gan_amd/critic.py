@@ -24,7 +24,7 @@ def _stream():
 class Critic(object):
     """MLP critic: input = [tuning curve (nx), contrast, |norm_probe|, cell_type]."""
 
-    def __init__(self, nx, layers, seed=0, hide_cell_type=False, precision='bf16',
+    def __init__(self, nx, layers, seed=0, hide_cell_type=False, precision='fp32',
                  normalization='none', nonlinearity='rectify', device=None):
         norms = list(normalization) if isinstance(normalization, (list, tuple)) else [normalization] * len(layers)
         if len(norms) != len(layers) or any(n not in ('none', 'layer') for n in norms):

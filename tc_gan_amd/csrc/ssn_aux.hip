@@ -200,4 +200,49 @@ hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------
+// Counter-based uniform noise (Philox4x32-10, Salmon et al. 2011): out[i] = u(seed, offset + i) in [0, 1).
+// Element g of the stream is word g % 4 of the Philox block with counter (g / 4, 0, 0, 0) and key (seed lo, seed hi),
+// so any slice of the stream can be produced by itself: rank r of a data-parallel run fills only ITS rows of the
+// global z tensor and the job as a whole draws exactly the numbers a single process draws.  HBM-bound (4 or 8 B
+// written per element).
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) philox_uniform_kernel(unsigned long long seed, unsigned long long offset, T* __restrict__ out,
+                                                             unsigned long long n) {
+    const unsigned long long first_blk = offset >> 2, last_blk = (offset + n + 3) >> 2;      // Philox blocks touched
+    for (unsigned long long blk = first_blk + blockIdx.x * 256ull + threadIdx.x; blk < last_blk; blk += gridDim.x * 256ull) {
+        unsigned w[4];
+        philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long g = 4 * blk + j;
+            if (g >= offset && g < offset + n) out[g - offset] = (T)((float)(w[j] >> 8) * (1.0f / 16777216.0f));
+        }
+    }
+}
+template <typename T>
+hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long offset, T* out, unsigned long long n, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    unsigned long long blocks = ((n + 3) / 4 + 1 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((philox_uniform_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, seed, offset, out, n);
+    return hipGetLastError();
+}
+template hipError_t launch_philox_uniform<float>(unsigned long long, unsigned long long, float*, unsigned long long, hipStream_t);
+template hipError_t launch_philox_uniform<double>(unsigned long long, unsigned long long, double*, unsigned long long, hipStream_t);
+
 }  // namespace ssn

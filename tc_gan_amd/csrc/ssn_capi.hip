@@ -775,6 +775,16 @@ int ssn_stimulus_amp_f64(const double* bw, const double* con, double smoothness,
     SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_philox_uniform_f32(unsigned long long seed, unsigned long long offset, float* out, unsigned long long n, void* stream) {
+    if (n > 0 && !out) { g_last_error = "ssn_philox_uniform: null output"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_philox_uniform<float>(seed, offset, out, n, (hipStream_t)stream));
+    return 0;
+}
+int ssn_philox_uniform_f64(unsigned long long seed, unsigned long long offset, double* out, unsigned long long n, void* stream) {
+    if (n > 0 && !out) { g_last_error = "ssn_philox_uniform: null output"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_philox_uniform<double>(seed, offset, out, n, (hipStream_t)stream));
+    return 0;
+}
 int ssn_io_eval_f32(const float* v, float* out, long count, const ssn_solver_params* p, void* stream) {
     SSN_TRY(ssn::launch_io_eval<float>(v, out, count, ssn::make_io_consts<float>(*p), (hipStream_t)stream));
     return 0;

@@ -133,6 +133,7 @@ hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st);
 template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st);
+template <typename T> hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long offset, T* out, unsigned long long n, hipStream_t st);
 template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st);
 
 }  // namespace ssn

@@ -2,7 +2,6 @@
 BPTT (c)WGAN path.  No arithmetic: they consume the `info` namespaces of ``gan.learning()``."""
 from logging import getLogger
 import collections
-import contextlib
 
 import numpy as np
 
@@ -22,46 +21,63 @@ def net_isfinite(discriminator):
     return all(np.isfinite(arr).all() for arr in discriminator.get_param_values())
 
 
-@contextlib.contextmanager
-def recording_exit_reason(datastore):
-    """drivers.py:31-58."""
-    try:
-        yield
-    except KeyboardInterrupt:
-        datastore.save_exit_reason(reason='keyboard_interrupt', good=False)
-        raise
-    except execution.KnownError:
-        raise
-    except Exception as err:
-        datastore.save_exit_reason(reason='uncaught_exception', good=False, exception=str(err))
-        raise
-    else:
-        datastore.save_exit_reason(reason='end_of_iteration', good=True)
+class recording_exit_reason(object):
+    """``with recording_exit_reason(datastore): <loop>`` -- what ended the loop goes to exit.json
+    (drivers.py:31-58): a clean end is 'end_of_iteration' (good), Ctrl-C 'keyboard_interrupt', any other exception
+    'uncaught_exception' with its text.  A KnownError passes through untouched: whoever raised it has already written
+    its own exit.json.  Exceptions are never swallowed."""
+
+    def __init__(self, datastore):
+        self.datastore = datastore
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.datastore.save_exit_reason(reason='end_of_iteration', good=True)
+        elif issubclass(exc_type, execution.KnownError):
+            pass
+        elif issubclass(exc_type, KeyboardInterrupt):
+            self.datastore.save_exit_reason(reason='keyboard_interrupt', good=False)
+        elif issubclass(exc_type, Exception):
+            self.datastore.save_exit_reason(reason='uncaught_exception', good=False, exception=str(exc))
+        return False
+
+
+def _abort(datastore, reason, message, exit_code, **details):
+    """An expected abort: exit.json names the reason (good=False), the process ends with `exit_code`."""
+    datastore.dump_json(dict(reason=reason, good=False, **details), 'exit.json')
+    raise execution.KnownError(message, exit_code=exit_code)
 
 
 def maybe_quit(datastore, JDS_fake, JDS_true, quit_JDS_threshold):
-    """drivers.py:183-198."""
-    JDS_fake = np.concatenate(JDS_fake).flatten()
-    JDS_true = np.concatenate(JDS_true).flatten()
-    JDS_distance = np.linalg.norm(JDS_fake - JDS_true)
-    if quit_JDS_threshold > 0 and JDS_distance >= quit_JDS_threshold:
-        datastore.dump_json(dict(reason='JDS_distance', JDS_distance=JDS_distance, good=False), 'exit.json')
-        raise execution.KnownError(
-            'Exit simulation since (J, D, S)-distance (= {}) to the true parameter exceed threshold (= {}).'
-            .format(JDS_distance, quit_JDS_threshold), exit_code=4)
+    """Give up when the generator has wandered too far from the true parameters (drivers.py:183-198): Euclidean
+    distance over all twelve entries of (J, D, S); a threshold <= 0 switches the check off."""
+    if not quit_JDS_threshold > 0:
+        return
+    gap = np.concatenate(JDS_fake).ravel() - np.concatenate(JDS_true).ravel()
+    JDS_distance = np.linalg.norm(gap)
+    if JDS_distance >= quit_JDS_threshold:
+        _abort(datastore, 'JDS_distance',
+               'Exit simulation since (J, D, S)-distance (= {}) to the true parameter exceed threshold (= {}).'
+               .format(JDS_distance, quit_JDS_threshold), 4, JDS_distance=JDS_distance)
 
 
 def check_disc_param(datastore, discriminator, nnorms):
-    """drivers.py:201-211: NaN critic -> exit.json + exit code 3."""
-    isfinite_nnorms = np.isfinite(nnorms)
-    if not isfinite_nnorms.all() and not net_isfinite(discriminator):
-        datastore.dump_json(dict(reason='disc_param_has_nan', isfinite_nnorms=isfinite_nnorms.tolist(), good=False),
-                            'exit.json')
-        raise execution.KnownError("Discriminator parameter is not finite.", exit_code=3)
+    """A critic that has gone NaN/inf ends the run with exit code 3 (drivers.py:201-211).  The cheap test is on the
+    recorded norms; only when one of them is not finite are the parameters themselves read back and checked."""
+    finite = np.isfinite(nnorms)
+    if finite.all() or net_isfinite(discriminator):
+        return
+    _abort(datastore, 'disc_param_has_nan', "Discriminator parameter is not finite.", 3,
+           isfinite_nnorms=finite.tolist())
 
 
 class SSNRejectionLimiter(object):
-    """drivers.py:214-255."""
+    """Abort when the fixed-point finder keeps rejecting most of its draws (drivers.py:214-255): the share
+    rejections / (rejections + n_samples) must stay at or below `rejection_limit`; more than
+    `max_consecutive_exceedings` violations IN A ROW end the run (one good step resets the count)."""
 
     def __init__(self, datastore, n_samples, rejection_limit=0.6, max_consecutive_exceedings=5):
         self.datastore = datastore
@@ -71,16 +87,13 @@ class SSNRejectionLimiter(object):
         self._exceedings = 0
 
     def should_abort(self, rejections):
-        if rejections / (rejections + self.n_samples) > self.rejection_limit:
-            self._exceedings += 1
-        else:
-            self._exceedings = 0
+        share = rejections / (rejections + self.n_samples)
+        self._exceedings = self._exceedings + 1 if share > self.rejection_limit else 0
         return self._exceedings > self.max_consecutive_exceedings
 
     def __call__(self, rejections):
         if self.should_abort(rejections):
-            self.datastore.dump_json(dict(reason='too_many_rejections', good=False), 'exit.json')
-            raise execution.KnownError("Too many rejections in fixed-point finder.", exit_code=4)
+            _abort(self.datastore, 'too_many_rejections', "Too many rejections in fixed-point finder.", 4)
 
     @classmethod
     def from_driver(cls, driver):
@@ -88,7 +101,10 @@ class SSNRejectionLimiter(object):
 
 
 class WGANDiscLossLimiter(object):
-    """drivers.py:265-295."""
+    """Abort when the critic loss has blown up (drivers.py:265-295): over a sliding window of the last `hist_length`
+    critic losses -- judged only once the window is full -- more than `prob_limit` of them exceed `wild_disc_loss`.
+    As in the reference the comparison is one-sided (its abs() wraps the comparison's result, not the loss): hugely
+    NEGATIVE losses do not count."""
 
     def __init__(self, datastore, prob_limit=0.6, wild_disc_loss=10000, hist_length=50):
         self.datastore = datastore
@@ -98,7 +114,8 @@ class WGANDiscLossLimiter(object):
         self.dloss_hist = collections.deque(maxlen=hist_length)
 
     def prob_exceed(self):
-        return np.mean(abs(np.asarray(self.dloss_hist) > self.wild_disc_loss))
+        window = np.asarray(self.dloss_hist)
+        return np.count_nonzero(window > self.wild_disc_loss) / len(window)
 
     def should_abort(self, dloss):
         self.dloss_hist.append(dloss)
@@ -106,8 +123,7 @@ class WGANDiscLossLimiter(object):
 
     def __call__(self, dloss):
         if self.should_abort(dloss):
-            self.datastore.dump_json(dict(reason='wild_disc_loss', good=False), 'exit.json')
-            raise execution.KnownError("Too many wild discriminator losses.", exit_code=4)
+            _abort(self.datastore, 'wild_disc_loss', "Too many wild discriminator losses.", 4)
 
     @classmethod
     def from_driver(cls, driver):

@@ -307,6 +307,15 @@ def pre_learn(packages, datastore, datastore_template, load_config, extra_info={
     if distributed_rank() > 0:
         datastore = os.path.join(datastore, 'rank%d' % distributed_rank())
     makedirs_exist_ok(datastore)
+    if run_config.get('resume_from'):
+        # A resumed run starts its tables afresh (they are opened for writing, not appended to, and info.json is
+        # rewritten): continuing INSIDE the directory that holds the earlier run would wipe its rows.  Refuse.
+        old = sorted(f for f in os.listdir(datastore)
+                     if f.endswith(('.csv', '.hdf5')) or f in ('info.json', 'exit.json'))
+        if old:
+            raise KnownError('--resume-from needs a NEW --datastore directory: {} already holds {} (a resumed run '
+                             'rewrites its tables; the rows before the checkpoint stay in the earlier directory)'
+                             .format(datastore, ', '.join(old[:4]) + (', ...' if len(old) > 4 else '')), exit_code=5)
     with open(os.path.join(datastore, 'info.json'), 'w') as fp:
         json.dump(_jsonable(dict(run_config=run_config, extra_info=extra_info,
                                  meta_info=get_meta_info(packages=packages))), fp)

@@ -266,6 +266,12 @@ class ConditionalBPTTWassersteinGAN(object):
         single-GPU run.  Empty in device-noise mode (the generator draws from its Philox stream)."""
         if self.gen._zgen is not None:
             return {}
+        if self.reducer.on and not getattr(self, '_warned_host_noise', False):
+            # parity mode under data parallelism: EVERY rank draws the global (num_models, 2N, 2N) fp64 tensor on the host
+            # and keeps 1/world of it, so the host cost per step grows with the job.  Meant for equivalence tests.
+            self._warned_host_noise = True
+            logger.warning('host-side noise with %d ranks: every rank draws all %d models\' z on the host each step; '
+                           'use --z-device-seed for multi-GPU runs', self.reducer.world, batch.num_models)
         noise = self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((batch.num_models, 1)))
         if self.reducer.on:
             per = batch.num_models // self.reducer.world
@@ -472,7 +478,7 @@ class ConditionalBPTTWassersteinGAN(object):
                  gen_updaters={name: self.gen_updaters[name].state_dict() for name in self._pnames},
                  rng=dict(kind=kind, keys=keys, pos=pos, has_gauss=has_gauss, cached=cached))
         if self.gen._zgen is not None:
-            d['zgen'] = self.gen._zgen.get_state().cpu().numpy()
+            d['zgen'] = self.gen._zgen.get_state()
         return d
 
     def load_state_dict(self, d):
@@ -486,7 +492,7 @@ class ConditionalBPTTWassersteinGAN(object):
         self.rng.set_state((str(r['kind']), np.asarray(r['keys'], dtype='uint32'), int(r['pos']), int(r['has_gauss']),
                             float(r['cached'])))
         if self.gen._zgen is not None and 'zgen' in d:
-            self.gen._zgen.set_state(torch.as_tensor(np.asarray(d['zgen'], dtype='uint8')))
+            self.gen._zgen.set_state(d['zgen'])
 
     def save_checkpoint(self, path, gen_step):
         import pickle
@@ -543,7 +549,7 @@ def make_gan(config):
         include_time_avg=take('include_time_avg', False),
         unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'),
-        z_device_seed=take('z_device_seed', None),
+        z_device_seed=take('z_device_seed', None), shard=(reducer.rank, reducer.world),
         ssn_type=ssn_type, V=V, dist_in=dist_in)
     rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
     disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
@@ -552,7 +558,7 @@ def make_gan(config):
                   normalization=disc_cfg.pop('normalization', 'none'),
                   nonlinearity=disc_cfg.pop('nonlinearity', 'rectify'),
                   hide_cell_type=take('hide_cell_type'),
-                  precision=disc_cfg.pop('precision', 'bf16'),
+                  precision=disc_cfg.pop('precision', 'fp32'),
                   seed=disc_cfg.pop('init_seed', seed))
     disc_cfg.pop('net_options', None)
 

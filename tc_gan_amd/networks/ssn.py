@@ -13,6 +13,7 @@ Input and output names follow the reference (``stimulator_bandwidths``, ``model_
 [``model_time_avg``,] ``prober_tuning_curve``).
 """
 import collections
+import ctypes
 
 import numpy as np
 import torch
@@ -61,6 +62,35 @@ def make_flat_param_names(named_params):
     return tuple(names)
 
 
+class DeviceNoise(object):
+    """Uniform [0, 1) noise drawn on the device from ONE counter-based stream (Philox4x32-10, `ssn_philox_uniform_*`).
+
+    A draw of local shape (n, ...) stands for rows [rank * n, (rank + 1) * n) of the GLOBAL draw of shape
+    (world * n, ...): every rank generates only its own rows, and all ranks advance the stream position by the
+    global element count.  A data-parallel job therefore uses exactly the numbers a single process with the same seed
+    uses, ranks never repeat each other's draws, and the state (seed, position) is the same on every rank -- one
+    checkpoint restores all of them."""
+
+    def __init__(self, seed, rank=0, world=1):
+        self.seed, self.rank, self.world = int(seed), int(rank), int(world)
+        self.position = 0                      # elements of the global stream consumed so far
+
+    def uniform(self, local_shape, tdtype):
+        out = torch.empty(tuple(local_shape), device='cuda', dtype=tdtype)
+        n = out.numel()
+        fn = clib.libssnode.ssn_philox_uniform_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_uniform_f64
+        clib.check(fn(self.seed, self.position + self.rank * n, out.data_ptr(), n,
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_philox_uniform')
+        self.position += self.world * n
+        return out
+
+    def get_state(self):
+        return dict(seed=self.seed, position=self.position)
+
+    def set_state(self, state):
+        self.seed, self.position = int(state['seed']), int(state['position'])
+
+
 class TuningCurveGenerator(object):
     """Generator with a conditional prober (cwgan.py:72-120) or a fixed prober (ssn.py:779-851).
 
@@ -71,7 +101,7 @@ class TuningCurveGenerator(object):
 
     def __init__(self, num_sites, num_tcdom, smoothness, J, D, S, k, n, tau_E, tau_I, dt, io_type,
                  seqlen, skip_steps, batchsize, probes=None, include_rate_penalty=True,
-                 include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None,
+                 include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None, shard=(0, 1),
                  ssn_type='default', V=0, dist_in='bernoulli'):
         clib.require_gpu()
         if ssn_type not in ssn_type_choices:
@@ -113,11 +143,11 @@ class TuningCurveGenerator(object):
             names.append('model_time_avg')
         names.append('prober_tuning_curve')
         self.OutType = collections.namedtuple('OutType', names)
-        # device-side noise (perf mode): a per-generator Philox stream instead of host MT19937
+        # device-side noise (perf mode): one counter-based Philox stream per generator instead of host MT19937;
+        # `shard` = (rank, world) of a data-parallel job: every rank fills ITS rows of the one global stream
         self._zgen = None
         if z_device_seed is not None:
-            self._zgen = torch.Generator(device='cuda')
-            self._zgen.manual_seed(int(z_device_seed))
+            self._zgen = DeviceNoise(int(z_device_seed), *shard)
 
     num_neurons = property(lambda self: 2 * self.num_sites)
     conditional = property(lambda self: self.probes is None)
@@ -165,10 +195,9 @@ class TuningCurveGenerator(object):
         num_models = np.shape(stimulator_bandwidths)[0]
         M = self.num_neurons
         if self._zgen is not None:
-            noise = dict(model_zs=torch.rand((num_models, M, M), device='cuda', dtype=self.tdtype,
-                                             generator=self._zgen))
+            noise = dict(model_zs=self._zgen.uniform((num_models, M, M), self.tdtype))
             if self.heteroin:
-                u = torch.rand((num_models, M), device='cuda', dtype=self.tdtype, generator=self._zgen)
+                u = self._zgen.uniform((num_models, M), self.tdtype)
                 noise['model_zs_in'] = (u < 0.5).to(self.tdtype) * 2 - 1 if self.dist_in == 'bernoulli' else u * 2 - 1
             return noise
         noise = dict(model_zs=rng.rand(num_models, M, M))

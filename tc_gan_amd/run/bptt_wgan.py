@@ -55,15 +55,18 @@ def add_bptt_common_options(parser):
     parser.add_argument('--disc-layers', '--layers', default=[], type=eval)
     parser.add_argument('--disc-normalization', default='none', choices=('none', 'layer'))
     parser.add_argument('--disc-nonlinearity', default='rectify')
-    parser.add_argument('--disc-precision', default='bf16', choices=('bf16', 'fp32'),
-                        help='MFMA operand precision of the critic GEMMs (new)')
+    parser.add_argument('--disc-precision', default='fp32', choices=('bf16', 'fp32'),
+                        help='MFMA operand precision of the critic GEMMs (new).  fp32 (default) keeps the reference\'s '
+                             'floatX arithmetic; bf16 is the explicit fast mode (fp32 accumulation, ~1e-2 relative on '
+                             'the critic loss and gradients)')
     parser.add_argument('--lipschitz-cost', '--WGAN_lambda', default=10.0, type=float)
     parser.add_argument('--critic-iters-init', '--WGAN_n_critic0', default=50, type=int)
     parser.add_argument('--critic-iters', '--WGAN_n_critic', default=5, type=int)
     parser.add_argument('--ssn-type', default='default', choices=('default', 'heteroin', 'deg-heteroin'),
                         help='SSN variant (the reference sets it through --load-config)')
     parser.add_argument('--z-device-seed', default=None, type=int,
-                        help='Draw z on the device (Philox) instead of the host RandomState (new; fast mode)')
+                        help='Draw z on the device (Philox4x32-10, one stream sharded over the ranks) instead of the '
+                             'host RandomState (new; fast mode, and the mode to use for multi-GPU runs)')
 
 
 def add_learning_options(parser):

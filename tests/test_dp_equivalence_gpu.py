@@ -27,9 +27,9 @@ def _config():
                   nonlinearity='rectify', precision='fp32'))
 
 
-def _train(n_gen_steps=2):
+def _train(n_gen_steps=2, z_device_seed=None):
     from tc_gan_amd.networks.cwgan import make_gan
-    gan, _ = make_gan(_config())
+    gan, _ = make_gan(dict(_config(), z_device_seed=z_device_seed))
     data = np.random.RandomState(4).rand(9, 4 * 2 * 2 * 2) * 10
     gan.set_dataset(data)
     it = gan.learning()
@@ -90,7 +90,8 @@ def _worker(rank, world, port, out, what='gan'):
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    res = {'gan': _train, 'moments': _train_moments, 'find': _find_fixed_points}[what]()
+    res = {'gan': _train, 'gan_devnoise': lambda: _train(z_device_seed=31), 'moments': _train_moments,
+           'find': _find_fixed_points}[what]()
     out.put((rank,) + res)
     dist.barrier()
     dist.destroy_process_group()
@@ -115,6 +116,28 @@ def test_two_ranks_follow_the_single_process_run():
         np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
     np.testing.assert_array_equal(res[0][2], res[1][2])          # replicas stay bit-identical
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_two_ranks_with_device_noise_follow_the_single_process_run():
+    """`z_device_seed` (performance mode): the ranks fill disjoint rows of ONE Philox stream, so the 2-rank job trains on
+    the same weight draws as the single process -- not on two copies of half of them."""
+    sys.path.insert(0, ROOT)
+    jds1, critic1, losses1 = _train(z_device_seed=31)
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 26700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, 'gan_devnoise')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(res[r][3], losses1, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
 def test_two_ranks_moment_matching_follows_the_single_process_run():

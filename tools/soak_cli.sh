@@ -6,7 +6,7 @@ import subprocess, sys, time, os, resource
 t0 = time.time()
 p = subprocess.run([sys.executable, 'run.py', 'tc_gan.run.bptt_cwgan', '--', '--datastore', 'gpurun_out/soak', '--iterations', '3000',
                     '--num-models', '32', '--n_bandwidths', '8', '--seqlen', '120', '--skip-steps', '100', '--disc-layers', '[64,64]',
-                    '--dataset-provider', 'fixedtime', '--truth_size', '256', '--z-device-seed', '7', '--critic-iters-init', '5', '--quiet',
+                    '--dataset-provider', 'fixedtime', '--truth_size', '256', '--z-device-seed', '7', '--disc-precision', 'bf16', '--critic-iters-init', '5', '--quiet',
                     '--disc-param-save-interval', '500'], capture_output=True, text=True)
 print('rc', p.returncode, 'wall %.1f s' % (time.time() - t0))
 print(p.stderr[-600:])
