@@ -207,6 +207,15 @@ int ssn_gen_backward_ext_f32(const float *W, const float *traj, float *df_delta,
 int ssn_gen_backward_ext_f64(const double *W, const double *traj, double *df_delta, const double *g_time_avg, double *g_ext,
                              double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params *p, void *stream);
 /*
+ * dL/dW of the BPTT update (the `theano.grad` of networks/wgan.py:236-242 through the scan of ssn.py:354-385):
+ * gW[b][i][j] = sum_k delta[b][k][i] * traj[b][k][j],  delta / traj = the [B][K = NB*T][M] views of what
+ * ssn_gen_backward_* and ssn_gen_forward_* leave, gW device [B][M][M].  kernel: 0 automatic; 1 plain FMAs in k order
+ * (any size, fp64); 2 (fp32, M <= 224) bf16 matrix cores on an exact three-way split of every fp32 operand, six
+ * partial products per product, fp32 accumulation -- fp32 input precision at 6/16 of the fp32 MFMA cost.
+ */
+int ssn_weight_grad_f32(const float *delta, const float *traj, float *gW, int B, long K, int M, int kernel, void *stream);
+int ssn_weight_grad_f64(const double *delta, const double *traj, double *gW, int B, long K, int M, int kernel, void *stream);
+/*
  * Chain rule W -> (J, D, S) of make_W_with_x (make_w_batch.py:19-34): out[b][pq][0..2] =
  * partial dL/dJ_pq, dL/dD_pq, dL/dS_pq of draw b (device fp64 [B][4][3]; sum over b on the caller's
  * side in a fixed order).  J, D, S are HOST arrays of 4.

@@ -685,6 +685,22 @@ int ssn_gen_backward_ext_f64(const double* W, const double* traj, double* df_del
                              void* stream) {
     return gen_backward_impl<double>(W, traj, df_delta, g_time_avg, g_ext, c_dyn, c_rate, B, NB, M, p, stream);
 }
+int ssn_weight_grad_f32(const float* delta, const float* traj, float* gW, int B, long K, int M, int kernel, void* stream) {
+    if (B < 0 || K < 0 || M < 0 || (B > 0 && M > 0 && (!gW || (K > 0 && (!delta || !traj))))) {
+        g_last_error = "ssn_weight_grad: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_weight_grad<float>(delta, traj, gW, B, K, M, kernel, (hipStream_t)stream));
+    return 0;
+}
+int ssn_weight_grad_f64(const double* delta, const double* traj, double* gW, int B, long K, int M, int kernel, void* stream) {
+    if (B < 0 || K < 0 || M < 0 || (B > 0 && M > 0 && (!gW || (K > 0 && (!delta || !traj))))) {
+        g_last_error = "ssn_weight_grad: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_weight_grad<double>(delta, traj, gW, B, K, M, kernel, (hipStream_t)stream));
+    return 0;
+}
 int ssn_jds_grad_f32(const float* gW, const float* z, const float* J, const float* D, const float* S, double* out,
                      int B, int N, void* stream) {
     float jds[12];

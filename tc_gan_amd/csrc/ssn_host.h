@@ -79,6 +79,9 @@ template <typename T> hipError_t launch_gen_forward(const GenFwdArgs<T>& a, hipS
 template <typename T> hipError_t launch_gen_backward(const GenBwdArgs<T>& a, hipStream_t st);
 template <typename T> hipError_t launch_jds_grad(const T* gW, const T* z, const T* jds12, double* out, int B, int N, hipStream_t st);
 
+// ssn_gw.hip: gW[b] = delta[b]^T traj[b] over K rows ([K][M] row-major each); kernel 0 auto, 1 plain FMA, 2 split-bf16 MFMA
+template <typename T> hipError_t launch_weight_grad(const T* delta, const T* traj, T* gW, int B, long K, int M, int kernel, hipStream_t st);
+
 // ssn_critic.hip
 struct OptArgs {
     float* p; const float* g; float* s1; float* s2; long n;

@@ -1,8 +1,8 @@
 """Thin Python wrappers over the fixed-time generator kernels (include/ssnode_mi355x.h section 3).
 
 Everything here takes and returns torch CUDA tensors; the arithmetic is in
-``csrc/ssn_gen.hip`` (forward + BPTT adjoint) and one plain batched GEMM
-(``torch.bmm`` -> rocBLAS) for dL/dW = delta^T . traj.
+``csrc/ssn_gen.hip`` / ``ssn_mfma.hip`` (forward + BPTT adjoint) and ``csrc/ssn_gw.hip``
+(dL/dW = delta^T . traj, a hand-written batched GEMM on the bf16 matrix cores with exactly split fp32 operands).
 """
 import ctypes
 
@@ -80,10 +80,19 @@ def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp, want_g_ext=False):
     return (df, g_ext) if want_g_ext else df
 
 
-def weight_grad(delta, traj):
-    """dL/dW[b] = delta[b]^T . traj[b] over K = NB*T (one plain batched GEMM, rocBLAS)."""
+def weight_grad(delta, traj, kernel=0):
+    """dL/dW[b] = delta[b]^T . traj[b] over K = NB*T (``ssn_weight_grad_*``; kernel: 0 automatic, 1 plain FMAs,
+    2 split-bf16 MFMA)."""
+    clib.require_gpu()
     B, NB, T, M = traj.shape
-    return torch.bmm(delta.reshape(B, NB * T, M).transpose(1, 2), traj.reshape(B, NB * T, M))
+    suffix, _ = _DT[traj.dtype]
+    delta = delta.contiguous(); traj = traj.contiguous()
+    assert delta.shape == traj.shape and delta.dtype == traj.dtype
+    gW = torch.empty((B, M, M), device=traj.device, dtype=traj.dtype)
+    rc = getattr(libssnode, 'ssn_weight_grad_' + suffix)(delta.data_ptr(), traj.data_ptr(), gW.data_ptr(), B, NB * T, M,
+                                                         int(kernel), _stream())
+    clib.check(rc, 'ssn_weight_grad_' + suffix)
+    return gW
 
 
 def jds_grad(gW, z, J, D, S, as_tensor=False):

@@ -153,3 +153,34 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
         np.testing.assert_allclose(res[kernel][2], res[1][2], rtol=1e-4)
         scale = np.abs(res[1][3]).max()
         np.testing.assert_allclose(res[kernel][3], res[1][3], rtol=1e-3, atol=1e-4 * scale)
+
+
+@pytest.mark.parametrize('B,NB,T,M,dtype,kernel', [
+    (3, 2, 5, 20, 'float64', 0), (2, 4, 7, 20, 'float32', 1), (2, 8, 30, 100, 'float32', 2), (3, 8, 50, 200, 'float32', 0),
+    (2, 8, 37, 202, 'float32', 2), (2, 3, 11, 224, 'float32', 2), (1, 8, 20, 258, 'float32', 0), (2, 8, 1, 200, 'float32', 2),
+    (2, 8, 1200, 200, 'float32', 0)])
+def test_weight_grad_kernels_vs_fp64_matmul(B, NB, T, M, dtype, kernel):
+    """dL/dW[b] = delta[b]^T traj[b] (csrc/ssn_gw.hip) against numpy fp64.  The split-bf16 MFMA kernel must deliver fp32
+    input precision: every fp32 operand is the exact sum of its three bf16 terms and only partial products below 2^-24
+    are dropped, so its error is that of an fp32 dot product (~1e-7 * sqrt(K) * |d||x|), not bf16's 4e-3."""
+    from tc_gan_amd import genops
+    rs = np.random.RandomState(B * 1000 + T)
+    # wide dynamic range, mixed signs: rates up to ~1e2, deltas down to ~1e-6
+    d = (rs.randn(B, NB, T, M) * np.exp(rs.uniform(-12, 0, (B, NB, T, M)))).astype(dtype)
+    x = (rs.rand(B, NB, T, M) * 100 * np.exp(rs.uniform(-6, 0, (B, NB, T, M)))).astype(dtype)
+    want = np.einsum('bki,bkj->bij', d.reshape(B, NB * T, M).astype('float64'), x.reshape(B, NB * T, M).astype('float64'))
+    got = genops.weight_grad(torch.as_tensor(d).cuda(), torch.as_tensor(x).cuda(), kernel=kernel).cpu().numpy()
+    assert got.shape == (B, M, M)
+    # scale of one output element: sum_k |d||x| -- the bound every floating-point dot product is measured against
+    scale = np.einsum('bki,bkj->bij', np.abs(d.reshape(B, NB * T, M)).astype('float64'),
+                      np.abs(x.reshape(B, NB * T, M)).astype('float64'))
+    err = np.abs(got - want) / (scale + 1e-300)
+    tol = 1e-14 if dtype == "float64" else 2e-6            # fp32 dot product: ~2^-24 per product and per accumulation step, relative to sum |d||x|
+    assert err.max() < tol, (err.max(), kernel)
+    if dtype == 'float32' and M <= 224:
+        e = {}
+        for k in (1, 2):
+            r = genops.weight_grad(torch.as_tensor(d).cuda(), torch.as_tensor(x).cuda(), kernel=k).cpu().numpy()
+            e[k] = (np.abs(r - want) / (scale + 1e-300)).max()
+        # the split-bf16 MFMA kernel is at least as accurate as an fp32 FMA chain over the same K
+        assert e[2] < tol and e[2] <= 1.5 * e[1] + 1e-7, e
