@@ -45,7 +45,7 @@ template <> struct GwBlocks<4> {
 
 // One slab = 16 k.  Staging task of thread t: matrix t >> 8 (wave-uniform), k half (t >> 7) & 1, rows 2 p and 2 p + 1
 // with p = t & 127: eight 8-byte loads (coalesced: a wave reads 512 contiguous bytes per k), split, six 16-byte LDS
-// stores.  LDS: sm[buffer][matrix][part][256 rows][48 bytes: k half 0, k half 1, pad] (rows >= 2N hold zeros).
+// stores.  LDS: [buffer][matrix][part] images of 256 rows (rows >= 2N hold zeros), layout below.
 struct GwStage {
     __amdgpu_buffer_rsrc_t rs;
     int voff;            // byte offset of (k = 8 half, row 2 p), or -1 (row pair beyond the matrix: loads return 0)
@@ -106,21 +106,20 @@ __device__ __forceinline__ void gw_split_row(const float* v, gu4& ph, gu4& pm, g
     }
 }
 
-#ifndef GW_NOSCHED
-#define GW_PIPELINE(n) _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) { \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */  \
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* three VALU */ }
-#else
-#define GW_PIPELINE(n)
-#endif
-constexpr unsigned GW_ROWB = 48, GW_PARTB = 256 * GW_ROWB, GW_MATB = 3 * GW_PARTB, GW_BUFB = 2 * GW_MATB;
+// LDS image of one (matrix, part): row r, k half h at gw_row(r) + 16 h.  Even rows fill 128 slots of 48 bytes, odd rows
+// a second plane 128 bytes further on: a staging thread writes rows 2 p and 2 p + 1 at a lane stride of 48 bytes in both
+// planes (conflict-free 16-byte stores), and the 16 consecutive rows of one ds_read_b128 lane group fall on 64 distinct
+// banks (the odd plane's skew of 32 banks = what 8 more even slots would add).
+constexpr unsigned GW_ROWB = 48, GW_ODD = 128 * GW_ROWB + 128, GW_PARTB = 2 * 128 * GW_ROWB + 256, GW_MATB = 3 * GW_PARTB,
+                   GW_BUFB = 2 * GW_MATB;
+__device__ __forceinline__ unsigned gw_row(unsigned r) { return (r >> 1) * GW_ROWB + (r & 1) * GW_ODD; }
 
 __device__ __forceinline__ void gw_stage(const GwStage& g, char* buf, const float (&raw)[16]) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         gu4 ph, pm, pl;
         gw_split_row(&raw[8 * rr], ph, pm, pl);
-        char* p = buf + g.lds + rr * GW_ROWB;
+        char* p = buf + g.lds + rr * GW_ODD;
         *reinterpret_cast<gu4*>(p) = ph;
         *reinterpret_cast<gu4*>(p + GW_PARTB) = pm;
         *reinterpret_cast<gu4*>(p + 2 * GW_PARTB) = pl;
@@ -138,8 +137,8 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
     const int orow = lane & 31, ohalf = lane >> 5;
-    const unsigned a_off = (unsigned)(r0 * 32 + orow) * GW_ROWB + ohalf * 16;                 // matrix 0, part 0
-    const unsigned b_off = GW_MATB + (unsigned)(c0 * 32 + orow) * GW_ROWB + ohalf * 16;       // matrix 1, part 0
+    const unsigned a_off = gw_row(r0 * 32 + orow) + ohalf * 16;                 // matrix 0, part 0
+    const unsigned b_off = GW_MATB + gw_row(c0 * 32 + orow) + ohalf * 16;       // matrix 1, part 0
 
     float rawA[16], rawB[16];
     gw_fetch_first(g, half, rawA);
@@ -151,13 +150,13 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
     auto mma = [&](const char* buf) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const char* pa = buf + a_off + r * 32 * GW_ROWB;
+            const char* pa = buf + a_off + r * 16 * GW_ROWB;
             const gb8 ah = *reinterpret_cast<const gb8*>(pa);
             const gb8 am = *reinterpret_cast<const gb8*>(pa + GW_PARTB);
             const gb8 al = *reinterpret_cast<const gb8*>(pa + 2 * GW_PARTB);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
-                const char* pb = buf + b_off + c * 32 * GW_ROWB;
+                const char* pb = buf + b_off + c * 16 * GW_ROWB;
                 const gb8 bh = *reinterpret_cast<const gb8*>(pb);
                 const gb8 bm = *reinterpret_cast<const gb8*>(pb + GW_PARTB);
                 const gb8 bl = *reinterpret_cast<const gb8*>(pb + 2 * GW_PARTB);
@@ -173,18 +172,16 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
         }
     };
     // Slab s is multiplied from buffer s & 1 while slab s + 1 (in registers since two iterations) is split into the
-    // other buffer and slab s + 3 is requested from HBM.  The three are independent: one basic block, the scheduler
-    // is asked to put the VALU of the split into the shadow of the MFMAs.
+    // other buffer and slab s + 3 is requested from HBM.  The three are independent and sit in one basic block: the
+    // compiler puts the VALU of the split between the MFMAs (explicit sched_group_barrier pipelines changed nothing).
     for (int s = 0; s < nslab; s += 2) {
         mma(sm);
         gw_stage(g, sm + GW_BUFB, rawA);
         gw_fetch(g, s + 3, rawA);
-        GW_PIPELINE(NR * NC * 6)
         __syncthreads();
         mma(sm + GW_BUFB);
         gw_stage(g, sm, rawB);
         gw_fetch(g, s + 4, rawB);
-        GW_PIPELINE(NR * NC * 6)
         __syncthreads();
     }
     // (an odd slab count multiplies one slab of zeros at the end)
@@ -217,7 +214,7 @@ __global__ void __launch_bounds__(512, 2) gw_split_kernel(const float* __restric
     g.voff = (2 * pair < M) ? (8 * half * M + 2 * pair) * 4 : -1;
     g.k_stride = M * 4;
     g.pad = (int)((16 - K % 16) % 16);
-    g.lds = (unsigned)mat * GW_MATB + (unsigned)(2 * pair) * GW_ROWB + half * 16;
+    g.lds = (unsigned)mat * GW_MATB + gw_row(2 * pair) + half * 16;
     const int nslab = (int)((K + 15) / 16);
     float* out = gW + (size_t)b * M * M;
     using BL = GwBlocks<NT>;
@@ -265,7 +262,7 @@ hipError_t launch_weight_grad(const T* delta, const T* traj, T* gW, int B, long 
         const bool split_ok = M <= 224 && K * (long)M * 4 < (1L << 31);
         if (kernel == 2 && !split_ok) return hipErrorInvalidValue;
         if ((kernel == 0 && split_ok && M > 32) || kernel == 2) {
-            const size_t lds = 2 * (size_t)GW_BUFB;      // 147456 bytes: one workgroup per CU
+            const size_t lds = 2 * (size_t)GW_BUFB;      // 150528 bytes: one workgroup per CU
             hipError_t e;
             if (M <= 128) {
                 static bool once4 = false;
