@@ -220,7 +220,7 @@ static constexpr int TILE_RA = 7;
 static int tile_pick_c(int M, int elem_bytes) {
     const int need = (M + 7) / 8;
     const int ladder32[] = {4, 8, 13, 19, 25, 26};
-    const int ladder64[] = {4, 8, 13};                 // fp64: 2 VGPRs per value
+    const int ladder64[] = {4, 8, 13, 19, 26};         // fp64: 2 VGPRs per value; C >= 19 runs with 4 rows per lane
     if (elem_bytes == 4) { for (int c : ladder32) if (need <= c) return c; }
     else                 { for (int c : ladder64) if (need <= c) return c; }
     return 0;
@@ -251,7 +251,13 @@ static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st, bool spl
         if (a.NB >= 2) return launch_tile_k<T, TILE_RA, C, 0, 2, 2>(a, st);
         return launch_tile_k<T, TILE_RA, C, 0, 1, 2>(a, st);
     } else {
-        return launch_tile_k<T, TILE_RA, C, 0, 1, 1>(a, st);
+        // fp64 (2 VGPRs per value).  Up to 2N = 104: 7 rows x C <= 13 columns per lane, whole tile in VGPRs.  Beyond
+        // (the reference's default N = 102 gives 2N = 204, tc_gan/ssnode.py:28): 4 rows per lane and ceil(2N / 32)
+        // waves -- one workgroup of up to 7 waves owns the CU, W (333 KB at 2N = 204) sits in its VGPRs and, at C = 26,
+        // one row of every lane's tile in LDS (94 KB) so that the kernel stays under 256 VGPRs (two waves per SIMD).
+        if constexpr (C == 26) return launch_tile_k<T, 4, C, 1, 1, 2>(a, st);
+        else if constexpr (C == 19) return launch_tile_k<T, 4, C, 0, 1, 2>(a, st);
+        else return launch_tile_k<T, TILE_RA, C, 0, 1, 1>(a, st);
     }
 }
 
@@ -275,6 +281,8 @@ template <> hipError_t launch_tile<double>(const SolveArgs<double>& a, hipStream
         case 4: return launch_tile_nb<double, 4>(a, st, false);
         case 8: return launch_tile_nb<double, 8>(a, st, false);
         case 13: return launch_tile_nb<double, 13>(a, st, false);
+        case 19: return launch_tile_nb<double, 19>(a, st, false);
+        case 26: return launch_tile_nb<double, 26>(a, st, false);
         default: return hipErrorInvalidValue;
     }
 }

@@ -186,6 +186,10 @@ def test_test_inf_message():
     # variant 5: fp32 MFMA kernel (NB >= 4: matrix + serial waves, two stimulus groups half a step apart)
     (100, 8, 5, 'float32'), (100, 4, 5, 'float32'), (50, 5, 5, 'float32'), (101, 9, 5, 'float32'), (16, 11, 5, 'float32'),
     (76, 8, 5, 'float32'),
+    # fp64 resident shapes beyond 2N = 104: 4 rows per lane, 5-7 waves, one workgroup per CU (2N = 204 is the reference's
+    # default N = 102: the truth-data path of every CLI run)
+    (102, 1, 2, 'float64'), (102, 8, 2, 'float64'), (100, 3, 2, 'float64'), (76, 2, 2, 'float64'), (60, 1, 2, 'float64'),
+    (104, 1, 2, 'float64'),
 ])
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
@@ -393,3 +397,22 @@ def test_full_size_c2_properties(oracle_lib):
     want, _, _ = _oracle_batch(oracle_lib, Wd, exts, 'asym_tanh', T, 0.0)
     np.testing.assert_allclose(sub.x.cpu().numpy(), want, rtol=RTOL32, atol=1e-5)
     assert torch.isfinite(full.x).all()
+
+
+def test_default_size_fp64_resident_kernel_converges_like_the_oracle(oracle_lib):
+    """2N = 204 (the reference's default N = 102, tc_gan/ssnode.py:28), fp64, default solver settings: the register/LDS
+    resident tile kernel (the library's choice) and the streaming kernel against the C oracle -- codes, stop steps and
+    fixed points to 1e-9."""
+    from tc_gan_amd.ssnode import fixed_points_batch
+    N, B, NB = 102, 3, 8
+    Ws, exts = _inputs(N, B, NB, seed=11)
+    want, wcodes, wsteps = _oracle_batch(oracle_lib, Ws, exts, 'asym_tanh', 100000, 1e-5)
+    assert (wcodes == 0).all()
+    from tc_gan_amd.clib import libssnode
+    assert libssnode.ssn_solver_fast_path(2 * N, NB, 8) == 2              # the tile kernel covers this size
+    for variant in (None, 0):
+        res = fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=100000, atol=1e-5, io_type='asym_tanh',
+                                 dtype='float64', variant=variant, want_prev=True)
+        np.testing.assert_array_equal(res.codes, wcodes)
+        assert np.abs(res.steps - wsteps).max() <= 1
+        np.testing.assert_allclose(res.x, want, rtol=RTOL64, atol=1e-9)
