@@ -343,6 +343,13 @@ int ssn_stimulus_amp_f64(const double *bandwidths, const double *contrasts, doub
 int ssn_io_eval_f32(const float *v, float *out, long count, const ssn_solver_params *p, void *stream);
 int ssn_io_eval_f64(const double *v, double *out, long count, const ssn_solver_params *p, void *stream);
 
+/* Batched dense solve for the implicit gradient (the `solve` of tc_gan/gradient_expressions/SS_grad.py:44, once per
+ * (draw, stimulus)): A [nsys][M][M] row-major and rhs [nsys][M][nrhs] (nrhs = 4 or 1), device pointers, both
+ * OVERWRITTEN -- A with its LU factors (partial row pivoting), rhs with the solution.  info (device, [nsys], may be
+ * NULL): 0, or 1 + the first elimination step whose pivot column was all zero. */
+int ssn_lu_solve_f32(float *A, float *rhs, int *info, int nsys, int M, int nrhs, void *stream);
+int ssn_lu_solve_f64(double *A, double *rhs, int *info, int nsys, int M, int nrhs, void *stream);
+
 /* Device-side noise for the generator's z (replaces the host `rng.rand(batch, 2N, 2N)` of
  * tc_gan/networks/ssn.py:434-439 in the opt-in performance mode; the reference has no such mode, parity runs keep
  * host noise).  out[i] = u(seed, offset + i) in [0, 1) with 24 random bits, from Philox4x32-10 (Salmon, Moraes,

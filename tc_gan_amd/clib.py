@@ -113,6 +113,9 @@ libssnode.ssn_io_eval_f64.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
 for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
               'ssn_io_eval_f32', 'ssn_io_eval_f64'):
     getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_lu_solve_f32', 'ssn_lu_solve_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    getattr(libssnode, _name).restype = c_int
 for _name in ('ssn_weight_grad_f32', 'ssn_weight_grad_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]
     getattr(libssnode, _name).restype = c_int
@@ -230,7 +233,7 @@ DECLARED_SYMBOLS = (
     'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
     'ssn_critic_norm_workspace_floats', 'ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm',
     'ssn_critic_input_grad_norm', 'ssn_philox_uniform_f32', 'ssn_philox_uniform_f64',
-    'ssn_weight_grad_f32', 'ssn_weight_grad_f64',
+    'ssn_weight_grad_f32', 'ssn_weight_grad_f64', 'ssn_lu_solve_f32', 'ssn_lu_solve_f64',
 )
 
 

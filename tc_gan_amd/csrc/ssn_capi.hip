@@ -638,6 +638,16 @@ int ssn_ss_grad_system_f64(const double* R, const double* W, const double* dW, i
     return ss_system_impl<double>(R, W, dW, dw_per_draw, I, i_per_draw, nz, nb, M, p, A, rhs, stream);
 }
 
+int ssn_lu_solve_f32(float* A, float* rhs, int* info, int nsys, int M, int nrhs, void* stream) {
+    if (nsys < 0 || M < 0 || (nsys > 0 && M > 0 && (!A || !rhs))) { g_last_error = "ssn_lu_solve: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_lu_solve<float>(A, rhs, info, nsys, M, nrhs, (hipStream_t)stream));
+    return 0;
+}
+int ssn_lu_solve_f64(double* A, double* rhs, int* info, int nsys, int M, int nrhs, void* stream) {
+    if (nsys < 0 || M < 0 || (nsys > 0 && M > 0 && (!A || !rhs))) { g_last_error = "ssn_lu_solve: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_lu_solve<double>(A, rhs, info, nsys, M, nrhs, (hipStream_t)stream));
+    return 0;
+}
 int ssn_moment_sums_f32(const float* x, int B, int D, double* sums, void* stream) {
     if (B < 0 || D < 0 || (D > 0 && (!x || !sums))) {
         g_last_error = "ssn_moment_sums: invalid argument";

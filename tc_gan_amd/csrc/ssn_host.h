@@ -63,6 +63,8 @@ template <typename T> hipError_t launch_build_dw(const T* z, const T* jds12, int
 template <typename T> hipError_t launch_ss_system(const T* R, const T* W, const T* dW, int dw_per_draw, const T* I, int i_per_draw,
                                                   const IoConsts<T>& io, int nz, int nb, int M, T* A, T* rhs, hipStream_t st);
 
+template <typename T> hipError_t launch_lu_solve(T* A, T* rhs, int* info, int nsys, int M, int nrhs, hipStream_t st);
+
 // ssn_mfma.hip (fp32, NB >= 4)
 bool gen_mfma_supported(int M, int NB);
 hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st);

@@ -113,4 +113,102 @@ template hipError_t launch_ss_system<float>(const float*, const float*, const fl
 template hipError_t launch_ss_system<double>(const double*, const double*, const double*, int, const double*, int,
                                              const IoConsts<double>&, int, int, int, double*, double*, hipStream_t);
 
+// ---------------------------------------------------------------------------------------------------------------
+// Batched dense solve A x = b for the systems above (SS_grad.py:44 `solve` in a scan over (draw, stimulus)):
+// Gaussian elimination with partial (row) pivoting, one workgroup per system, in place -- A ends as its LU factors,
+// rhs as the solution.  The matrix stays in global memory (160 KB fp32 / 320 KB fp64 per system at 2N = 200: it lives in
+// L2 while its workgroup works on it); pivot row and multipliers of the current step are staged in LDS.  Per step:
+// pivot search (LDS tree), row swap, multipliers, rank-1 update of the trailing block and of the right-hand sides;
+// then a column-oriented back substitution.  ~4 M barriers per system; M^3 / 3 FMAs in k order.
+// info[s] = 0, or 1 + the first step whose pivot column was entirely zero (singular to working precision).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, int NRHS>
+__global__ void __launch_bounds__(256) lu_solve_kernel(T* __restrict__ Aall, T* __restrict__ Ball, int* __restrict__ info, int M) {
+    extern __shared__ __align__(16) unsigned char lu_smem[];
+    T* rowk = reinterpret_cast<T*>(lu_smem);              // [M + NRHS]  pivot row (columns k.., then its right-hand sides)
+    T* lcol = rowk + M + NRHS;                            // [M]         multipliers of the current column
+    __shared__ T red_v[256];
+    __shared__ int red_i[256];
+    __shared__ int bad;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    T* A = Aall + (size_t)blockIdx.x * M * M;
+    T* B = Ball + (size_t)blockIdx.x * M * NRHS;
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    for (int k = 0; k < M; ++k) {
+        // ---- pivot: largest |A[i][k]|, i >= k (ties: the smallest i, as LAPACK's i?amax) ------------------
+        T best = (T)-1; int bi = k;
+        for (int i = k + tid; i < M; i += nt) {
+            const T v = abs_t(A[(size_t)i * M + k]);
+            if (v > best) { best = v; bi = i; }
+        }
+        red_v[tid] = best; red_i[tid] = bi;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if (tid < off) {
+                const T v = red_v[tid + off]; const int i2 = red_i[tid + off];
+                if (v > red_v[tid] || (v == red_v[tid] && i2 < red_i[tid])) { red_v[tid] = v; red_i[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        const int p = red_i[0];
+        const T pv = red_v[0];
+        if (!(pv > (T)0)) { if (tid == 0 && bad == 0) bad = k + 1; }
+        // ---- swap rows k and p (columns k.. and the right-hand sides); stage the new row k in LDS -----------
+        for (int j = k + tid; j < M + NRHS; j += nt) {
+            T* ak = (j < M) ? &A[(size_t)k * M + j] : &B[(size_t)k * NRHS + (j - M)];
+            T* ap = (j < M) ? &A[(size_t)p * M + j] : &B[(size_t)p * NRHS + (j - M)];
+            const T vk = *ak, vp = *ap;
+            if (p != k) { *ak = vp; *ap = vk; }
+            rowk[j] = vp;
+        }
+        __syncthreads();
+        const T piv = rowk[k];
+        const T rinv = (piv != (T)0) ? (T)1 / piv : (T)0;
+        for (int i = k + 1 + tid; i < M; i += nt) {
+            const T l = A[(size_t)i * M + k] * rinv;
+            lcol[i] = l;
+            A[(size_t)i * M + k] = l;
+        }
+        __syncthreads();
+        // ---- trailing update: A[i][j] -= l_i rowk[j] (j > k) and the right-hand sides ----------------------
+        const int w = M + NRHS - (k + 1);                  // columns k+1 .. M+NRHS-1
+        const long cells = (long)(M - k - 1) * w;
+        for (long e = tid; e < cells; e += nt) {
+            const int i = k + 1 + (int)(e / w), j = k + 1 + (int)(e % w);
+            T* a = (j < M) ? &A[(size_t)i * M + j] : &B[(size_t)i * NRHS + (j - M)];
+            *a = fma(-lcol[i], rowk[j], *a);
+        }
+        __syncthreads();
+    }
+    // ---- back substitution, column oriented: x_k = b_k / u_kk, then b_i -= u_ik x_k for i < k --------------
+    for (int k = M - 1; k >= 0; --k) {
+        if (tid < NRHS) {
+            const T ukk = A[(size_t)k * M + k];
+            const T x = (ukk != (T)0) ? B[(size_t)k * NRHS + tid] / ukk : (T)0;
+            B[(size_t)k * NRHS + tid] = x;
+            rowk[tid] = x;
+        }
+        __syncthreads();
+        for (int e = tid; e < k * NRHS; e += nt) {
+            const int i = e / NRHS, c = e % NRHS;
+            B[(size_t)i * NRHS + c] = fma(-A[(size_t)i * M + k], rowk[c], B[(size_t)i * NRHS + c]);
+        }
+        __syncthreads();
+    }
+    if (info && tid == 0) info[blockIdx.x] = bad;
+}
+
+template <typename T>
+hipError_t launch_lu_solve(T* A, T* rhs, int* info, int nsys, int M, int nrhs, hipStream_t st) {
+    if (nsys <= 0 || M <= 0) return hipSuccess;
+    if (nrhs != 4 && nrhs != 1) return hipErrorInvalidValue;
+    const size_t lds = (size_t)(2 * M + nrhs) * sizeof(T);
+    if (nrhs == 4) hipLaunchKernelGGL((lu_solve_kernel<T, 4>), dim3(nsys), dim3(256), lds, st, A, rhs, info, M);
+    else hipLaunchKernelGGL((lu_solve_kernel<T, 1>), dim3(nsys), dim3(256), lds, st, A, rhs, info, M);
+    return hipGetLastError();
+}
+template hipError_t launch_lu_solve<float>(float*, float*, int*, int, int, int, hipStream_t);
+template hipError_t launch_lu_solve<double>(double*, double*, int*, int, int, int, hipStream_t);
+
 }  // namespace ssn

@@ -3,8 +3,8 @@
 
     dr/dtheta = (1 - Phi W)^-1 Phi (dW/dtheta r),     Phi = diag f'(W r + I).
 
-``ssn_ss_grad_system_*`` (csrc/ssn_ssgrad.hip) builds the batched systems; the batched LU solve is a library call
-(torch.linalg.solve -> rocSOLVER/hipBLAS)."""
+``ssn_ss_grad_system_*`` (csrc/ssn_ssgrad.hip) builds the batched systems and ``ssn_lu_solve_*`` (same file) solves
+them: Gaussian elimination with partial pivoting, one workgroup per (draw, stimulus) system, in place."""
 import ctypes
 
 import numpy as np
@@ -41,4 +41,11 @@ def WRgrad_batch(R, W, DW, I, n, k, nz, nb, N, CGAN=False, io_type=DEFAULT_PARAM
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_ss_grad_system')
     if nz * nb == 0:
         return rhs.reshape(nz, nb, M, 2, 2)
-    return torch.linalg.solve(A, rhs).reshape(nz, nb, M, 2, 2)
+    info = torch.zeros(nz * nb, device='cuda', dtype=torch.int32)
+    fn = libssnode.ssn_lu_solve_f64 if td == torch.float64 else libssnode.ssn_lu_solve_f32
+    clib.check(fn(A.data_ptr(), rhs.data_ptr(), info.data_ptr(), int(nz * nb), int(M), 4,
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_lu_solve')
+    if int(info.count_nonzero()) != 0:          # (the reference's theano `solve` raises on a singular matrix too)
+        raise np.linalg.LinAlgError('1 - Phi W is singular for {} of the {} (draw, stimulus) systems'
+                                    .format(int(info.count_nonzero()), nz * nb))
+    return rhs.reshape(nz, nb, M, 2, 2)         # solved in place

@@ -40,8 +40,9 @@ def test_fast_path_table():
     assert libssnode.ssn_solver_fast_path(204, 8, 4) == 2
     assert libssnode.ssn_solver_fast_path(402, 8, 4) == 0      # falls back to the streaming kernel
     assert libssnode.ssn_solver_fast_path(100, 1, 8) == 2
-    assert libssnode.ssn_solver_fast_path(112, 1, 8) == 1      # fp64: DPP kernel only
-    assert libssnode.ssn_solver_fast_path(200, 1, 8) == 0
+    assert libssnode.ssn_solver_fast_path(112, 1, 8) == 2      # fp64 beyond 2N = 104: 4 rows per lane, 5-7 waves
+    assert libssnode.ssn_solver_fast_path(204, 8, 8) == 2      # the reference's default N = 102 in fp64
+    assert libssnode.ssn_solver_fast_path(210, 1, 8) == 0
     assert libssnode.ssn_solver_fast_path(7, 1, 4) == 0         # odd M is invalid
 
 

@@ -101,3 +101,45 @@ def test_WRgrad_batch_per_draw_input_and_empty():
     e = SS_grad.WRgrad_batch(np.zeros((0, nb, 2 * N)), np.zeros((0, 2 * N, 2 * N)), osg.make_dW('J', Z, J, D, S, N), ext,
                              P['n'], P['k'], 0, nb, N)
     assert tuple(e.shape) == (0, nb, 2 * N, 2, 2)
+
+
+@pytest.mark.parametrize('M,nsys,dtype', [(1, 3, 'float64'), (7, 5, 'float64'), (50, 4, 'float64'), (200, 3, 'float64'),
+                                          (204, 2, 'float32'), (33, 6, 'float32')])
+def test_batched_lu_solve_vs_numpy(M, nsys, dtype):
+    """ssn_lu_solve_* (partial pivoting, in place) against numpy.linalg.solve: generic matrices, matrices that NEED row
+    exchanges (zero / tiny leading entries), the (1 - Phi W) form of the implicit gradient, and a singular system."""
+    import ctypes
+    import torch
+    from tc_gan_amd import clib
+    rs = np.random.RandomState(M * 7 + nsys)
+    A = rs.randn(nsys, M, M)
+    A[0] = np.eye(M) - 0.3 * rs.rand(M, M) / max(M, 1) * 4            # diagonally dominant, like 1 - Phi W
+    if nsys > 1 and M > 1:
+        A[1, 0, 0] = 0.0                                             # first pivot must come from another row
+        A[1, 1, :2] = [1e-14, 1.0]
+    b = rs.randn(nsys, M, 4)
+    want = np.linalg.solve(A, b)
+    td = getattr(torch, dtype)
+    At, bt = torch.as_tensor(A).to('cuda', td).contiguous(), torch.as_tensor(b).to('cuda', td).contiguous()
+    info = torch.full((nsys,), -1, device='cuda', dtype=torch.int32)
+    fn = clib.libssnode.ssn_lu_solve_f64 if dtype == 'float64' else clib.libssnode.ssn_lu_solve_f32
+    clib.check(fn(At.data_ptr(), bt.data_ptr(), info.data_ptr(), nsys, M, 4, None), 'ssn_lu_solve')
+    assert (info.cpu().numpy() == 0).all()
+    got = bt.cpu().numpy()
+    # backward-stable solve: error relative to cond(A) * eps; compare through the residual and against numpy
+    resid = np.abs(np.einsum('sij,sjc->sic', A, got.astype('float64')) - b).max()
+    eps = 1e-12 if dtype == 'float64' else 1e-3
+    assert resid < eps * max(1.0, np.abs(A).max() * np.abs(want).max() * M)
+    if dtype == 'float64':
+        cond = max(np.linalg.cond(a) for a in A)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-13 * cond * np.abs(want).max())
+    # a singular system is reported, not silently "solved"
+    if M >= 2:
+        S = rs.randn(1, M, M)
+        S[0, :, 1] = 2.0 * S[0, :, 0]                                # two proportional columns
+        S[0, :, 0] = 0.0                                              # and an all-zero one: zero pivot column
+        St = torch.as_tensor(S).to('cuda', td).contiguous()
+        bt1 = torch.as_tensor(b[:1]).to('cuda', td).contiguous()
+        info1 = torch.zeros(1, device='cuda', dtype=torch.int32)
+        clib.check(fn(St.data_ptr(), bt1.data_ptr(), info1.data_ptr(), 1, M, 4, None), 'ssn_lu_solve')
+        assert int(info1[0]) == 1
