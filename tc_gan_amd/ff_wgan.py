@@ -64,7 +64,7 @@ class FFWGAN(object):
         """(Wasserstein distance estimate, full loss, d loss / d w) for minibatches (nsam, ni)."""
         w = self.w.to(torch.float64)
         xd, xg, xp = (t.to(torch.float64) for t in (xd, xg, xp))
-        wdist = (xg @ w).mean() - (xd @ w).mean()
+        wdist = (xg * w[None, :]).sum(dim=1).mean() - (xd * w[None, :]).sum(dim=1).mean()   # 27-term dots: elementwise
         a = 1.0 / (1.0 + xp)                                  # d log(1 + x) / d x
         nrm = torch.sqrt(((w[None, :] * a) ** 2).sum(dim=1))
         pen = ((nrm - 1.0) ** 2).mean()
@@ -90,7 +90,7 @@ class FFWGAN(object):
         """FF_lalazar_model.py:291-292: loss = -mean D(G(z)); Adam on (RF_low, RF_del, THR, THR_del, Js)."""
         ss = self.draw()
         xg, out, saved = self.generate(ss, keep=True)
-        loss = -float((xg.to(torch.float64) @ self.w.to(torch.float64)).mean())
+        loss = -float((xg.to(torch.float64) * self.w.to(torch.float64)[None, :]).sum(dim=1).mean())
         g_out = torch.zeros_like(out)
         g_out[:, :, self.observed] = -self.w[None, :] / self.nsam
         g = ff_model.ff_backward(self.params, saved, out, g_out)
