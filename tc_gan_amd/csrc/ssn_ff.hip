@@ -132,44 +132,73 @@ __global__ void __launch_bounds__(256) ff_forward_lattice_kernel(FFArgs a, FFLat
     { const int g = threadIdx.x * pts; bz = g % a.box; by = (g / a.box) % a.box; bx = g / (a.box * a.box); }
     const int stride = 256 * pts;
     const int sx = stride / (a.box * a.box), sy = (stride % (a.box * a.box)) / a.box, sz = stride % a.box;
-    for (int v = threadIdx.x; v < nv; v += 256) {
-        const V4 q0 = n0, q1 = n1, q2 = n2;
-        fetch(v + 256, n0, n1, n2);
-        const float w4[4] = {q0.x, q0.y, q0.z, q0.w}, c4[4] = {q1.x, q1.y, q1.z, q1.w}, s4[4] = {q2.x, q2.y, q2.z, q2.w};
-        const int cnt = vec ? 4 : 1;
-        int iz = bz, iy = by, ix = bx;
-        for (int t = 0; t < cnt; ++t) {
-            if (t > 0) { if (++iz >= a.box) { iz = 0; if (++iy >= a.box) { iy = 0; ++ix; } } }
-            const float px = -3.f + step * ix, py = -3.f + step * iy, pz = -3.f + step * iz;
-            const float sig = w4[t] * a.RF_d + a.RF_l;
-            const float c2 = -0.72134752044448170f * __builtin_amdgcn_rcpf(sig * sig);   // -log2(e) / (2 sig^2), 1 ulp
-            const float wj = a.J * c4[t] * s4[t];
-            float ex[3], ey[3], ez[3], ezw[3];
+    // one point: 9 exponentials, 9 + 9 + 3 multiplies, 27 packed FMAs.  e = ex ey ez is never formed:
+    // sum e w += (ex ey) (ez w), sum e += (ex ey) ez.
+    auto point = [&](const float (&dxx)[3], const float (&dyy)[3], const float (&dzz)[3], float w, float c, float sv) {
+        const float sig = w * a.RF_d + a.RF_l;
+        const float c2 = -0.72134752044448170f * __builtin_amdgcn_rcpf(sig * sig);   // -log2(e) / (2 sig^2), 1 ulp
+        const float wj = a.J * c * sv;
+        float ex[3], ey[3], ez[3], ezw[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float dx = px - lat.x[k], dy = py - lat.y[k], dz = pz - lat.z[k];
-                ex[k] = __builtin_amdgcn_exp2f(dx * dx * c2);
-                ey[k] = __builtin_amdgcn_exp2f(dy * dy * c2);
-                ez[k] = __builtin_amdgcn_exp2f(dz * dz * c2);
-                ezw[k] = ez[k] * wj;
-            }
-            // e = ex ey ez is never formed: sum e w += (ex ey) (ez w), sum e += (ex ey) ez -- 9 + 3 multiplies and
-            // 54 FMAs per point instead of 36 multiplies and 54 FMAs
-#pragma unroll
-            for (int ia = 0; ia < 3; ++ia)
-#pragma unroll
-                for (int ib = 0; ib < 3; ++ib) {
-                    const float exy = ex[ia] * ey[ib];
-#pragma unroll
-                    for (int ic = 0; ic < 3; ++ic) {
-                        const int i = (ia * 3 + ib) * 3 + ic;
-                        acc2[i] = __builtin_elementwise_fma(V2{exy, exy}, V2{ezw[ic], ez[ic]}, acc2[i]);
-                    }
-                }
+        for (int k = 0; k < 3; ++k) {
+            ex[k] = __builtin_amdgcn_exp2f(dxx[k] * c2);
+            ey[k] = __builtin_amdgcn_exp2f(dyy[k] * c2);
+            ez[k] = __builtin_amdgcn_exp2f(dzz[k] * c2);
+            ezw[k] = ez[k] * wj;
         }
-        bz += sz; if (bz >= a.box) { bz -= a.box; ++by; }
-        by += sy; if (by >= a.box) { by -= a.box; ++bx; }
-        bx += sx;
+#pragma unroll
+        for (int ia = 0; ia < 3; ++ia)
+#pragma unroll
+            for (int ib = 0; ib < 3; ++ib) {
+                const float exy = ex[ia] * ey[ib];
+#pragma unroll
+                for (int ic = 0; ic < 3; ++ic) {
+                    const int i = (ia * 3 + ib) * 3 + ic;
+                    acc2[i] = __builtin_elementwise_fma(V2{exy, exy}, V2{ezw[ic], ez[ic]}, acc2[i]);
+                }
+            }
+    };
+    auto sq3 = [&](float p, const float (&l)[3], float (&out)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const float d = p - l[k]; out[k] = d * d; }
+    };
+    if (vec && a.box % 4 == 0) {
+        // the four points of a 16-byte load are consecutive in z and share (ix, iy): the squared x and y distances to the
+        // lattice are formed once per load (6 + 6 VALU per four points instead of per point), fully unrolled
+        for (int v = threadIdx.x; v < nv; v += 256) {
+            const V4 q0 = n0, q1 = n1, q2 = n2;
+            fetch(v + 256, n0, n1, n2);
+            float dxx[3], dyy[3], dzz[3];
+            sq3(-3.f + step * bx, lat.x, dxx);
+            sq3(-3.f + step * by, lat.y, dyy);
+            const float pz0 = -3.f + step * bz;
+            sq3(pz0, lat.z, dzz);             point(dxx, dyy, dzz, q0.x, q1.x, q2.x);
+            sq3(pz0 + step, lat.z, dzz);      point(dxx, dyy, dzz, q0.y, q1.y, q2.y);
+            sq3(pz0 + 2.f * step, lat.z, dzz); point(dxx, dyy, dzz, q0.z, q1.z, q2.z);
+            sq3(pz0 + 3.f * step, lat.z, dzz); point(dxx, dyy, dzz, q0.w, q1.w, q2.w);
+            bz += sz; if (bz >= a.box) { bz -= a.box; ++by; }
+            by += sy; if (by >= a.box) { by -= a.box; ++bx; }
+            bx += sx;
+        }
+    } else {
+        for (int v = threadIdx.x; v < nv; v += 256) {
+            const V4 q0 = n0, q1 = n1, q2 = n2;
+            fetch(v + 256, n0, n1, n2);
+            const float w4[4] = {q0.x, q0.y, q0.z, q0.w}, c4[4] = {q1.x, q1.y, q1.z, q1.w}, s4[4] = {q2.x, q2.y, q2.z, q2.w};
+            const int cnt = vec ? 4 : 1;
+            int iz = bz, iy = by, ix = bx;
+            for (int t = 0; t < cnt; ++t) {
+                if (t > 0) { if (++iz >= a.box) { iz = 0; if (++iy >= a.box) { iy = 0; ++ix; } } }
+                float dxx[3], dyy[3], dzz[3];
+                sq3(-3.f + step * ix, lat.x, dxx);
+                sq3(-3.f + step * iy, lat.y, dyy);
+                sq3(-3.f + step * iz, lat.z, dzz);
+                point(dxx, dyy, dzz, w4[t], c4[t], s4[t]);
+            }
+            bz += sz; if (bz >= a.box) { bz -= a.box; ++by; }
+            by += sy; if (by >= a.box) { by -= a.box; ++bx; }
+            bx += sx;
+        }
     }
     float acc[2 * NI_T];
 #pragma unroll
