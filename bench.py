@@ -112,6 +112,14 @@ def cpu_baseline(N, NB, T, sample_B, threads):
                        (sample_B, NB, T, M, threads, best))
 
 
+def _traffic(key):
+    """PMC-derived HBM bytes per launch of the workload's dominant kernel (profiles/hbm_traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json'))).get(key)
+    except Exception:
+        return None
+
+
 def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iters_init=5, critic_iters=5, models=None):
     """The GAN of BASELINE config 3/4 (or, `paper=True`, of scripts/fig4/gan/run.json) with its truth data set:
     returns (gan, (N, models_per_rank, NB, T, skip), bandwidths).  Shared by the bench and by the full-size parity test."""
@@ -278,7 +286,7 @@ def run_c5(args, rank, world, local_rank):
            'config': {'workload': 'C5: FF_lalazar get_FF_output, box_width 40 (64000 points), 27 stimuli, 1 hidden unit, '
                                   '16384 samples per GPU', 'parallelism': 'samples sharded over %d GPU(s)' % world},
            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                        'traffic': None, 'kernel': 'ff_forward_kernel', 'kernel_ms': kernel_ms,
+                        'traffic': _traffic('c5'), 'kernel': 'ff_forward_lattice_kernel', 'kernel_ms': kernel_ms,
                         'algorithmic_hbm_bytes': bytes_alg}}
     res['world_size'] = world
     return res

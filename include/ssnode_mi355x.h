@@ -85,8 +85,10 @@ typedef struct ssn_solver_params {
 int         ssn_abi_version(void);
 int         ssn_device_count(void);          /* <0: -hipError_t */
 const char *ssn_last_error(void);            /* thread-local, "" if none */
-/* Which kernel a (M, NB, dtype) solve dispatches to: 2 = register-stationary "tile"
- * kernel, 1 = register-stationary DPP kernel, 0 = generic streaming kernel.
+/* Which register-resident kernel family covers a (M, NB, dtype) solve: 2 = "tile" kernel
+ * (fp32: 2N <= 208, fp64: 2N <= 208), 1 = DPP kernel only, 0 = none (generic streaming
+ * kernel).  The automatic dispatch of ssn_solve_batch_* additionally prefers the fp32 MFMA
+ * kernel (variant 5) for NB >= 4, 104 < 2N <= 208 and >= 192 (draw, 8 stimuli) workgroups.
  * dtype_bytes is 4 or 8. */
 int         ssn_solver_fast_path(int M, int NB, int dtype_bytes);
 

@@ -181,10 +181,25 @@ __global__ void __launch_bounds__(256) moment_loss_grad_kernel(const float* __re
         const double xv = (double)x[(size_t)b * D + d];
         gx[(size_t)b * D + d] = (float)(c0 + c1 * (xv - m));
     }
-    if (threadIdx.x == 0) {
-        out[1 + d] = m; out[1 + D + d] = s;
-        atomicAdd(&out[0], (w0 * em * em + w1 * es * es) / (2.0 * D));
+    if (threadIdx.x == 0) { out[1 + d] = m; out[1 + D + d] = s; }
+}
+// L0 = mean over the (2, D) array of w (data - gen)^2, summed in channel order by ONE workgroup (a tree with a fixed
+// shape: the value does not depend on which channel's workgroup finished first, as an atomic sum would)
+__global__ void __launch_bounds__(256) moment_loss_sum_kernel(const double* __restrict__ data_moments,
+                                                              const double* __restrict__ weights, int D, double* __restrict__ out) {
+    __shared__ double red[256];
+    double t = 0.0;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const double em = out[1 + d] - data_moments[d], es = out[1 + D + d] - data_moments[D + d];
+        t += weights[d] * em * em + weights[D + d] * es * es;
     }
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (2.0 * D);
 }
 
 hipError_t launch_moment_sums(const float* x, int B, int D, double* sums, hipStream_t st) {
@@ -197,6 +212,7 @@ hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg
     hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
     if (e != hipSuccess || D == 0) return e;
     hipLaunchKernelGGL(moment_loss_grad_kernel, dim3(D), dim3(256), 0, st, x, sums, Bg, data_moments, weights, B, D, gx, out);
+    hipLaunchKernelGGL(moment_loss_sum_kernel, dim3(1), dim3(256), 0, st, data_moments, weights, D, out);
     return hipGetLastError();
 }
 

@@ -16,12 +16,17 @@
 //     reads (the 8 lanes of a column group read the same address -> broadcast;
 //     slabs are padded so the 8 column groups hit disjoint banks) and issues
 //     RA*C plain FMAs: every loaded r value feeds RA FMAs;
-//   * the 8 partial sums of a row sit in 8 ADJACENT lanes and are combined by
-//     three DPP adds (quad_perm xor-1, xor-2, row_half_mirror);
+//   * the 8 partial sums of a row sit in 8 ADJACENT lanes; a transpose-reduce
+//     (reduce8_to_lane, ssn_tile_core.h: 7 DPP adds + selects, the first stage as
+//     masked v_add_f32_dpp) leaves lane cg with the complete sum of row a = cg;
 //   * lane cg < RA then finishes row a = cg: + ext, I/O nonlinearity, Euler
 //     update, stop tests, and writes r' back to LDS.  ONE barrier per step.
 // For 2N = 200: C = 25, RA = 7, 4 waves (224 row slots, 200 used; all 200
-// columns exact), 175 W registers per lane, two workgroups per CU.
+// columns exact).  Default shape: split residency (RL = 2: five rows of every
+// lane's tile in VGPRs as packed pairs, two in LDS), 167 VGPRs, three workgroups
+// per CU; the all-register shape (175 W registers per lane, two workgroups per
+// CU) is variant 4.  fp64: 7 rows x C <= 13 up to 2N = 104, 4 rows x C = 19 / 26
+// (one workgroup of 5-7 waves per CU) up to 2N = 208.
 #include <hip/hip_runtime.h>
 #include "ssn_device.h"
 #include "ssn_host.h"

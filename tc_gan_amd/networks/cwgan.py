@@ -175,17 +175,24 @@ class GradientAllReducer(object):
         self.rank = dist.get_rank() if self.on else 0
 
     def mean_(self, *tensors):
-        """In-place mean over ranks of several tensors through ONE collective."""
+        """In-place mean over ranks of several tensors through ONE collective (one persistent flat fp32 buffer per
+        total size: no allocation per update)."""
         if not self.on:
             return
-        flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+        n = sum(t.numel() for t in tensors)
+        flat = getattr(self, '_flat', None)
+        if flat is None or flat.numel() != n or flat.device != tensors[0].device:
+            flat = self._flat = torch.empty(n, device=tensors[0].device, dtype=torch.float32)
+        off = 0
+        for t in tensors:
+            flat[off:off + t.numel()].copy_(t.reshape(-1))
+            off += t.numel()
         self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
         flat /= self.world
         off = 0
         for t in tensors:
-            n = t.numel()
-            t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
-            off += n
+            t.copy_(flat[off:off + t.numel()].reshape(t.shape))
+            off += t.numel()
 
 
 class ConditionalBPTTWassersteinGAN(object):
