@@ -42,3 +42,32 @@ def test_gan_loop_line():
     assert KEYS <= set(d)
     assert d['metric'] == 'GAN iters/sec' and d['value'] > 0 and d['roofline']['bound'] == 'mfma'
     assert abs(d['value'] - 1e3 / d['ms_per_step']) / d['value'] < 1e-6
+
+
+def test_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU) starts two ranks; here they
+    share the one card of the test box over gloo.  One JSON line, n_gpus = world_size = 2, the C3 secondary aboard."""
+    env = dict(os.environ, BENCH_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                          '--secondary-steps', '1'], check=True, env=env, capture_output=True, text=True,
+                         timeout=900).stdout.strip().splitlines()
+    lines = [l for l in out if l.startswith('{')]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['world_size'] == 2 and d['dist_backend'] == 'gloo'
+    assert d['metric'] == 'SSN-steps/sec' and d['scaling'] == 'weak'
+    # value = all ranks' units / max-over-ranks time
+    assert abs(d['value'] - 2 * 200 * 4096 * 2000 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
+    sec = d['secondary']
+    assert sec['metric'] == 'GAN iters/sec' and sec['n_gpus'] == 2 and sec['value'] > 0
+    assert 'cpu_baseline' not in d                      # rank 0 at N = 1 only
+
+
+def test_gpus_mismatch_is_refused():
+    """A launcher that started a different number of ranks than --gpus names: no line, non-zero exit."""
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and '{' not in r.stdout
