@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <condition_variable>
@@ -507,12 +508,28 @@ long ssn_critic_num_params(const int* dims, int nlayers) {
     for (int l = 0; l < nlayers; ++l) n += (long)dims[l] * dims[l + 1] + dims[l + 1];
     return n + dims[nlayers];
 }
+// Critics whose layers are all <= 128 wide run through the fused row-block kernels (ssn_critic_fused.hip: 3 launches per
+// update, fp32 arithmetic whatever `precision` says); wider ones through the layer-by-layer MFMA GEMM chain.  The
+// workspace is sized for whichever path the sizes select.
+static size_t max_sz(size_t a, size_t b) { return a > b ? a : b; }
+// SSN_CRITIC_FUSED=0 in the environment keeps small critics on the layer-by-layer path too (A/B timing, tests of that path)
+// Above ~2048 stacked rows the layer-by-layer chain (fixed ~250 us of launch latency, MFMA arithmetic) is as fast as the
+// fused kernels (plain FMAs, time proportional to the rows).
+static bool fused_ok(const int* dims, int nlayers, long rows) {
+    static const bool enabled = [] { const char* v = std::getenv("SSN_CRITIC_FUSED"); return !(v && v[0] == '0'); }();
+    return enabled && rows <= 2048 && ssn::critic_fused_supported(dims, nlayers);
+}
 size_t ssn_critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p) {
-    return ssn::critic_workspace_floats(dims, nlayers, batch_gd, batch_p);
+    const size_t base = ssn::critic_workspace_floats(dims, nlayers, batch_gd, batch_p);
+    return ssn::critic_fused_supported(dims, nlayers) ? max_sz(base, ssn::critic_fused_workspace_floats(dims, nlayers, batch_gd, batch_p)) : base;
 }
 int ssn_critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
                        int hide_cell_type, float* out, float* workspace, int precision, void* stream) {
     if (batch == 0) return 0;
+    if (fused_ok(dims, nlayers, batch)) {
+        SSN_TRY(ssn::critic_fused_forward(params, dims, nullptr, nlayers, x, cond, batch, hide_cell_type, out, workspace, (hipStream_t)stream));
+        return 0;
+    }
     SSN_TRY(ssn::critic_forward(params, dims, nlayers, x, cond, batch, hide_cell_type, out, workspace, precision == 0,
                                 (hipStream_t)stream));
     return 0;
@@ -521,6 +538,11 @@ int ssn_critic_loss_grad(const float* params, const int* dims, int nlayers, cons
                          const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
                          float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* workspace,
                          int precision, void* stream) {
+    if (fused_ok(dims, nlayers, (long)ng + nd + np)) {
+        SSN_TRY(ssn::critic_fused_loss_grad(params, dims, nullptr, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type,
+                                            grads, stats, dvals, workspace, (hipStream_t)stream));
+        return 0;
+    }
     SSN_TRY(ssn::critic_loss_grad(params, dims, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type, grads,
                                   stats, dvals, workspace, precision == 0, (hipStream_t)stream));
     return 0;
@@ -529,17 +551,27 @@ int ssn_critic_input_grad(const float* params, const int* dims, int nlayers, con
                           int hide_cell_type, float scale, float* gx, float* stats, float* workspace, int precision,
                           void* stream) {
     if (batch == 0) return 0;
+    if (fused_ok(dims, nlayers, batch)) {
+        SSN_TRY(ssn::critic_fused_input_grad(params, dims, nullptr, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
+                                             workspace, (hipStream_t)stream));
+        return 0;
+    }
     SSN_TRY(ssn::critic_input_grad(params, dims, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats, workspace,
                                    precision == 0, (hipStream_t)stream));
     return 0;
 }
 size_t ssn_critic_norm_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p) {
-    return ssn::critic_norm_workspace_floats(dims, nlayers, batch_gd, batch_p);
+    const size_t base = ssn::critic_norm_workspace_floats(dims, nlayers, batch_gd, batch_p);
+    return ssn::critic_fused_supported(dims, nlayers) ? max_sz(base, ssn::critic_fused_workspace_floats(dims, nlayers, batch_gd, batch_p)) : base;
 }
 int ssn_critic_forward_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* x,
                             const float* cond, int batch, int hide_cell_type, float* out, float* workspace, int precision,
                             void* stream) {
     if (batch == 0) return 0;
+    if (fused_ok(dims, nlayers, batch)) {
+        SSN_TRY(ssn::critic_fused_forward(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, out, workspace, (hipStream_t)stream));
+        return 0;
+    }
     SSN_TRY(ssn::critic_norm_forward(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, out, workspace,
                                      precision == 0, (hipStream_t)stream));
     return 0;
@@ -548,6 +580,11 @@ int ssn_critic_loss_grad_norm(const float* params, const int* dims, const int* l
                               const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
                               int nd, int np, float lmd, int hide_cell_type, float* grads, float* stats, float* dvals,
                               float* workspace, int precision, void* stream) {
+    if (fused_ok(dims, nlayers, (long)ng + nd + np)) {
+        SSN_TRY(ssn::critic_fused_loss_grad(params, dims, layer_norm, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type,
+                                            grads, stats, dvals, workspace, (hipStream_t)stream));
+        return 0;
+    }
     SSN_TRY(ssn::critic_norm_loss_grad(params, dims, layer_norm, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd,
                                        hide_cell_type, grads, stats, dvals, workspace, precision == 0, (hipStream_t)stream));
     return 0;
@@ -556,6 +593,11 @@ int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* 
                                const float* cond, int batch, int hide_cell_type, float scale, float* gx, float* stats,
                                float* workspace, int precision, void* stream) {
     if (batch == 0) return 0;
+    if (fused_ok(dims, nlayers, batch)) {
+        SSN_TRY(ssn::critic_fused_input_grad(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
+                                             workspace, (hipStream_t)stream));
+        return 0;
+    }
     SSN_TRY(ssn::critic_norm_input_grad(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
                                         workspace, precision == 0, (hipStream_t)stream));
     return 0;

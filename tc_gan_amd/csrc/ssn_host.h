@@ -114,6 +114,19 @@ hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int
                                  int nd, int np, float lmd, int hide, float* grads, float* stats, float* dvals, float* ws,
                                  bool bf16, hipStream_t st);
 
+// ssn_critic_fused.hip: critics whose layer widths are all <= 128 (3 launches per update; fp32 arithmetic)
+bool critic_fused_supported(const int* dims, int nlayers);
+size_t critic_fused_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);
+hipError_t critic_fused_forward(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
+                                const float* cond, int batch, int hide, float* out, float* ws, hipStream_t st);
+hipError_t critic_fused_input_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
+                                   const float* cond, int batch, int hide, float scale, float* gx, float* stats, float* ws,
+                                   hipStream_t st);
+hipError_t critic_fused_loss_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* xg,
+                                  const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
+                                  int nd, int np, float lmd, int hide, float* grads, float* stats, float* dvals, float* ws,
+                                  hipStream_t st);
+
 // ssn_ff.hip
 struct FFArgs {
     const float* RF_w;     // [nsam][G]

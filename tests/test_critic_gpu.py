@@ -1,5 +1,9 @@
 """GPU parity of the critic (forward, WGAN-GP loss and gradient, input gradient) and of the optimizer
 kernels against oracle/gan_torch.py.  fp32-MFMA path: tight; bf16-MFMA path: bf16 tolerance."""
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -248,3 +252,15 @@ def test_reference_layer_norm_layer_known_answer():
     c.set_flat(np.concatenate([-np.eye(n).ravel(), np.zeros(n), np.zeros(n)]))
     neg = _hidden_activations(c, x)
     np.testing.assert_allclose(pos - neg, _np_norm_layer(x.astype('float64'), 1e-4), rtol=2e-5, atol=2e-6)
+
+
+def test_layer_by_layer_path_still_covers_small_widths():
+    """Critics up to 128 wide (and up to 2048 stacked rows) take the fused row-block kernels (ssn_critic_fused.hip); the
+    layer-by-layer MFMA chain keeps serving wider or larger ones.  Rerun this file's parity tests with the fused path
+    switched off (SSN_CRITIC_FUSED=0) so that both implementations are checked against the oracle at the same shapes."""
+    if os.environ.get('SSN_CRITIC_FUSED') == '0':
+        pytest.skip('already running with the fused path disabled')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k',
+                        'not layer_by_layer'], env=dict(os.environ, SSN_CRITIC_FUSED='0'), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
