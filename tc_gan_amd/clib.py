@@ -23,7 +23,8 @@ try:
 except ImportError:      # pure-ctypes use without torch: the system runtime is used
     torch = None
 
-libdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ext')
+# (SSN_LIBDIR: A/B timing of two builds of the library in one session -- tools/ab_build.sh; never set in production)
+libdir = os.environ.get('SSN_LIBDIR') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ext')
 
 
 def load_library(name):

@@ -13,6 +13,10 @@
 #ifndef SSN_PRIO_MODE
 #define SSN_PRIO_MODE 2
 #endif
+// diagnostic switch: 0 = leave the packed FMAs of the split tile to the compiler (A/B builds), 1 = asm with op_sel broadcast
+#ifndef SSN_PK_ASM
+#define SSN_PK_ASM 1
+#endif
 
 namespace ssn {
 
@@ -345,13 +349,27 @@ template <typename T, int RA, int C, int RL> struct SplitTile {
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 const T rr[4] = {rv[q][s].x, rv[q][s].y, rv[q][s].z, rv[q][s].w};
+                // fp32: acc += w2 * (r, r) with r taken from ONE half of the aligned register pair the 16-byte read left it
+                // in (op_sel broadcasts the low or the high half to both lanes of v_pk_fma_f32).  Written as asm because
+                // the compiler, short of registers, copies every fourth r into a fresh pair first (one v_mov per quad and
+                // accumulator group: ~15 of ~190 instructions per step).
+                const V2 rlo = {rv[q][s].x, rv[q][s].y}, rhi = {rv[q][s].z, rv[q][s].w};
+                auto pk_bcast = [&](V2& acc, const V2& w2, int e) {
+                    if constexpr (sizeof(T) == 4 && SSN_PK_ASM) {
+                        if (e == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w2), "v"(rlo));
+                        else if (e == 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w2), "v"(rlo));
+                        else if (e == 2) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w2), "v"(rhi));
+                        else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w2), "v"(rhi));
+                    } else {
+                        acc = __builtin_elementwise_fma(w2, (V2){rr[e], rr[e]}, acc);
+                    }
+                };
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * q + e;
                     if (c < C) {
-                        const V2 x2 = {rr[e], rr[e]};
 #pragma unroll
-                        for (int k = 0; k < NP; ++k) a2[s][k] = __builtin_elementwise_fma(p[k][c], x2, a2[s][k]);
+                        for (int k = 0; k < NP; ++k) pk_bcast(a2[s][k], p[k][c], e);
                         if (ODD) ao[s] = fma(o[c], rr[e], ao[s]);
                     }
                 }
@@ -362,7 +380,7 @@ template <typename T, int RA, int C, int RL> struct SplitTile {
                         if constexpr (RL == 2) {
                             const int j = c * 2;
                             const V2 wp = {wu[j / 4][j % 4], wu[j / 4][j % 4 + 1]};
-                            al2[s] = __builtin_elementwise_fma(wp, (V2){rr[e], rr[e]}, al2[s]);
+                            pk_bcast(al2[s], wp, e);
                         } else if constexpr (RL == 1) {
                             al1[s] = fma(wu[c / 4][c % 4], rr[e], al1[s]);
                         }
