@@ -32,35 +32,36 @@
 #include "ssn_host.h"
 #include "ssn_tile_core.h"
 
+// diagnostic switch: 0 = the uniform 7-row kernel also at 2N = 170..200 (A/B builds)
+#ifndef SSN_TILE_MIXED
+#define SSN_TILE_MIXED 1
+#endif
+
 namespace ssn {
 
-template <typename T, int RA, int C, int RL, int NB, int MAXTHREADS, int MINWAVES>
-__global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveArgs<T> a) {
+// The Euler loop of one wave: its RA x C tile of W (rows rowbase + a of row group rg), the step loop with ONE workgroup
+// barrier per step, the stop protocol and the final stores.  Every wave of a workgroup runs this with the same C, NB
+// and barrier sequence; RA / RL / PK (row pairs packed for v_pk_fma_f32) may differ between waves (mixed kernel below).
+template <typename T, int RA, int C, int RL, int NB, bool PK>
+__device__ __forceinline__ void tile_wave_body(const SolveArgs<T>& a, T* wlds, T (*rbuf)[NB][8 * SlabPad<C>::value],
+                                               int (*flags)[NB], const int rowbase) {
     constexpr int CP = SlabPad<C>::value;
-    using Split = TileSplit<RA, C, RL>;       // RL > 0: last RL rows of every lane's tile live in LDS
-    __shared__ __align__(16) T wlds[Split::lds_elems(MAXTHREADS)];
     constexpr int NQ = (C + 3) / 4;              // 16-B reads per lane per stimulus
     static_assert(RA <= 8, "a row group has 8 lanes to finish its rows");
     using V4 = T __attribute__((ext_vector_type(4)));
-    __shared__ __align__(16) T rbuf[2][NB][8 * CP];
-    // per slot and stimulus one 32-bit word: low half = "some row has not converged", high half = "some row hit
-    // the rate bound"; written with 16-bit stores (no race between the two kinds), read and cleared as one word
-    __shared__ int flags[3][NB];
-
     const int M = a.M, N = a.N;
     const int ngroups = (a.NB + NB - 1) / NB;
     const int b = blockIdx.x / ngroups;
     const int s0 = (blockIdx.x % ngroups) * NB;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cg = lane & 7, rg = lane >> 3;
-    const int rowbase = (8 * wave + rg) * RA;
+    const int lane = threadIdx.x & 63;
+    const int cg = lane & 7;
     const int colbase = cg * C;
 
     // ---- prologue: my RA x C tile of W -> registers (and LDS for the last RL rows) -----------------
-    if constexpr (RL > 0) set_rank_priority((blockIdx.x >> 8) % 3);
-    T w[RL == 0 ? RA : 1][RL == 0 ? C : 1];     // all-register shape
-    SplitTile<T, RA, C, RL> sw;                 // split shape (RL > 0)
-    if constexpr (RL > 0) sw.template load<false>(a.W + (size_t)b * M * M, M, rowbase, colbase, wlds, threadIdx.x);
+    constexpr bool SPLIT = RL > 0 || PK;        // SplitTile: packed row pairs in VGPRs (+ RL rows in LDS)
+    T w[!SPLIT ? RA : 1][!SPLIT ? C : 1];       // plain all-register shape
+    SplitTile<T, RA, C, RL> sw;
+    if constexpr (SPLIT) sw.template load<false>(a.W + (size_t)b * M * M, M, rowbase, colbase, wlds, threadIdx.x);
     else tile_load<T, RA, C, false>(a.W + (size_t)b * M * M, M, rowbase, colbase, w);
     // the row this lane finishes each step (a = cg), its LDS slot, input and state
     const int myrow = rowbase + cg;
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
         for (int s = 0; s < NB; ++s)
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[s][r] = (T)0;
-        if constexpr (RL > 0) {
+        if constexpr (SPLIT) {
             sw.template matvec<NB>(wlds, threadIdx.x, &rbuf[cur][0][0], cg, acc);
         } else {
 #pragma unroll
@@ -214,6 +215,37 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     }
 }
 
+template <typename T, int RA, int C, int RL, int NB, int MAXTHREADS, int MINWAVES>
+__global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveArgs<T> a) {
+    constexpr int CP = SlabPad<C>::value;
+    using Split = TileSplit<RA, C, RL>;       // RL > 0: last RL rows of every lane's tile live in LDS
+    __shared__ __align__(16) T wlds[Split::lds_elems(MAXTHREADS)];
+    __shared__ __align__(16) T rbuf[2][NB][8 * CP];
+    // per slot and stimulus one 32-bit word: low half = "some row has not converged", high half = "some row hit
+    // the rate bound"; written with 16-bit stores (no race between the two kinds), read and cleared as one word
+    __shared__ int flags[3][NB];
+    if constexpr (RL > 0) set_rank_priority((blockIdx.x >> 8) % 3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    tile_wave_body<T, RA, C, RL, NB, false>(a, wlds, rbuf, flags, (8 * wave + (lane >> 3)) * RA);
+}
+
+// 2N = 170..200 in the split shape: waves 0-2 own 56 rows each (7 per lane, 2 of them in LDS); what is left for wave 3 is
+// at most 32 rows, i.e. 4 per lane -- it runs a 4-row tile, all in VGPRs as two packed pairs: 50 packed FMAs per step
+// instead of 100 instructions on mostly padded rows, no LDS-resident rows to re-read.  Same barriers, same stop
+// protocol, same results.
+template <typename T, int C, int NB, int MINWAVES>
+__global__ void __launch_bounds__(256, MINWAVES) solve_tile_mixed_kernel(SolveArgs<T> a) {
+    constexpr int CP = SlabPad<C>::value;
+    using Split = TileSplit<7, C, 2>;
+    __shared__ __align__(16) T wlds[Split::lds_elems(192)];          // waves 0-2 only
+    __shared__ __align__(16) T rbuf[2][NB][8 * CP];
+    __shared__ int flags[3][NB];
+    set_rank_priority((blockIdx.x >> 8) % 3);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 3) tile_wave_body<T, 7, C, 2, NB, false>(a, wlds, rbuf, flags, (8 * wave + (lane >> 3)) * 7);
+    else tile_wave_body<T, 4, C, 0, NB, true>(a, wlds, rbuf, flags, 168 + (lane >> 3) * 4);
+}
+
 // ---------------------------------------------------------------------------------
 // dispatch: C = columns per column group (8*C >= M), RA = 7 rows per lane, waves = ceil(M / 56) <= 4.
 // Shapes (fp32): "split" = RL rows of every lane's tile in LDS so that the kernel fits 168 VGPRs and
@@ -249,7 +281,14 @@ static hipError_t launch_tile_k(const SolveArgs<T>& a, hipStream_t st) {
 template <typename T, int C>
 static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st, bool split) {
     if constexpr (sizeof(T) == 4) {
-        if constexpr (C == 25) { if (split) return launch_tile_k<T, TILE_RA, C, 2, 1, 3>(a, st); }   // (C = 26 spills in the loop)
+        if constexpr (C == 25) {                                                      // (C = 26 spills in the loop)
+            if (SSN_TILE_MIXED && split && a.M > 168) {            // four waves: the last one holds <= 32 rows -> lighter tile for it
+                const int ngroups = a.NB;
+                hipLaunchKernelGGL((solve_tile_mixed_kernel<T, C, 1, 3>), dim3(a.B * ngroups), dim3(256), 0, st, a);
+                return hipGetLastError();
+            }
+            if (split) return launch_tile_k<T, TILE_RA, C, 2, 1, 3>(a, st);
+        }
         if constexpr (C == 19) { if (split) return launch_tile_k<T, TILE_RA, C, 1, 1, 3>(a, st); }
         // 7*C W registers + 8*NB accumulators + 4*NB states must stay under 256 VGPRs (no spills)
         if constexpr (C <= 19) { if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 0, 4, 2>(a, st); }
