@@ -166,7 +166,7 @@ __device__ __forceinline__ void tile_wave_body(const SolveArgs<T>& a, T* wlds, T
         const int slot = step % 3;
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
-            const T u = (SSN_ABLATE & 2) ? acc[s][0] : reduce8_to_lane(acc[s], cg);
+            const T u = (SSN_ABLATE & 2) ? acc[s][0] : reduce_rows_to_lane<RA>(acc[s], cg);
             // ---- Euler update + stop tests for my row ---------------------------------
             const T fu = (SSN_ABLATE & 1) ? (u + ex[s]) : io_eval(u + ex[s], a.io);
             const T r1 = rc[s] + (-rc[s] + fu) * eps;

@@ -17,6 +17,9 @@
 #ifndef SSN_PK_ASM
 #define SSN_PK_ASM 1
 #endif
+#ifndef SSN_REDUCE4
+#define SSN_REDUCE4 1            // diagnostic: 0 = 8-row transpose-reduce also for tiles of <= 4 rows
+#endif
 
 namespace ssn {
 
@@ -116,6 +119,29 @@ __device__ __forceinline__ float reduce8_to_lane<float>(const float (&acc)[8], i
     return keep + dpp_get_f<0xB1>(send);                // quad_perm:[1,0,3,2]: lane i <-> i^1
 }
 #endif
+
+// Tiles of at most 4 rows (acc[4..7] == 0): the first exchange only has to fold the two halves of the lane group
+// together -- four DPP adds, no second masked add, no zero inputs to materialise; lanes 0-3 end with rows 0-3.
+template <int ROWS, typename T>
+__device__ __forceinline__ T reduce_rows_to_lane(const T (&acc)[8], int cg) {
+    if constexpr (ROWS > 4 || sizeof(T) != 4 || !SSN_REDUCE4) {
+        return reduce8_to_lane(acc, cg);
+    } else {
+        const bool bB = cg & 2, bC = cg & 1;
+        T n4[4], n2[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) n4[k] = acc[k] + dpp_get_f<0x141>(acc[k]);      // row_half_mirror: lane i <-> 7-i
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const T keep = bB ? n4[k + 2] : n4[k];
+            const T send = bB ? n4[k] : n4[k + 2];
+            n2[k] = keep + dpp_get_f<0x4E>(send);           // quad_perm:[2,3,0,1]: lane i <-> i^2
+        }
+        const T keep = bC ? n2[1] : n2[0];
+        const T send = bC ? n2[0] : n2[1];
+        return keep + dpp_get_f<0xB1>(send);                // quad_perm:[1,0,3,2]: lane i <-> i^1
+    }
+}
 
 template <int C> struct SlabPad {
     // floats per column-group slab in LDS: multiple of 4 (16-B reads) with an ODD number of
