@@ -71,3 +71,14 @@ def test_gpus_mismatch_is_refused():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and '{' not in r.stdout
+
+
+def test_c1_dropin_line():
+    """BASELINE config 1 through the zero-change drop-in symbols, timed like the reference calls them (thread pool, one
+    ctypes call per solve, host buffers) with the reference's own C beside it."""
+    d = _bench('--workload', 'c1', '--via', 'dropin', '--steps', '1', '--cpu-sample', '64')
+    assert d['metric'] == 'SSN-steps/sec' and d['dtype'] == 'f64' and d['roofline'] is None
+    assert 'drop-in' in d['config']['workload'] and d['config']['calls'] == 64
+    assert d['value'] > 0 and d['config']['us_per_call_single_thread'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and abs(c['gpu_over_cpu'] - d['value'] / c['value']) < 1e-9
