@@ -106,7 +106,10 @@ def cpu_baseline(N, NB, T, sample_B, threads):
             return lib.oracle_solve_euler(2, N_, W, ext, k, n, r0, r1, tE, tI, dt, T_, atol, soft, hard, None)
     best = time_threaded_solves(fn, Ws, exts, N, T, threads)
     units = float(M) * sample_B * NB * T
+    n1 = max(2, min(sample_B, 16))                      # the same call pattern on ONE thread, a few draws
+    best1 = time_threaded_solves(fn, Ws[:n1], exts, N, T, 1)
     return dict(value=units / best, unit='neuron*batch*Euler-steps/s', cores=threads, kind=kind,
+                value_1thread=float(M) * n1 * NB * T / best1,
                 sample='%d of the workload\'s weight draws x %d stimuli x %d steps, 2N=%d, fp64, '
                        '%d Python threads over ctypes (best of 2 after warm-up, %.2f s)' %
                        (sample_B, NB, T, M, threads, best))
