@@ -229,21 +229,21 @@ __global__ void __launch_bounds__(MAXTHREADS, MINWAVES) solve_tile_kernel(SolveA
     tile_wave_body<T, RA, C, RL, NB, false>(a, wlds, rbuf, flags, (8 * wave + (lane >> 3)) * RA);
 }
 
-// 2N = 170..200 in the split shape: waves 0-2 own 56 rows each (7 per lane, 2 of them in LDS); what is left for wave 3 is
-// at most 32 rows, i.e. 4 per lane -- it runs a 4-row tile, all in VGPRs as two packed pairs: 50 packed FMAs per step
-// instead of 100 instructions on mostly padded rows, no LDS-resident rows to re-read.  Same barriers, same stop
-// protocol, same results.
-template <typename T, int C, int NB, int MINWAVES>
-__global__ void __launch_bounds__(256, MINWAVES) solve_tile_mixed_kernel(SolveArgs<T> a) {
+// Split shapes whose LAST wave is left with at most 40 rows (2N = 170..200 at C = 25: waves 0-2 own 56 rows each, 32 remain;
+// 2N = 114..152 at C = 19: 40 remain): that wave runs an LRA-row tile (LRA = 4 or 5), all in VGPRs as packed row pairs --
+// 50 (or 57) FMA instructions per step instead of 100 (76) on a 7-row tile that is mostly padding, and no LDS-resident
+// rows to re-read.  Same barriers, same stop protocol, same results.
+template <typename T, int C, int RL, int NW, int LRA, int NB, int MINWAVES>
+__global__ void __launch_bounds__(64 * NW, MINWAVES) solve_tile_mixed_kernel(SolveArgs<T> a) {
     constexpr int CP = SlabPad<C>::value;
-    using Split = TileSplit<7, C, 2>;
-    __shared__ __align__(16) T wlds[Split::lds_elems(192)];          // waves 0-2 only
+    using Split = TileSplit<7, C, RL>;
+    __shared__ __align__(16) T wlds[Split::lds_elems(64 * (NW - 1))];      // heavy waves only
     __shared__ __align__(16) T rbuf[2][NB][8 * CP];
     __shared__ int flags[3][NB];
     set_rank_priority((blockIdx.x >> 8) % 3);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave < 3) tile_wave_body<T, 7, C, 2, NB, false>(a, wlds, rbuf, flags, (8 * wave + (lane >> 3)) * 7);
-    else tile_wave_body<T, 4, C, 0, NB, true>(a, wlds, rbuf, flags, 168 + (lane >> 3) * 4);
+    if (wave < NW - 1) tile_wave_body<T, 7, C, RL, NB, false>(a, wlds, rbuf, flags, (8 * wave + (lane >> 3)) * 7);
+    else tile_wave_body<T, LRA, C, 0, NB, true>(a, wlds, rbuf, flags, 56 * (NW - 1) + (lane >> 3) * LRA);
 }
 
 // ---------------------------------------------------------------------------------
@@ -281,15 +281,23 @@ static hipError_t launch_tile_k(const SolveArgs<T>& a, hipStream_t st) {
 template <typename T, int C>
 static hipError_t launch_tile_nb(const SolveArgs<T>& a, hipStream_t st, bool split) {
     if constexpr (sizeof(T) == 4) {
+        // split shapes; when the last wave is left with <= 40 rows it gets a lighter tile (mixed kernel)
+        const int waves = (a.M + 55) / 56, last_rows = a.M - 56 * (waves - 1);
         if constexpr (C == 25) {                                                      // (C = 26 spills in the loop)
-            if (SSN_TILE_MIXED && split && a.M > 168) {            // four waves: the last one holds <= 32 rows -> lighter tile for it
-                const int ngroups = a.NB;
-                hipLaunchKernelGGL((solve_tile_mixed_kernel<T, C, 1, 3>), dim3(a.B * ngroups), dim3(256), 0, st, a);
+            if (SSN_TILE_MIXED && split && waves == 4 && last_rows <= 32) {
+                hipLaunchKernelGGL((solve_tile_mixed_kernel<T, C, 2, 4, 4, 1, 3>), dim3(a.B * a.NB), dim3(256), 0, st, a);
                 return hipGetLastError();
             }
             if (split) return launch_tile_k<T, TILE_RA, C, 2, 1, 3>(a, st);
         }
-        if constexpr (C == 19) { if (split) return launch_tile_k<T, TILE_RA, C, 1, 1, 3>(a, st); }
+        if constexpr (C == 19) {
+            if (SSN_TILE_MIXED && split && waves == 3 && last_rows <= 40) {
+                if (last_rows <= 32) hipLaunchKernelGGL((solve_tile_mixed_kernel<T, C, 1, 3, 4, 1, 3>), dim3(a.B * a.NB), dim3(192), 0, st, a);
+                else hipLaunchKernelGGL((solve_tile_mixed_kernel<T, C, 1, 3, 5, 1, 3>), dim3(a.B * a.NB), dim3(192), 0, st, a);
+                return hipGetLastError();
+            }
+            if (split) return launch_tile_k<T, TILE_RA, C, 1, 1, 3>(a, st);
+        }
         // 7*C W registers + 8*NB accumulators + 4*NB states must stay under 256 VGPRs (no spills)
         if constexpr (C <= 19) { if (a.NB >= 4) return launch_tile_k<T, TILE_RA, C, 0, 4, 2>(a, st); }
         if (a.NB >= 2) return launch_tile_k<T, TILE_RA, C, 0, 2, 2>(a, st);

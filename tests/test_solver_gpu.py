@@ -190,6 +190,9 @@ def test_test_inf_message():
     # default N = 102: the truth-data path of every CLI run)
     (102, 1, 2, 'float64'), (102, 8, 2, 'float64'), (100, 3, 2, 'float64'), (76, 2, 2, 'float64'), (60, 1, 2, 'float64'),
     (104, 1, 2, 'float64'),
+    # mixed kernels: lighter tile for the last wave (2N = 114..152 at C = 19: 4- and 5-row tiles; 2N = 170..200 at C = 25)
+    (58, 1, 3, 'float32'), (64, 2, 3, 'float32'), (72, 1, 3, 'float32'), (73, 3, 3, 'float32'), (86, 1, 3, 'float32'),
+    (92, 2, 3, 'float32'), (99, 1, 3, 'float32'),
 ])
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
