@@ -352,6 +352,15 @@ int ssn_io_eval_f64(const double *v, double *out, long count, const ssn_solver_p
 int ssn_lu_solve_f32(float *A, float *rhs, int *info, int nsys, int M, int nrhs, void *stream);
 int ssn_lu_solve_f64(double *A, double *rhs, int *info, int nsys, int M, int nrhs, void *stream);
 
+/* The two scalar penalties of the fixed-time generator from the per-neuron window sums ssn_gen_forward_* leaves
+ * (networks/ssn.py:626, 632): out[0] = scale_dyn * sum(dyn_row), out[1] = scale_rate * sum(rate_row), fp64, one launch,
+ * deterministic.  ws: device scratch of 2 * 256 + 1 doubles whose LAST 8 bytes are zero before the first call (the
+ * kernel leaves them zero); out: device [2]. */
+int ssn_penalty_means_f32(const float *dyn_row, const float *rate_row, long n, double scale_dyn, double scale_rate,
+                          double *ws, double *out, void *stream);
+int ssn_penalty_means_f64(const double *dyn_row, const double *rate_row, long n, double scale_dyn, double scale_rate,
+                          double *ws, double *out, void *stream);
+
 /* Device-side noise for the generator's z (replaces the host `rng.rand(batch, 2N, 2N)` of
  * tc_gan/networks/ssn.py:434-439 in the opt-in performance mode; the reference has no such mode, parity runs keep
  * host noise).  out[i] = u(seed, offset + i) in [0, 1) with 24 random bits, from Philox4x32-10 (Salmon, Moraes,

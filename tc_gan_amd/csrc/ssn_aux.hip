@@ -261,4 +261,53 @@ hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long off
 template hipError_t launch_philox_uniform<float>(unsigned long long, unsigned long long, float*, unsigned long long, hipStream_t);
 template hipError_t launch_philox_uniform<double>(unsigned long long, unsigned long long, double*, unsigned long long, hipStream_t);
 
+// ---------------------------------------------------------------------------------
+// The two penalty means of the fixed-time generator (networks/ssn.py:626, 632): out[0] = scale_dyn * sum(dyn_row),
+// out[1] = scale_rate * sum(rate_row), fp64, in ONE launch: every workgroup writes its fp64 partial sums to `ws`,
+// takes a ticket, and the workgroup that draws the last ticket adds the partials in workgroup order (deterministic)
+// and resets the ticket.  ws: [2 * PEN_BLOCKS] doubles + the ticket (one int, zero before the first launch).
+// ---------------------------------------------------------------------------------
+constexpr int PEN_BLOCKS = 256;
+template <typename T>
+__global__ void __launch_bounds__(256) penalty_means_kernel(const T* __restrict__ dyn, const T* __restrict__ rate, long n,
+                                                            double scale_dyn, double scale_rate, double* __restrict__ ws,
+                                                            double* __restrict__ out) {
+    __shared__ double red[2][256];
+    __shared__ int last;
+    double s0 = 0.0, s1 = 0.0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256L) { s0 += (double)dyn[e]; s1 += (double)rate[e]; }
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    int* ticket = reinterpret_cast<int*>(ws + 2 * PEN_BLOCKS);
+    if (threadIdx.x == 0) {
+        ws[2 * blockIdx.x] = red[0][0]; ws[2 * blockIdx.x + 1] = red[1][0];
+        __threadfence();                                           // partials visible before the ticket
+        last = (atomicAdd(ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();                                               // acquire: see every workgroup's partials
+    if (threadIdx.x == 0) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int b = 0; b < (int)gridDim.x; ++b) { t0 += ws[2 * b]; t1 += ws[2 * b + 1]; }
+        out[0] = t0 * scale_dyn; out[1] = t1 * scale_rate;
+        *ticket = 0;
+    }
+}
+template <typename T>
+hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws,
+                                double* out, hipStream_t st) {
+    long blocks = (n + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > PEN_BLOCKS) blocks = PEN_BLOCKS;
+    hipLaunchKernelGGL((penalty_means_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, dyn, rate, n, scale_dyn, scale_rate, ws, out);
+    return hipGetLastError();
+}
+template hipError_t launch_penalty_means<float>(const float*, const float*, long, double, double, double*, double*, hipStream_t);
+template hipError_t launch_penalty_means<double>(const double*, const double*, long, double, double, double*, double*, hipStream_t);
+
 }  // namespace ssn

@@ -843,6 +843,16 @@ int ssn_stimulus_amp_f64(const double* bw, const double* con, double smoothness,
     SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_penalty_means_f32(const float* dyn, const float* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, void* stream) {
+    if (n < 0 || !ws || !out || (n > 0 && (!dyn || !rate))) { g_last_error = "ssn_penalty_means: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_penalty_means<float>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream));
+    return 0;
+}
+int ssn_penalty_means_f64(const double* dyn, const double* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, void* stream) {
+    if (n < 0 || !ws || !out || (n > 0 && (!dyn || !rate))) { g_last_error = "ssn_penalty_means: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_penalty_means<double>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream));
+    return 0;
+}
 int ssn_philox_uniform_f32(unsigned long long seed, unsigned long long offset, float* out, unsigned long long n, void* stream) {
     if (n > 0 && !out) { g_last_error = "ssn_philox_uniform: null output"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::launch_philox_uniform<float>(seed, offset, out, n, (hipStream_t)stream));

@@ -32,6 +32,18 @@ def make_gen_params(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=
                           rate_penalty_threshold=float(rate_penalty_threshold))
 
 
+_PEN_SCRATCH = {}
+
+
+def _penalty_scratch(device):
+    """Per (device, stream) scratch of ssn_penalty_means_* (partials + ticket; zeroed once, the kernel keeps the ticket zero)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _PEN_SCRATCH.get(key)
+    if ws is None:
+        ws = _PEN_SCRATCH[key] = torch.zeros(2 * 256 + 1, device=device, dtype=torch.float64)
+    return ws
+
+
 def gen_forward(W, ext, gp, save=False):
     """W (B, M, M), ext (B, NB, M) CUDA tensors -> dict(time_avg, dynamics_penalty, rate_penalty[, traj, df]).
 
@@ -55,10 +67,13 @@ def gen_forward(W, ext, gp, save=False):
     clib.check(rc, 'ssn_gen_forward_' + suffix)
     n_dyn = B * (T - skip - 1) * NB * M
     n_rate = B * (T - skip) * NB * M
-    out = dict(time_avg=ta,
-               dynamics_penalty=(dyn.sum(dtype=torch.float64) / n_dyn) if n_dyn > 0 else dyn.sum() * float('nan'),
-               rate_penalty=rate.sum(dtype=torch.float64) / n_rate,
-               n_dyn=n_dyn, n_rate=n_rate)
+    # both penalty means in one launch (fp64 sums in a fixed order), instead of two reductions and two scalings
+    pens = torch.empty(2, device=W.device, dtype=torch.float64)
+    rc = getattr(libssnode, 'ssn_penalty_means_' + suffix)(
+        dyn.data_ptr(), rate.data_ptr(), dyn.numel(), (1.0 / n_dyn) if n_dyn > 0 else float('nan'), 1.0 / n_rate,
+        _penalty_scratch(W.device).data_ptr(), pens.data_ptr(), _stream())
+    clib.check(rc, 'ssn_penalty_means_' + suffix)
+    out = dict(time_avg=ta, dynamics_penalty=pens[0], rate_penalty=pens[1], n_dyn=n_dyn, n_rate=n_rate)
     if save:
         out.update(traj=traj, df=df)
     return out
