@@ -208,19 +208,33 @@ class TuningCurveGenerator(object):
         return noise
 
     # -- forward ------------------------------------------------------------------------------
-    def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs, model_zs_in=None):
-        bw = np.asarray(stimulator_bandwidths) if not torch.is_tensor(stimulator_bandwidths) else stimulator_bandwidths
-        con = np.asarray(stimulator_contrasts) if not torch.is_tensor(stimulator_contrasts) else stimulator_contrasts
+    def _cached_upload(self, slot, host, dtype):
+        """Device copy of a small host array, re-uploaded only when its contents change (the stimulus grid of a run is the
+        same at every step when there is one contrast; the input-variability vector changes once per generator step)."""
+        cache = self.__dict__.setdefault('_upload_cache', {})
+        hit = cache.get(slot)
+        if hit is not None and hit[0].shape == host.shape and hit[0].dtype == host.dtype and np.array_equal(hit[0], host):
+            return hit[1]
+        dev = to_device(host, dtype)
+        cache[slot] = (np.array(host, copy=True), dev)
+        return dev
+
+    def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs, model_zs_in=None, save=True):
+        bw = stimulator_bandwidths if torch.is_tensor(stimulator_bandwidths) else \
+            self._cached_upload('bw', np.asarray(stimulator_bandwidths), self.tdtype)
+        con = stimulator_contrasts if torch.is_tensor(stimulator_contrasts) else \
+            self._cached_upload('con', np.asarray(stimulator_contrasts), self.tdtype)
         amp = None
         self._zin = None
         if self.heteroin:
             zin = to_device(model_zs_in, self.tdtype)                     # (pinned staging: no wait for queued kernels)
-            vs = to_device(np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'), self.tdtype)
+            vs = self._cached_upload('vs', np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'), self.tdtype)
             amp = 1 + vs[None, :] * zin                                   # ssn.py:679-684
             self._zin = zin
         ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)
+        # the un-amplified stimulus is only needed by the V gradient of a BPTT step
         self._ext_base = (stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
-                          if self.heteroin else None)
+                          if self.heteroin and save else None)
         if torch.is_tensor(model_zs):
             z = model_zs.to('cuda', self.tdtype).contiguous()
         else:
@@ -233,8 +247,8 @@ class TuningCurveGenerator(object):
             probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
                                                        self.num_sites, type='uint16').astype(np.int64) \
                 + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
-            ids = to_device(np.asarray(prober_model_ids).astype(np.int64))
-            pr = to_device(probes)
+            ids = self._cached_upload('ids', np.asarray(prober_model_ids).astype(np.int64), None)
+            pr = self._cached_upload('probes', probes, None)
             return time_avg[ids, :, pr], ids, pr                                       # cwgan.py:98
         if getattr(self, '_probes_dev', None) is None or self._probes_dev[0] is not self.probes:
             self._probes_dev = (self.probes, to_device(np.asarray(self.probes)))
@@ -251,7 +265,7 @@ class TuningCurveGenerator(object):
                 kwargs.update(self.gen_noise(rng, **kwargs))
         theta = kwargs.pop('model_rate_penalty_threshold', 200.0)
         ext, z, W = self._device_inputs(kwargs.pop('stimulator_bandwidths'), kwargs.pop('stimulator_contrasts'),
-                                        kwargs.pop('model_zs'), kwargs.pop('model_zs_in', None))
+                                        kwargs.pop('model_zs'), kwargs.pop('model_zs_in', None), save=save)
         probe_kw = {k: kwargs.pop(k) for k in list(kwargs) if k.startswith('prober_')}
         assert not kwargs, 'unknown inputs: {}'.format(sorted(kwargs))
         gp = self.gen_params(theta)
