@@ -369,6 +369,13 @@ int ssn_penalty_means_f64(const double *dyn_row, const double *rate_row, long n,
  * ranks of a data-parallel job each fill their own rows of ONE global stream.  `out` is a device pointer. */
 int ssn_philox_uniform_f32(unsigned long long seed, unsigned long long offset, float *out, unsigned long long n, void *stream);
 int ssn_philox_uniform_f64(unsigned long long seed, unsigned long long offset, double *out, unsigned long long n, void *stream);
+/* The heterogeneous-input SSN's noise from the same stream, in one launch (networks/ssn.py:679-720): zin[i] = +1 / -1
+ * (u < 0.5; bernoulli != 0) or 2 u - 1, and amp[i] = 1 + v[i % M] * zin[i] (v: device [M], the input variability per
+ * neuron); zin, amp: device [n]. */
+int ssn_philox_amp_f32(unsigned long long seed, unsigned long long offset, const float *v, float *zin, float *amp,
+                       unsigned long long n, int M, int bernoulli, void *stream);
+int ssn_philox_amp_f64(unsigned long long seed, unsigned long long offset, const double *v, double *zin, double *amp,
+                       unsigned long long n, int M, int bernoulli, void *stream);
 
 #ifdef __cplusplus
 }

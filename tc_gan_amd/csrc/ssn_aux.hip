@@ -258,6 +258,42 @@ hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long off
     hipLaunchKernelGGL((philox_uniform_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, seed, offset, out, n);
     return hipGetLastError();
 }
+// The heterogeneous-input SSN's per-neuron input variability in one launch (networks/ssn.py:679-720): element i of the
+// draw gets z = +1 / -1 (u < 0.5, `dist_in = 'bernoulli'`) or 2 u - 1 ('uniform') from the same stream element u as
+// philox_uniform_kernel would give it, and amp = 1 + v[i % M] * z (v = the population's input variability per neuron).
+template <typename T>
+__global__ void __launch_bounds__(256) philox_amp_kernel(unsigned long long seed, unsigned long long offset, const T* __restrict__ v,
+                                                         T* __restrict__ zin, T* __restrict__ amp, unsigned long long n, int M,
+                                                         int bernoulli) {
+    const unsigned long long first_blk = offset >> 2, last_blk = (offset + n + 3) >> 2;
+    for (unsigned long long blk = first_blk + blockIdx.x * 256ull + threadIdx.x; blk < last_blk; blk += gridDim.x * 256ull) {
+        unsigned w[4];
+        philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned long long g = 4 * blk + j;
+            if (g >= offset && g < offset + n) {
+                const unsigned long long i = g - offset;
+                const T u = (T)((float)(w[j] >> 8) * (1.0f / 16777216.0f));
+                const T z = bernoulli ? (u < (T)0.5 ? (T)1 : (T)-1) : u * (T)2 - (T)1;
+                zin[i] = z;
+                amp[i] = (T)1 + v[i % (unsigned long long)M] * z;
+            }
+        }
+    }
+}
+template <typename T>
+hipError_t launch_philox_amp(unsigned long long seed, unsigned long long offset, const T* v, T* zin, T* amp,
+                             unsigned long long n, int M, int bernoulli, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    unsigned long long blocks = ((n + 3) / 4 + 1 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((philox_amp_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, seed, offset, v, zin, amp, n, M, bernoulli);
+    return hipGetLastError();
+}
+template hipError_t launch_philox_amp<float>(unsigned long long, unsigned long long, const float*, float*, float*, unsigned long long, int, int, hipStream_t);
+template hipError_t launch_philox_amp<double>(unsigned long long, unsigned long long, const double*, double*, double*, unsigned long long, int, int, hipStream_t);
+
 template hipError_t launch_philox_uniform<float>(unsigned long long, unsigned long long, float*, unsigned long long, hipStream_t);
 template hipError_t launch_philox_uniform<double>(unsigned long long, unsigned long long, double*, unsigned long long, hipStream_t);
 

@@ -853,6 +853,16 @@ int ssn_penalty_means_f64(const double* dyn, const double* rate, long n, double 
     SSN_TRY(ssn::launch_penalty_means<double>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream));
     return 0;
 }
+int ssn_philox_amp_f32(unsigned long long seed, unsigned long long offset, const float* v, float* zin, float* amp, unsigned long long n, int M, int bernoulli, void* stream) {
+    if (n > 0 && (!v || !zin || !amp || M <= 0)) { g_last_error = "ssn_philox_amp: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_philox_amp<float>(seed, offset, v, zin, amp, n, M, bernoulli, (hipStream_t)stream));
+    return 0;
+}
+int ssn_philox_amp_f64(unsigned long long seed, unsigned long long offset, const double* v, double* zin, double* amp, unsigned long long n, int M, int bernoulli, void* stream) {
+    if (n > 0 && (!v || !zin || !amp || M <= 0)) { g_last_error = "ssn_philox_amp: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_philox_amp<double>(seed, offset, v, zin, amp, n, M, bernoulli, (hipStream_t)stream));
+    return 0;
+}
 int ssn_philox_uniform_f32(unsigned long long seed, unsigned long long offset, float* out, unsigned long long n, void* stream) {
     if (n > 0 && !out) { g_last_error = "ssn_philox_uniform: null output"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::launch_philox_uniform<float>(seed, offset, out, n, (hipStream_t)stream));

@@ -84,6 +84,20 @@ class DeviceNoise(object):
         self.position += self.world * n
         return out
 
+    def signs_and_amp(self, local_shape, tdtype, v, bernoulli):
+        """The heterogeneous-input noise z (+-1 or 2 u - 1 from the next `uniform` draw of this shape) and 1 + v * z,
+        in one launch (`ssn_philox_amp_*`)."""
+        zin = torch.empty(tuple(local_shape), device='cuda', dtype=tdtype)
+        amp = torch.empty_like(zin)
+        n = zin.numel()
+        assert v.dtype == tdtype and v.numel() == local_shape[-1] and v.is_contiguous()
+        fn = clib.libssnode.ssn_philox_amp_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_amp_f64
+        clib.check(fn(self.seed, self.position + self.rank * n, v.data_ptr(), zin.data_ptr(), amp.data_ptr(), n,
+                      int(local_shape[-1]), int(bool(bernoulli)),
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_philox_amp')
+        self.position += self.world * n
+        return zin, amp
+
     def get_state(self):
         return dict(seed=self.seed, position=self.position)
 
@@ -197,8 +211,10 @@ class TuningCurveGenerator(object):
         if self._zgen is not None:
             noise = dict(model_zs=self._zgen.uniform((num_models, M, M), self.tdtype))
             if self.heteroin:
-                u = self._zgen.uniform((num_models, M), self.tdtype)
-                noise['model_zs_in'] = (u < 0.5).to(self.tdtype) * 2 - 1 if self.dist_in == 'bernoulli' else u * 2 - 1
+                vs = self._input_variability()
+                zin, amp = self._zgen.signs_and_amp((num_models, M), self.tdtype, vs, self.dist_in == 'bernoulli')
+                noise['model_zs_in'] = zin
+                self._amp_of = (zin, vs, amp)          # picked up by _device_inputs when it is handed this very draw
             return noise
         noise = dict(model_zs=rng.rand(num_models, M, M))
         if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720
@@ -219,6 +235,9 @@ class TuningCurveGenerator(object):
         cache[slot] = (np.array(host, copy=True), dev)
         return dev
 
+    def _input_variability(self):
+        return self._cached_upload('vs', np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'), self.tdtype)
+
     def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs, model_zs_in=None, save=True):
         bw = stimulator_bandwidths if torch.is_tensor(stimulator_bandwidths) else \
             self._cached_upload('bw', np.asarray(stimulator_bandwidths), self.tdtype)
@@ -227,9 +246,13 @@ class TuningCurveGenerator(object):
         amp = None
         self._zin = None
         if self.heteroin:
-            zin = to_device(model_zs_in, self.tdtype)                     # (pinned staging: no wait for queued kernels)
-            vs = self._cached_upload('vs', np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'), self.tdtype)
-            amp = 1 + vs[None, :] * zin                                   # ssn.py:679-684
+            vs = self._input_variability()
+            made = self.__dict__.get('_amp_of')
+            if made is not None and made[0] is model_zs_in and made[1] is vs:
+                zin, amp = model_zs_in, made[2]                           # device noise: amp came with the draw
+            else:
+                zin = to_device(model_zs_in, self.tdtype)                 # (pinned staging: no wait for queued kernels)
+                amp = 1 + vs[None, :] * zin                               # ssn.py:679-684
             self._zin = zin
         ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)
         # the un-amplified stimulus is only needed by the V gradient of a BPTT step
