@@ -158,6 +158,29 @@ def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iter
     return gan, (N, models, NB, T, skip), bandwidths
 
 
+def _forward_roofline(variant, achieved, traffic, kernel_ms, M, steps_in_loop):
+    """Roofline object of the generator forward.  `achieved` is ALGORITHMIC: (2 M + 8) flop per neuron-step.
+    fp32 MFMA kernel (v_mfma_f32_4x4x1): peak = fp32 matrix peak = fp32 vector peak = 157.3 TFLOP/s.
+    fp16-split kernel (v_mfma_f32_16x16x32_f16): priced against the fp16 dense peak, 16x that; the kernel EXECUTES
+    8 fp16 flops per algorithmic flop (W as 2 fp16 parts x 4 operand columns per stimulus: 3 state parts + 1 unused)
+    on tiles padded from M x M to 16 ceil(M / 16) x 32 ceil(M / 32)."""
+    groups = {2: 'two 4-stimulus groups per workgroup', 3: 'one 4-stimulus group per workgroup'}
+    if variant in (4, 5):
+        peak = 16 * PEAK_FP32_VALU_TFLOPS
+        pad = (16 * -(-M // 16)) * (32 * -(-M // 32)) / float(M * M)
+        executed = achieved * (2 * M) / (2 * M + 8) * 8 * pad
+        return {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                'traffic': traffic, 'kernel': 'gen_forward_split_kernel (fp16-split MFMA, %s)' % groups[variant - 2],
+                'mfma_dtype': 'f16 (W = 2 parts, state = 3 parts, exact products, fp32 accumulate)',
+                'executed_mfma_tflops': executed, 'executed_frac': executed / peak,
+                'frac_of_fp32_peak': achieved / PEAK_FP32_VALU_TFLOPS,
+                'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8, 'ssn_steps_per_s_in_loop': steps_in_loop}
+    return {'bound': 'mfma' if variant in (2, 3) else 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
+            'kernel': 'gen_forward_mfma_kernel (fp32 MFMA, %s)' % groups[variant] if variant in (2, 3) else 'gen_forward_kernel',
+            'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8, 'ssn_steps_per_s_in_loop': steps_in_loop}
+
+
 def run_c3(args, rank, world, local_rank, paper=False):
     """``paper=True``: the shape of the reference's published run (scripts/fig4/gan/run.json): 2N=202, 128 models,
     seqlen 240 / skip 200, tau_E=2, deg-heteroin SSN, 4x128 critic with LayerNorm on layers 2-4, rmsprop.
@@ -215,6 +238,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
     units = float(M) * models * NB * T                     # neuron-steps of one generator forward (per rank)
     achieved = units * (2 * M + 8) / (kernel_ms * 1e-3) * 1e-12
     iters_per_s = args.steps / elapsed
+    variant = genops.forward_variant(models, NB, M, gp)
     traffic = None
     tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'hbm_traffic.json')
     if not paper and os.path.exists(tpath):
@@ -222,7 +246,8 @@ def run_c3(args, rank, world, local_rank, paper=False):
     out = {
         'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '%d-model GAN iterations/s' % models,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (critic GEMMs bf16)',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32 (critic GEMMs bf16%s)' % ('; generator forward W.r on fp16 matrix cores as an exact-product split, W 22 bits' if variant in (4, 5) else ''),
         'data': 'synthetic',
         'config': {'workload': ('C3 paper shape (scripts/fig4/gan/run.json): 2N=202, 128 models x 8 bandwidths per GPU, '
                                 'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
@@ -230,13 +255,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
                                'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
                                '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
                                'device-side z (Philox)', 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
-        # fp32-input MFMA (v_mfma_f32_4x4x1) peak = fp32 vector peak = 157.3 TFLOP/s (MI355X_MICROARCH.md)
-        'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
-                     'kernel': 'gen_forward_mfma_kernel (fp32 MFMA)' if not paper else
-                               'gen_forward_mfma_kernel (fp32 MFMA, one 4-stimulus group per workgroup)',
-                     'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8,
-                     'ssn_steps_per_s_in_loop': 7 * units * iters_per_s * world},
+        'roofline': _forward_roofline(variant, achieved, traffic, kernel_ms, M, 7 * units * iters_per_s * world),
         'last_gen_loss': info.gen_loss,
     }
     out['world_size'] = world

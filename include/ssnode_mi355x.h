@@ -167,8 +167,12 @@ typedef struct ssn_gen_params {
     int io_type;                 /* SSN_IO_* */
     int seqlen;                  /* T: Euler steps from r = 0 */
     int skip_steps;              /* first output index of the measurement window */
-    int kernel;                  /* 0 library default, 1 VALU tile kernels, 2 MFMA kernels (fp32, NB >= 4), 3 MFMA
-                                  * kernels with one 4-stimulus group per workgroup (few draws: more workgroups) */
+    int kernel;                  /* 0 library default, 1 VALU tile kernels, 2 fp32 MFMA kernels (fp32, NB >= 4), 3 the
+                                  * same with one 4-stimulus group per workgroup (few draws: more workgroups), 4 / 5
+                                  * forward: fp16-split MFMA kernel (W carried as two fp16 parts = 22 significant bits,
+                                  * the state as three = exact, every product exact, fp32 accumulation; asym_tanh only)
+                                  * with two / one group per workgroup, backward: as 2 / 3.  The default picks 4 / 5
+                                  * where they apply unless SSN_FWD_SPLIT=0 is set in the environment. */
     double k, n;
     double tau_E, tau_I, dt;     /* eps = dt / tau per neuron */
     double rate_soft_bound, rate_hard_bound;
@@ -177,6 +181,10 @@ typedef struct ssn_gen_params {
 
 /* 1 if the register-stationary generator kernels cover this size (2N <= 208 fp32, <= 104 fp64). */
 int ssn_gen_supported(int M, int dtype_bytes);
+/* Which fp32 forward kernel ssn_gen_forward_f32 runs for this call shape and p->kernel (the numbering of p->kernel:
+ * 1 VALU tile / streaming kernels, 2 / 3 fp32 MFMA, 4 / 5 fp16-split MFMA); save != 0: with trajectory stores;
+ * -1: the call would be refused.  For benchmarks and tests that must name the kernel they measured. */
+int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ssn_gen_params *p);
 
 /*
  * Forward: r_{t+1} = (1-eps) r_t + eps f(W r_t + ext), r_0 = 0, T = seqlen steps.

@@ -145,6 +145,8 @@ class GenParams(Structure):
 _gp = POINTER(GenParams)
 libssnode.ssn_gen_supported.argtypes = [c_int, c_int]
 libssnode.ssn_gen_supported.restype = c_int
+libssnode.ssn_gen_forward_variant.argtypes = [c_int, c_int, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_gen_forward_variant.restype = c_int
 for _name in ('ssn_gen_forward_f32', 'ssn_gen_forward_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p] * 7 + [c_int, c_int, c_int, _gp, c_void_p]
     getattr(libssnode, _name).restype = c_int
@@ -232,7 +234,7 @@ DECLARED_SYMBOLS = (
     'ssn_solve_batch_host_f32', 'ssn_solve_batch_host_f64',
     'ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
     'ssn_io_eval_f32', 'ssn_io_eval_f64',
-    'ssn_gen_supported', 'ssn_gen_forward_f32', 'ssn_gen_forward_f64',
+    'ssn_gen_supported', 'ssn_gen_forward_variant', 'ssn_gen_forward_f32', 'ssn_gen_forward_f64',
     'ssn_gen_backward_f32', 'ssn_gen_backward_f64', 'ssn_jds_grad_f32', 'ssn_jds_grad_f64',
     'ssn_critic_num_params', 'ssn_critic_workspace_floats', 'ssn_critic_forward', 'ssn_critic_loss_grad',
     'ssn_critic_input_grad', 'ssn_optimizer_step',

@@ -404,9 +404,15 @@ ssn::IoConsts<T> gen_io_consts(const ssn_gen_params& g) {
 // (two groups when that already gives >= 192 workgroups, one group when only that fills the chip -- 128 draws x 8
 // stimuli of the paper's runs -- else the tile kernels, which run one workgroup per (draw, stimulus)), 1 tile kernels,
 // 2 MFMA with two groups per workgroup, 3 MFMA with one group per workgroup.
+// SSN_FWD_SPLIT=0 keeps the automatic choice on the fp32 MFMA kernel (A/B timing, and for anyone who wants W carried
+// with all 24 bits)
+static bool forward_split_default() {
+    static const bool on = [] { const char* e = getenv("SSN_FWD_SPLIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static int mfma_groups_for(int kernel, bool mfma_ok, int B, int NB) {
-    if (kernel == 2) return 2;
-    if (kernel == 3) return 1;
+    if (kernel == 2 || kernel == 4) return 2;
+    if (kernel == 3 || kernel == 5) return 1;
     if (kernel != 0 || !mfma_ok) return 0;
     if ((long)B * ((NB + 7) / 8) >= 192) return 2;
     if ((long)B * ((NB + 3) / 4) >= 192) return 1;
@@ -431,13 +437,21 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
     if constexpr (sizeof(T) == 4) {
         // (trajectory stores address one draw's block with 32-bit byte offsets)
         const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (!traj || (long)NB * g->seqlen * M < (1L << 29));
-        if ((g->kernel == 2 || g->kernel == 3) && !mfma_ok) {
-            g_last_error = "ssn_gen_forward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
+        if (g->kernel >= 2 && g->kernel <= 5 && !mfma_ok) {
+            g_last_error = "ssn_gen_forward: the MFMA kernels need fp32, NB >= 4 and 2N <= 208";
+            return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+        }
+        const bool split_ok = mfma_ok && ssn::gen_split_rshift(a) >= 0;
+        if ((g->kernel == 4 || g->kernel == 5) && !split_ok) {
+            g_last_error = "ssn_gen_forward: the fp16-split MFMA kernel needs the saturating I/O function (asym_tanh), "
+                           "rate_hard_bound < 3e4 and dt <= tau";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
         }
         if (const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB)) {
             a.mfma_groups = groups;
-            SSN_TRY(ssn::launch_gen_forward_mfma(a, (hipStream_t)stream));
+            const bool split = g->kernel >= 4 || (g->kernel == 0 && split_ok && forward_split_default());
+            if (split) SSN_TRY(ssn::launch_gen_forward_split(a, (hipStream_t)stream));
+            else SSN_TRY(ssn::launch_gen_forward_mfma(a, (hipStream_t)stream));
             return 0;
         }
     }
@@ -461,7 +475,7 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
     a.c_dyn = (T)c_dyn; a.c_rate = (T)c_rate;
     if constexpr (sizeof(T) == 4) {
         const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (long)NB * g->seqlen * M < (1L << 29);
-        if ((g->kernel == 2 || g->kernel == 3) && !mfma_ok) {
+        if (g->kernel >= 2 && g->kernel <= 5 && !mfma_ok) {
             g_last_error = "ssn_gen_backward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
         }
@@ -706,6 +720,21 @@ int ssn_moment_loss_grad_f32(const float* x, const double* sums, double global_b
     }
     SSN_TRY(ssn::launch_moment_loss_grad(x, sums, global_batch, data_moments, weights, B, D, gx, out, (hipStream_t)stream));
     return 0;
+}
+
+int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ssn_gen_params* g) {
+    if (!g || B <= 0 || NB <= 0 || M <= 0 || (M & 1) || !ssn::gen_supported<float>(M)) return -1;
+    ssn::GenFwdArgs<float> a{};
+    a.B = B; a.NB = NB; a.M = M; a.seqlen = seqlen;
+    a.eps_E = (float)(g->dt / g->tau_E); a.eps_I = (float)(g->dt / g->tau_I);
+    a.io = gen_io_consts<float>(*g);
+    const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (!save || (long)NB * seqlen * M < (1L << 29));
+    const bool split_ok = mfma_ok && ssn::gen_split_rshift(a) >= 0;
+    if ((g->kernel >= 2 && g->kernel <= 5 && !mfma_ok) || (g->kernel >= 4 && !split_ok)) return -1;
+    const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB);
+    if (!groups) return 1;
+    const bool split = g->kernel >= 4 || (g->kernel == 0 && split_ok && forward_split_default());
+    return (split ? 4 : 2) + (groups == 1 ? 1 : 0);
 }
 
 int ssn_gen_supported(int M, int dtype_bytes) {

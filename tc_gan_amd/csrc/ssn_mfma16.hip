@@ -1,0 +1,369 @@
+// Generator forward (fixed-time SSN recurrence, NB >= 4 stimuli per weight draw) with W . r on the fp16 matrix cores
+// as an EXACT-PRODUCT SPLIT: fp32 operands are carried as sums of fp16 numbers, every partial product of two fp16
+// numbers is exact in the fp32 accumulator, and the fp16 MFMA runs at 16x the rate of the fp32 one that
+// ssn_mfma.hip uses (v_mfma_f32_16x16x32_f16: 16 cycles per 16 x 16 x 32 tile per SIMD).
+//
+//   r (the state, fp32 in the serial waves' registers)  =  r_h + r_m + r_l    three fp16 numbers, EXACT
+//       (11 + 11 + 2 significant bits by truncation; below 2^-24 / rscale in absolute value the tail is dropped);
+//   W (stationary, registers of the matrix waves)       =  W_h + W_m          two fp16 numbers, 22 significant bits:
+//       relative representation error <= 2^-22 = 2.4e-7 per element (fp32 itself: 6e-8) -- a third part would need
+//       half as many registers again (273 per lane) and half as many MFMAs again.  That is a fixed perturbation of the
+//       weights four times the fp32 rounding of the W-build itself and below the error of the fp32 power law
+//       k v^n = exp2(n log2 v + log2 k) of the same step (tests/test_generator_gpu.py measures both against fp64).
+//   All parts share one power-of-two scale per operand (W: per draw, from max |W|, found in the prologue; r: from the
+//   rate bound of the saturating I/O function), so the six products land in one accumulator and parts of small elements
+//   that fall below the fp16 range only lose bits that are below 2^-24 of the largest element.
+//
+// B operand = 16 columns = 4 stimuli x [r_h, r_m, r_l, (unused)], so one MFMA with A = W_h and one with A = W_m give all
+// six products of a 16 x 32 tile of W for one group of 4 stimuli; the serial lane of (row quad, stimulus) adds the three
+// part columns.  The two 4-stimulus groups of a draw run half a step apart exactly as in ssn_mfma.hip: in phase p the
+// matrix waves run the chain of (group p & 1, step p >> 1) while the serial waves finish (group (p - 1) & 1,
+// step (p - 1) >> 1): nonlinearity, Euler update, windowed reductions, trajectory stores, split of the new state.
+//
+// Workgroup = 4 matrix waves + 4 serial waves (one of each per SIMD, 256 registers).  The NRT x NKT tiles of the padded
+// W (13 x 7 at 2N = 200) are dealt to the matrix waves in row-major order, 22-23 each, so a row tile is finished by
+// one wave or by two neighbours; the second partial sum of a shared row tile goes to an "extra" slot that the serial
+// lanes of that tile add (all others read a row of zeros).
+//
+// Only the saturating I/O function (asym_tanh, the default of every driver) bounds the rates, hence the choice of the
+// r scale; the other two run the fp32 MFMA kernel.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include "ssn_device.h"
+#include "ssn_host.h"
+#include "ssn_mfma_io.h"
+
+#ifndef SSN_SPLIT_ABLATE
+#define SSN_SPLIT_ABLATE 0      // diagnostic builds: 1 = no serial part, 2 = no chains (wrong results, timing only)
+#endif
+
+namespace ssn {
+
+typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
+typedef unsigned uv2 __attribute__((ext_vector_type(2)));
+
+// a = 14 - floor(log2 max |W|): W 2^a fills [2^14, 2^15), the top of the fp16 range
+__device__ __forceinline__ int split_w_exp(unsigned maxbits) {
+    const int biased = (int)((maxbits >> 23) & 0xffu);
+    const int a = 14 - ((biased ? biased : 1) - 127);
+    return a > 100 ? 100 : (a < -100 ? -100 : a);
+}
+__device__ __forceinline__ float split_w_scale(unsigned maxbits) {
+    return __builtin_bit_cast(float, (unsigned)(127 + split_w_exp(maxbits)) << 23);
+}
+// accumulator -> input current: 2^-(a + rshift)
+__device__ __forceinline__ float split_u_scale(unsigned maxbits, int rshift) {
+    return __builtin_bit_cast(float, (unsigned)(127 - split_w_exp(maxbits) - rshift) << 23);
+}
+
+template <int MK>
+struct Split16 {
+    static constexpr int NRT = (MK + 15) / 16, NKT = (MK + 31) / 32;     // row tiles (16 rows), k tiles (32 columns)
+    static constexpr int UNITS = NRT * NKT;
+    static constexpr int WM = 4;                                         // matrix waves = serial waves
+    static constexpr int start(int w) { return UNITS * w / WM; }         // first unit (rt * NKT + kt) of matrix wave w
+    static constexpr int MAXU = (UNITS + WM - 1) / WM;
+    static constexpr int ROW = 320;     // LDS bytes per (tile, 16-lane group): 16 columns x 16 B + 64 B of skew, which
+                                        // puts the serial lanes' column reads / k-slot writes on disjoint banks
+    static constexpr int BB = NKT * 4 * ROW;         // B operand of one group: [k tile][k octet][column][8 fp16]
+    static constexpr int AB = NRT * 4 * ROW;         // sums of one group:      [row tile][row quad][column][4 fp32]
+    static constexpr int XB = (WM - 1) * 4 * ROW;    // second partial sums of the row tiles shared by waves w-1 | w
+    static constexpr int LDS = 2 * BB + 2 * AB + 2 * XB + ROW + 16;
+    static_assert(NRT * 16 <= 256, "serial lanes: 4 waves x 64 lanes x 4 rows");
+    static_assert(start(1) >= NKT, "a row tile is shared by at most two waves");
+};
+
+// One matrix wave: its slice of W in registers for the whole launch, one chain per phase.
+template <int MK, int WV>
+__device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, int M, int lane, int T_, int gpw,
+                                                  char* bbuf, char* abuf, char* xbuf, unsigned* wmax) {
+    using S = Split16<MK>;
+    constexpr int U0 = S::start(WV), U1 = S::start(WV + 1), NU = U1 - U0;
+    constexpr int RT0 = U0 / S::NKT, RT1 = (U1 - 1) / S::NKT, NT = RT1 - RT0 + 1;
+    constexpr bool HEAD_SHARED = (U0 % S::NKT) != 0;       // my first row tile was started by wave WV - 1
+    const int li = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wd), 0, M * M * 4, 0x00020000);
+
+    // the lane's 8 elements of unit u: W[16 rt + li][32 kt + 8 lg .. + 7], zero outside M x M
+    auto fetch = [&](int u, float (&w)[8]) {
+        const int row = 16 * (u / S::NKT) + li, k0 = 32 * (u % S::NKT) + 8 * lg;
+        const int voff = ((row < M ? row : M - 1) * M + k0) * 4;
+        const mf4 lo = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        const mf4 hi = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 0, 0));
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = (row < M && k0 + e < M) ? v[e] : 0.f;
+    };
+    // pass 1: max |W| of the draw (non-negative floats order like their bit patterns)
+    float mx = 0.f;
+    for (int u = U0; u < U1; ++u) {
+        float w[8];
+        fetch(u, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
+    }
+    atomicMax(wmax, __builtin_bit_cast(unsigned, mx));
+    __syncthreads();                                                          // (A)
+    const float sa = split_w_scale(*wmax);
+    // pass 2: W 2^a = W_h + W_m
+    hv8 Ah[NU], Am[NU];
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui) {
+        float w[8];
+        fetch(U0 + ui, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s = w[e] * sa;
+            const _Float16 h = (_Float16)s;
+            Ah[ui][e] = h;
+            Am[ui][e] = (_Float16)(s - (float)h);
+        }
+    }
+    using LdsH8 = const __attribute__((address_space(3))) hv8*;
+    using LdsF4 = __attribute__((address_space(3))) mf4*;
+    const unsigned boff = (unsigned)(lg * S::ROW + li * 16);
+    __syncthreads();                                                          // (B)
+    const int nphase = 2 * T_ + 1;
+    for (int p = 0; p < nphase; ++p) {
+        if (p < 2 * T_ && (p & 1) < gpw && !(SSN_SPLIT_ABLATE & 2)) {
+            const int g = p & 1;
+            const unsigned bb = (unsigned)(size_t)(LdsH8)(bbuf + g * S::BB) + boff;
+            hv8 bt[S::NKT];
+#pragma unroll
+            for (int kt = 0; kt < S::NKT; ++kt) bt[kt] = *(LdsH8)(size_t)(bb + (unsigned)(kt * 4 * S::ROW));
+            mf4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < S::NKT; ++kt) {
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int u = (RT0 + t) * S::NKT + kt;
+                        if (u >= U0 && u < U1)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(part ? Am[u - U0] : Ah[u - U0], bt[kt], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                char* dst = (t == 0 && HEAD_SHARED) ? xbuf + g * S::XB + (WV - 1) * 4 * S::ROW
+                                                    : abuf + g * S::AB + (RT0 + t) * 4 * S::ROW;
+                *(LdsF4)(size_t)((unsigned)(size_t)(LdsF4)dst + boff) = acc[t];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MK, bool SAVE>
+__global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<float> a, int rshift) {
+    using S = Split16<MK>;
+    __shared__ __align__(16) char lds[S::LDS];
+    char* const bbuf = lds;
+    char* const abuf = lds + 2 * S::BB;
+    char* const xbuf = abuf + 2 * S::AB;
+    char* const zrow = xbuf + 2 * S::XB;
+    unsigned* const wmax = reinterpret_cast<unsigned*>(zrow + S::ROW);
+    const int M = a.M, N = a.M / 2, T_ = a.seqlen;
+    const int gpw = a.mfma_groups;                // stimulus groups of 4 in this workgroup (2; 1: group 1 idle)
+    const int ngroups = (a.NB + 4 * gpw - 1) / (4 * gpw);
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < S::LDS / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
+    __syncthreads();                              // (zeroed before any wave records max |W|)
+
+    if (wave < S::WM) {
+        const float* Wd = a.W + (size_t)b * M * M;
+        switch (wave) {
+            case 0: split_matrix_wave<MK, 0>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
+            case 1: split_matrix_wave<MK, 1>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
+            case 2: split_matrix_wave<MK, 2>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
+            default: split_matrix_wave<MK, 3>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
+        }
+        return;
+    }
+
+    // ================================ serial wave ================================
+    const int sw = wave - S::WM;
+    const int blk = lane >> 2, j = lane & 3;
+    const int er = 64 * sw + 4 * blk;             // first of the 4 rows this lane finishes
+    const IoSelect io(a.io);
+    float eps[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) eps[v] = (er + v < N) ? a.eps_E : a.eps_I;
+    bool live[2];
+    float rc[2][4], ex[2][4], ta[2][4], dp[2][4], rpn[2][4];
+    int toff[2];                                  // byte offset of (my stimulus, step 0, row er) within this draw's block
+    const size_t blk_elems = (size_t)a.NB * T_ * M;
+    __amdgpu_buffer_rsrc_t rs_traj, rs_df;
+    if constexpr (SAVE) {
+        rs_traj = __builtin_amdgcn_make_buffer_rsrc(a.traj + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+        rs_df = __builtin_amdgcn_make_buffer_rsrc(a.df + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB && g < gpw;
+        toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rc[g][v] = ta[g][v] = dp[g][v] = rpn[g][v] = 0.f;
+            ex[g][v] = (live[g] && er + v < M) ? a.ext[((size_t)b * a.NB + s) * M + er + v] : 0.f;
+        }
+    }
+    // LDS addresses of this lane (bytes, relative to a group's buffer)
+    const int rt = er / 16 < S::NRT ? er / 16 : S::NRT - 1, rq = (er / 4) & 3;
+    const unsigned a_off = (unsigned)((rt * 4 + rq) * S::ROW + j * 16);       // column 4 part + j: + 64 part
+    int x_slot = -1;                                                          // extra slot of my row tile, if shared
+#pragma unroll
+    for (int w = 1; w < S::WM; ++w)
+        if (S::start(w) % S::NKT != 0 && S::start(w) / S::NKT == rt) x_slot = w - 1;
+    const unsigned x_off = (unsigned)((x_slot * 4 + rq) * S::ROW + j * 16);
+    const bool b_live = er < 32 * S::NKT;
+    const unsigned b_off = (unsigned)(((er / 32) * 4 + ((er & 31) >> 3)) * S::ROW + j * 16 + ((er & 7) >> 2) * 8);
+    const float rs = __builtin_bit_cast(float, (unsigned)(127 + rshift) << 23);          // 2^rshift
+    using LdsF4 = const __attribute__((address_space(3))) mf4*;
+    using LdsU2 = __attribute__((address_space(3))) uv2*;
+
+    __syncthreads();                                                          // (A) max |W| of the draw is known
+    const float usc = split_u_scale(*wmax, rshift);                           // 2^-(a + rshift)
+
+    auto serial = [&](auto G, auto WIN, int it) {
+        constexpr int g = decltype(G)::value;
+        constexpr bool win_on = decltype(WIN)::value;
+        const unsigned ab = (unsigned)(size_t)(LdsF4)(abuf + g * S::AB) + a_off;
+        const unsigned xb = x_slot < 0 ? (unsigned)(size_t)(LdsF4)zrow + (unsigned)(j * 16)
+                                       : (unsigned)(size_t)(LdsF4)(xbuf + g * S::XB) + x_off;
+        const mf4 p0 = *(LdsF4)(size_t)ab, p1 = *(LdsF4)(size_t)(ab + 64u), p2 = *(LdsF4)(size_t)(ab + 128u);
+        const mf4 q0 = *(LdsF4)(size_t)xb, q1 = *(LdsF4)(size_t)(xb + 64u), q2 = *(LdsF4)(size_t)(xb + 128u);
+        const mf4 acc = ((p0 + q0) + (p1 + q1)) + (p2 + q2);
+        const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float win2 = (it > a.skip) ? 1.f : 0.f;
+        float rnew[4], dfn[4] = {0.f, 0.f, 0.f, 0.f};
+        float uu[4], ff[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uu[v] = fmaf(accs[v], usc, ex[g][v]);
+        io.template eval4<SAVE>(uu, ff, dfn);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float f = ff[v];
+            const float r1 = fmaf(eps[v], f - rc[g][v], rc[g][v]);             // (1 - eps) r + eps f(u)
+            const float dd = r1 - rc[g][v];
+            if constexpr (win_on) {
+                ta[g][v] += r1;
+                rpn[g][v] += fmaxf(r1 - a.theta, 0.f);
+                dp[g][v] = fmaf(win2 * dd, dd, dp[g][v]);
+            }
+            rc[g][v] = r1;
+            rnew[v] = (er + v < M) ? r1 : 0.f;
+        }
+        if constexpr (SAVE) {
+            if (er + 3 < M) {       // whole quad inside the matrix (always when M % 4 == 0)
+                const int off = toff[g] < 0 ? -1 : toff[g] + it * M * 4;
+                const mf4 rv = {rnew[0], rnew[1], rnew[2], rnew[3]}, dv = {dfn[0], dfn[1], dfn[2], dfn[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                    unsigned __attribute__((ext_vector_type(4))), rv), rs_traj, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                    unsigned __attribute__((ext_vector_type(4))), dv), rs_df, off, 0, 0);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int off = (toff[g] < 0 || er + v >= M) ? -1 : toff[g] + (it * M + v) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rnew[v]), rs_traj, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[v]), rs_df, off, 0, 0);
+                }
+            }
+        }
+        // new state -> three fp16 parts by truncation (the masked values have 11 significant bits: their conversion is
+        // exact), written where the matrix lanes read their B operands
+        if (b_live) {
+            float hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float s = rnew[v] * rs;
+                hh[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) & 0xffffe000u);
+                const float d = s - hh[v];
+                mm[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) & 0xffffe000u);
+                ll[v] = d - mm[v];
+            }
+            const unsigned bw = (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off;
+            auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
+            *(LdsU2)(size_t)bw = (uv2){pk(hh[0], hh[1]), pk(hh[2], hh[3])};
+            *(LdsU2)(size_t)(bw + 64u) = (uv2){pk(mm[0], mm[1]), pk(mm[2], mm[3])};
+            *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(ll[0], ll[1]), pk(ll[2], ll[3])};
+        }
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+    __syncthreads();                                  // (B)
+    __syncthreads();                                  // phase 0: nothing to finish yet
+    constexpr std::integral_constant<bool, false> W0{};
+    constexpr std::integral_constant<bool, true> W1{};
+    const int nskip = a.skip < T_ ? (a.skip > 0 ? a.skip : 0) : T_;
+    for (int it = 0; it < nskip; ++it) {
+        if (!(SSN_SPLIT_ABLATE & 1)) serial(G0, W0, it);     // phase 2 it + 1
+        __syncthreads();
+        if (!(SSN_SPLIT_ABLATE & 1) && gpw == 2) serial(G1, W0, it);     // phase 2 it + 2
+        __syncthreads();
+    }
+    for (int it = nskip; it < T_; ++it) {
+        if (!(SSN_SPLIT_ABLATE & 1)) serial(G0, W1, it);
+        __syncthreads();
+        if (!(SSN_SPLIT_ABLATE & 1) && gpw == 2) serial(G1, W1, it);
+        __syncthreads();
+    }
+
+    const float inv = 1.f / (float)(T_ - a.skip);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!live[g]) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (er + v >= M) continue;
+            const size_t o = ((size_t)b * a.NB + s0 + 4 * g + j) * M + er + v;
+            a.time_avg[o] = ta[g][v] * inv;
+            a.dyn_row[o] = dp[g][v];
+            a.rate_row[o] = rpn[g][v];
+        }
+    }
+}
+
+static int split_pick_mk(int M) {
+    const int ladder[] = {104, 152, 208};
+    for (int mk : ladder) if (M <= mk) return mk;
+    return 0;
+}
+
+// rshift: r 2^rshift stays below the fp16 range for every reachable rate (r <= rate_hard_bound with the saturating
+// I/O function and Euler factors <= 1); -1: the split kernel does not apply
+int gen_split_rshift(const GenFwdArgs<float>& a) {
+    if (a.io.io_type != SSN_IO_TANH || !(a.io.hard > 0.f) || !(a.io.hard < 3.0e4f) || !(a.io.soft >= 0.f)) return -1;
+    if (!(a.eps_E > 0.f && a.eps_E <= 1.f && a.eps_I > 0.f && a.eps_I <= 1.f)) return -1;
+    if ((a.M & 1) || a.NB < 4 || split_pick_mk(a.M) == 0) return -1;
+    int sh = 0;
+    while (sh < 14 && a.io.hard * (float)(2 << sh) <= 32768.f) ++sh;
+    return sh;
+}
+
+template <int MK>
+static hipError_t launch_split_mk(const GenFwdArgs<float>& a, int rshift, hipStream_t st) {
+    const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
+    if (a.traj) hipLaunchKernelGGL((gen_forward_split_kernel<MK, true>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
+    else hipLaunchKernelGGL((gen_forward_split_kernel<MK, false>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
+    return hipGetLastError();
+}
+hipError_t launch_gen_forward_split(const GenFwdArgs<float>& a, hipStream_t st) {
+    const int rshift = gen_split_rshift(a);
+    if (rshift < 0) return hipErrorInvalidValue;
+    switch (split_pick_mk(a.M)) {
+        case 104: return launch_split_mk<104>(a, rshift, st);
+        case 152: return launch_split_mk<152>(a, rshift, st);
+        case 208: return launch_split_mk<208>(a, rshift, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ssn

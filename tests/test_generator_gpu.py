@@ -33,9 +33,16 @@ def _problem(N, B, NB, seed, T, skip, theta):
     # sizes beyond the register-resident instantiations (2N > 208 fp32, > 104 fp64): streaming kernels
     (110, 1, 2, 'float32', 0), (60, 2, 2, 'float64', 0), (129, 1, 4, 'float32', 0), (201, 1, 2, 'float32', 0),
     # MFMA kernels with one 4-stimulus group per workgroup (kernel 3)
-    (100, 2, 8, 'float32', 3), (101, 1, 6, 'float32', 3), (50, 2, 9, 'float32', 3)])
+    (100, 2, 8, 'float32', 3), (101, 1, 6, 'float32', 3), (50, 2, 9, 'float32', 3),
+    # fp16-split MFMA kernel (csrc/ssn_mfma16.hip; saturating I/O function only), two groups per workgroup (4) and one (5):
+    # the three tile grids (2N <= 104, <= 152, <= 208), odd sizes, ragged stimulus groups
+    (100, 2, 8, 'float32', 4), (101, 1, 6, 'float32', 5), (50, 2, 9, 'float32', 5), (76, 1, 11, 'float32', 4),
+    (10, 3, 8, 'float32', 4), (33, 2, 5, 'float32', 4), (104, 1, 4, 'float32', 4), (90, 2, 8, 'float32', 4),
+    (65, 1, 6, 'float32', 4), (102, 2, 8, 'float32', 4), (52, 2, 8, 'float32', 5), (100, 2, 8, 'float32', 5)])
 def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
     from tc_gan_amd import genops, stimuli, weight_gen
+    if kernel in (4, 5) and io_type != 'asym_tanh':
+        pytest.skip('the fp16-split kernel needs the rate bound of asym_tanh (refusal: test_split_kernel_refuses_...)')
     T, skip, theta = 60, 40, 2.0
     jds, z, bws, con = _problem(N, B, NB, N + NB, T, skip, theta)
     gen = dict(GEN, io_type=io_type)
@@ -62,10 +69,14 @@ def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
     (100, 1, 8, 'float32', 2), (100, 1, 8, 'float32', 1), (50, 2, 5, 'float32', 2), (101, 1, 4, 'float32', 2),
     (20, 2, 9, 'float32', 2), (76, 1, 8, 'float32', 2), (90, 1, 5, 'float32', 2),
     (110, 1, 2, 'float32', 0), (60, 2, 2, 'float64', 0), (100, 1, 8, 'float32', 3), (76, 2, 5, 'float32', 3),
-    (201, 1, 1, 'float32', 0)])
+    (201, 1, 1, 'float32', 0),
+    # trajectory-saving forward on the fp16-split kernel, adjoint on the fp32 MFMA kernel
+    (100, 1, 8, 'float32', 4), (76, 2, 5, 'float32', 5), (101, 1, 8, 'float32', 4)])
 def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype, kernel):
     """dL/dJ, dL/dD, dL/dS for L = sum(G * time_avg) + c_d * dyn_pen + c_r * rate_pen."""
     from tc_gan_amd import genops, stimuli, weight_gen
+    if kernel in (4, 5) and io_type != 'asym_tanh':
+        pytest.skip('the fp16-split kernel needs the rate bound of asym_tanh')
     T, skip, theta = 50, 30, 1.0
     jds, z, bws, con = _problem(N, B, NB, 7 * N + NB, T, skip, theta)
     gen = dict(GEN, io_type=io_type)
@@ -125,8 +136,8 @@ def test_compare_with_ssnode(num_sites, batchsize, seqlen, tol):
 
 def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
     """C3 sizes (2N = 200, 8 stimuli, seqlen 1200 / skip 1000; 256 draws instead of 1024 to bound the 4 GB of
-    trajectory per kernel): the fp32-MFMA kernels (two groups per workgroup and one), and the VALU tile kernels compute
-    the same recurrence in different summation orders -- outputs and adjoint results must agree to fp32 accuracy."""
+    trajectory per kernel): the fp32-MFMA kernels (two groups per workgroup and one), the fp16-split MFMA kernels (4, 5)
+    and the VALU tile kernels compute the same recurrence in different summation orders -- outputs and adjoint results must agree to fp32 accuracy."""
     from tc_gan_amd import genops, stimuli, weight_gen
     N, B, NB, T, skip = 100, 256, 8, 1200, 1000
     rs = np.random.RandomState(7)
@@ -137,7 +148,7 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
     ext = stimuli.stimulus_batch(bws, np.full_like(bws, 20.0), P['smoothness'], N, dtype='float32')
     gta = torch.as_tensor(rs.rand(B, NB, 2 * N), device='cuda', dtype=torch.float32)
     res = {}
-    for kernel in (1, 2, 3):
+    for kernel in (1, 2, 3, 4, 5):
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=kernel, **GEN)
         out = genops.gen_forward(W, ext, gp, save=True)
         delta = genops.gen_backward(W, out['traj'], out['df'], gta, 1e-3, 1e-3, gp)
@@ -147,7 +158,7 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
         del out, delta, gW
         torch.cuda.empty_cache()
     assert np.isfinite(res[1][0]).all() and res[1][0].max() > 1.0
-    for kernel in (2, 3):
+    for kernel in (2, 3, 4, 5):
         np.testing.assert_allclose(res[kernel][0], res[1][0], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(res[kernel][1], res[1][1], rtol=1e-3)
         np.testing.assert_allclose(res[kernel][2], res[1][2], rtol=1e-4)
@@ -184,3 +195,50 @@ def test_weight_grad_kernels_vs_fp64_matmul(B, NB, T, M, dtype, kernel):
             e[k] = (np.abs(r - want) / (scale + 1e-300)).max()
         # the split-bf16 MFMA kernel is at least as accurate as an fp32 FMA chain over the same K
         assert e[2] < tol and e[2] <= 1.5 * e[1] + 1e-7, e
+
+
+def test_split_kernel_refuses_unbounded_io_functions():
+    """The fp16-split kernel scales the state by the rate bound of asym_tanh; asked for explicitly with another I/O
+    function it must fail, not overflow."""
+    from tc_gan_amd import clib, genops, stimuli, weight_gen
+    jds, z, bws, con = _problem(50, 2, 8, 3, 20, 10, 1.0)
+    W = weight_gen.generate_weight_batch(50, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], 50, dtype='float32')
+    for io_type in ('asym_power', 'asym_linear'):
+        gp = genops.make_gen_params(seqlen=20, skip_steps=10, kernel=4, **dict(GEN, io_type=io_type))
+        with pytest.raises(clib.SSNLibraryError):
+            genops.gen_forward(W, ext, gp)
+    gp = genops.make_gen_params(seqlen=20, skip_steps=10, kernel=4, **dict(GEN, dt=1.5))     # dt > tau_I: no bound
+    with pytest.raises(clib.SSNLibraryError):
+        genops.gen_forward(W, ext, gp)
+
+
+@pytest.mark.parametrize('case', ['plain', 'weak', 'tiny', 'strong-diagonal'])
+def test_split_kernel_error_against_fp64_is_that_of_the_fp32_kernels(case):
+    """csrc/ssn_mfma16.hip carries W as two fp16 parts (22 significant bits) and the state as three (exact); every
+    product is exact and the accumulation is fp32.  Its distance from the fp64 oracle must be the distance of the fp32
+    MFMA kernel (whose own error is dominated by the fast power law) -- also for weights far from 1 in magnitude (the
+    operand scale is taken from max |W| per draw: 2^-20 J, and a -60 self-inhibition on top of |W| ~ 0.1)."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    N, B, NB, T, skip = 100, 4, 8, 400, 300
+    jds, z, bws, con = _problem(N, B, NB, 11, T, skip, 2.0)
+    scale = {'plain': 1.0, 'weak': 1e-3, 'tiny': 2.0 ** -20, 'strong-diagonal': 1.0}[case]
+    jds = dict(jds, J=jds['J'] * scale, D=jds['D'] * scale)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    if case == 'strong-diagonal':
+        W[:, torch.arange(2 * N), torch.arange(2 * N)] = -60.0
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
+    # the oracle runs on the very fp32 inputs the kernels get: only the recurrence itself is compared
+    ta_o, dyn_o, rate_o = og.euler_ssn(og.t64(W.cpu().numpy()), og.t64(ext.cpu().numpy()), seqlen=T, skip_steps=skip,
+                                       rate_penalty_threshold=2.0, **GEN)
+    err, ta = {}, {}
+    for kernel in (2, 4, 5):
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=2.0, kernel=kernel, **GEN)
+        ta[kernel] = genops.gen_forward(W, ext, gp)['time_avg'].cpu().numpy().astype('float64')
+        assert np.isfinite(ta[kernel]).all()
+        err[kernel] = np.abs(ta[kernel] - ta_o.numpy()).max() / np.abs(ta_o.numpy()).max()
+    print('%s: max error / max rate against fp64: fp32 MFMA %.2e, fp16-split %.2e' % (case, err[2], err[4]))
+    assert ta_o.numpy().max() > 0.1
+    assert err[2] < 2e-5 and err[4] < 2e-5
+    assert err[4] < 2.0 * err[2] + 2e-7
+    np.testing.assert_array_equal(ta[4], ta[5])
