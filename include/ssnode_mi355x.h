@@ -171,8 +171,10 @@ typedef struct ssn_gen_params {
                                   * same with one 4-stimulus group per workgroup (few draws: more workgroups), 4 / 5
                                   * forward: fp16-split MFMA kernel (W carried as two fp16 parts = 22 significant bits,
                                   * the state as three = exact, every product exact, fp32 accumulation; asym_tanh only)
-                                  * with two / one group per workgroup, backward: as 2 / 3.  The default picks 4 / 5
-                                  * where they apply unless SSN_FWD_SPLIT=0 is set in the environment. */
+                                  * with two / one group per workgroup; backward: the adjoint sweep in the same form
+                                  * (W^T as two fp16 parts, delta as three with a scale that follows max |delta| step
+                                  * by step; any I/O function).  The default picks 4 / 5 where they apply unless
+                                  * SSN_FWD_SPLIT=0 is set in the environment. */
     double k, n;
     double tau_E, tau_I, dt;     /* eps = dt / tau per neuron */
     double rate_soft_bound, rate_hard_bound;

@@ -481,7 +481,10 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
         }
         if (const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB)) {
             a.mfma_groups = groups;
-            SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
+            const bool split_ok = ssn::gen_split_backward_supported(M, NB);
+            const bool split = split_ok && (g->kernel >= 4 || (g->kernel == 0 && forward_split_default()));
+            if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
+            else SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
             return 0;
         }
     }

@@ -73,10 +73,11 @@ struct Split16 {
     static_assert(start(1) >= NKT, "a row tile is shared by at most two waves");
 };
 
-// One matrix wave: its slice of W in registers for the whole launch, one chain per phase.
-template <int MK, int WV>
-__device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, int M, int lane, int T_, int gpw,
-                                                  char* bbuf, char* abuf, char* xbuf, unsigned* wmax) {
+// One matrix wave: its slice of W (TRANSPOSED: of W^T, for the adjoint sweep) in registers for the whole launch, one
+// chain per phase p in [p0, p1) for group (p - p0) & 1, a barrier at the end of each of the `nphase` phases.
+template <int MK, int WV, bool TRANSPOSED>
+__device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, int M, int lane, int p0, int p1, int nphase,
+                                                  int gpw, char* bbuf, char* abuf, char* xbuf, unsigned* wmax) {
     using S = Split16<MK>;
     constexpr int U0 = S::start(WV), U1 = S::start(WV + 1), NU = U1 - U0;
     constexpr int RT0 = U0 / S::NKT, RT1 = (U1 - 1) / S::NKT, NT = RT1 - RT0 + 1;
@@ -84,13 +85,23 @@ __device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, 
     const int li = lane & 15, lg = lane >> 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wd), 0, M * M * 4, 0x00020000);
 
-    // the lane's 8 elements of unit u: W[16 rt + li][32 kt + 8 lg .. + 7], zero outside M x M
+    // the lane's 8 elements of unit u: A[16 rt + li][32 kt + 8 lg .. + 7], A = W or W^T, zero outside M x M
     auto fetch = [&](int u, float (&w)[8]) {
         const int row = 16 * (u / S::NKT) + li, k0 = 32 * (u % S::NKT) + 8 * lg;
-        const int voff = ((row < M ? row : M - 1) * M + k0) * 4;
-        const mf4 lo = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
-        const mf4 hi = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 0, 0));
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const int rowc = row < M ? row : M - 1;
+        float v[8];
+        if constexpr (!TRANSPOSED) {
+            const int voff = (rowc * M + k0) * 4;
+            const mf4 lo = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+            const mf4 hi = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 0, 0));
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {          // A[row][k] = W[k][row]: 64-byte runs over the 16 lanes of a row tile
+                const int k = k0 + e < M ? k0 + e : M - 1;
+                v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (k * M + rowc) * 4, 0, 0));
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = (row < M && k0 + e < M) ? v[e] : 0.f;
     };
@@ -123,10 +134,9 @@ __device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, 
     using LdsF4 = __attribute__((address_space(3))) mf4*;
     const unsigned boff = (unsigned)(lg * S::ROW + li * 16);
     __syncthreads();                                                          // (B)
-    const int nphase = 2 * T_ + 1;
     for (int p = 0; p < nphase; ++p) {
-        if (p < 2 * T_ && (p & 1) < gpw && !(SSN_SPLIT_ABLATE & 2)) {
-            const int g = p & 1;
+        if (p >= p0 && p < p1 && ((p - p0) & 1) < gpw && !(SSN_SPLIT_ABLATE & 2)) {
+            const int g = (p - p0) & 1;
             const unsigned bb = (unsigned)(size_t)(LdsH8)(bbuf + g * S::BB) + boff;
             hv8 bt[S::NKT];
 #pragma unroll
@@ -177,11 +187,11 @@ __global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<fl
 
     if (wave < S::WM) {
         const float* Wd = a.W + (size_t)b * M * M;
-        switch (wave) {
-            case 0: split_matrix_wave<MK, 0>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
-            case 1: split_matrix_wave<MK, 1>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
-            case 2: split_matrix_wave<MK, 2>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
-            default: split_matrix_wave<MK, 3>(Wd, M, lane, T_, gpw, bbuf, abuf, xbuf, wmax); break;
+        switch (wave) {       // phases 0 .. 2T: chains in 0 .. 2T - 1
+            case 0: split_matrix_wave<MK, 0, false>(Wd, M, lane, 0, 2 * T_, 2 * T_ + 1, gpw, bbuf, abuf, xbuf, wmax); break;
+            case 1: split_matrix_wave<MK, 1, false>(Wd, M, lane, 0, 2 * T_, 2 * T_ + 1, gpw, bbuf, abuf, xbuf, wmax); break;
+            case 2: split_matrix_wave<MK, 2, false>(Wd, M, lane, 0, 2 * T_, 2 * T_ + 1, gpw, bbuf, abuf, xbuf, wmax); break;
+            default: split_matrix_wave<MK, 3, false>(Wd, M, lane, 0, 2 * T_, 2 * T_ + 1, gpw, bbuf, abuf, xbuf, wmax); break;
         }
         return;
     }
@@ -331,6 +341,252 @@ __global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<fl
     }
 }
 
+
+// max over the wave of a non-negative float (bit patterns order like the values), in every lane's SGPR copy
+__device__ __forceinline__ unsigned wave_max_bits(float x) {
+    unsigned v = __builtin_bit_cast(unsigned, x);
+    auto dpp_max = [&](auto CTRL, auto ROWMASK) {
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(CTRL)::value, decltype(ROWMASK)::value, 0xf, false);
+        v = o > v ? o : v;
+    };
+    using I = std::integral_constant<int, 0>;
+    (void)sizeof(I);
+    dpp_max(std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+    dpp_max(std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+    dpp_max(std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+    dpp_max(std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror: every lane = row max
+    dpp_max(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast15 -> rows 1, 3
+    dpp_max(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast31 -> rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// Reverse-time adjoint sweep with W^T delta on the fp16 matrix cores: the matrix waves hold W^T as two fp16 parts
+// (the forward's layout and scale), the serial waves own the adjoint state (the recurrence, HBM streams and the in-place
+// shifted delta of gen_backward_mfma_kernel, ssn_mfma.hip) and hand delta_tau over as three fp16 parts, exact.
+// delta has no a-priori bound, so its power-of-two scale follows the data: the scale of step tau is taken from
+// max |delta_{tau+1}| of the same group (one step of lag keeps the reduction off the critical path: a wave maximum by DPP
+// and one LDS atomic per wave, three rotating slots), placed at 2^7 so that delta may grow or shrink by 2^8 per step
+// before bits are lost (a part that overflows saturates: v_cvt_pkrtz never produces infinity); the first step's scale
+// comes from its own delta, found in the prologue.
+template <int MK>
+__global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<float> a) {
+    using S = Split16<MK>;
+    __shared__ __align__(16) char lds[S::LDS + 32];
+    char* const bbuf = lds;
+    char* const abuf = lds + 2 * S::BB;
+    char* const xbuf = abuf + 2 * S::AB;
+    char* const zrow = xbuf + 2 * S::XB;
+    unsigned* const wmax = reinterpret_cast<unsigned*>(zrow + S::ROW);
+    unsigned* const dmax = wmax + 4;              // [group][3 rotating slots]: max |delta| bit patterns
+    const int M = a.M, N = a.M / 2, T_ = a.seqlen;
+    const int gpw = a.mfma_groups;
+    const int ngroups = (a.NB + 4 * gpw - 1) / (4 * gpw);
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < (S::LDS + 32) / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
+    __syncthreads();
+
+    if (wave < S::WM) {
+        const float* Wd = a.W + (size_t)b * M * M;
+        switch (wave) {       // phases 0 .. 2T - 1: chains in 1 .. 2T - 1 (phase 0 is the first serial part)
+            case 0: split_matrix_wave<MK, 0, true>(Wd, M, lane, 1, 2 * T_, 2 * T_, gpw, bbuf, abuf, xbuf, wmax); break;
+            case 1: split_matrix_wave<MK, 1, true>(Wd, M, lane, 1, 2 * T_, 2 * T_, gpw, bbuf, abuf, xbuf, wmax); break;
+            case 2: split_matrix_wave<MK, 2, true>(Wd, M, lane, 1, 2 * T_, 2 * T_, gpw, bbuf, abuf, xbuf, wmax); break;
+            default: split_matrix_wave<MK, 3, true>(Wd, M, lane, 1, 2 * T_, 2 * T_, gpw, bbuf, abuf, xbuf, wmax); break;
+        }
+        return;
+    }
+
+    const int sw = wave - S::WM;
+    const int blk = lane >> 2, j = lane & 3;
+    const int er = 64 * sw + 4 * blk;
+    const float inv = 1.f / (float)(T_ - a.skip);
+    float eps[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) eps[v] = (er + v < N) ? a.eps_E : a.eps_I;
+    const size_t blk_elems = (size_t)a.NB * T_ * M;
+    const __amdgpu_buffer_rsrc_t rs_traj =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.traj) + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dlt =
+        __builtin_amdgcn_make_buffer_rsrc(a.delta + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    const bool quad = er + 3 < M;
+    bool live[2];
+    int toff[2];
+    float gta[2][4], carry[2][4], xn[2][4], xc[2][4], xm[2][4], dfc[2][4], dsum[2][4];
+    float pxm[2][4], pdf[2][4];                   // loads in flight for the END of the group's next serial part
+    int bused[2] = {0, 0};                        // the scale exponent the group's delta in LDS was written with
+    unsigned lastref[2] = {0u, 0u};
+    auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float (&out)[4]) {
+        if (quad) {
+            const mf4 q = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+            out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                out[v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (off < 0 || er + v >= M) ? -1 : off + 4 * v, 0, 0));
+        }
+    };
+    auto store4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, const float (&val)[4]) {
+        if (quad) {
+            const mf4 q = {val[0], val[1], val[2], val[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(4))), q), rs, off, 0, 0);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val[v]), rs, (off < 0 || er + v >= M) ? -1 : off + 4 * v, 0, 0);
+        }
+    };
+    auto at_step = [&](int g, int t) { return toff[g] < 0 ? -1 : toff[g] + t * M * 4; };   // byte offset of index t
+    using LdsAtom = __attribute__((address_space(3))) unsigned*;
+    using LdsUC = volatile const __attribute__((address_space(3))) unsigned*;
+    const unsigned dmax_addr = (unsigned)(size_t)(LdsAtom)dmax;
+    auto slot = [&](int g, int tau) { return dmax_addr + 4u * (unsigned)(3 * g + (tau + 3) % 3); };
+    // direct gradient of the loss w.r.t. x_tau inside the penalty window
+    auto direct = [&](int g, int v, int tau) {
+        float gg = gta[g][v] + ((xc[g][v] > a.theta) ? a.c_rate : 0.f);
+        if (tau <= T_ - 1) gg -= 2.f * a.c_dyn * (xn[g][v] - xc[g][v]);
+        if (tau >= a.skip + 2) gg += 2.f * a.c_dyn * (xc[g][v] - xm[g][v]);
+        return gg;
+    };
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB && g < gpw;
+        toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
+        const float zero4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            gta[g][v] = (live[g] && er + v < M) ? a.g_time_avg[((size_t)b * a.NB + s) * M + er + v] * inv : 0.f;
+            carry[g][v] = dsum[g][v] = xn[g][v] = 0.f;
+        }
+        load4(rs_traj, at_step(g, T_ - 1), xc[g]);                                   // x_T
+        if (T_ >= 2) load4(rs_traj, at_step(g, T_ - 2), xm[g]); else { for (int v = 0; v < 4; ++v) xm[g][v] = 0.f; }
+        load4(rs_dlt, at_step(g, T_ - 1), dfc[g]);                                   // f'(u_T)
+        store4(rs_dlt, at_step(g, T_ - 1), zero4);                                   // slot T-1 of the shifted delta stays zero
+        if (T_ >= 3) load4(rs_traj, at_step(g, T_ - 3), pxm[g]); else { for (int v = 0; v < 4; ++v) pxm[g][v] = 0.f; }
+        if (T_ >= 2) load4(rs_dlt, at_step(g, T_ - 2), pdf[g]); else { for (int v = 0; v < 4; ++v) pdf[g][v] = 0.f; }
+        // the first step's scale: max |delta_T| (carry = 0), or of eps |a_T| 2^-20 if f' vanishes everywhere
+        float m0 = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (er + v >= M) continue;
+            const float at = (T_ >= a.skip + 1) ? direct(g, v, T_) : 0.f;
+            m0 = fmaxf(m0, fmaxf(__builtin_fabsf(eps[v] * dfc[g][v] * at), __builtin_fabsf(eps[v] * at) * 9.5367431640625e-07f));
+        }
+        const unsigned wm0 = wave_max_bits(m0);
+        if (lane == 0 && g < gpw) __hip_atomic_fetch_max((LdsAtom)(size_t)slot(g, T_ + 1), wm0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // LDS addresses of this lane (as in the forward kernel)
+    const int rt = er / 16 < S::NRT ? er / 16 : S::NRT - 1, rq = (er / 4) & 3;
+    const unsigned a_off = (unsigned)((rt * 4 + rq) * S::ROW + j * 16);
+    int x_slot = -1;
+#pragma unroll
+    for (int w = 1; w < S::WM; ++w)
+        if (S::start(w) % S::NKT != 0 && S::start(w) / S::NKT == rt) x_slot = w - 1;
+    const unsigned x_off = (unsigned)((x_slot * 4 + rq) * S::ROW + j * 16);
+    const bool b_live = er < 32 * S::NKT;
+    const unsigned b_off = (unsigned)(((er / 32) * 4 + ((er & 31) >> 3)) * S::ROW + j * 16 + ((er & 7) >> 2) * 8);
+    using LdsF4 = const __attribute__((address_space(3))) mf4*;
+    using LdsU2 = __attribute__((address_space(3))) uv2*;
+
+    __syncthreads();                                                          // (A) max |W| and the first delta scale
+    const int wexp = split_w_exp(*wmax);
+
+    // serial part of (group g, step tau): first = no matrix result yet (tau == T)
+    auto serial = [&](auto G, auto WIN, int tau) {
+        constexpr int g = decltype(G)::value;
+        constexpr bool win_on = decltype(WIN)::value;
+        float nxm[4] = {0.f, 0.f, 0.f, 0.f}, ndf[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (win_on) {
+            if (tau >= 4 && tau >= a.skip + 3) load4(rs_traj, at_step(g, tau - 4), nxm);
+        }
+        if (tau >= 3) load4(rs_dlt, at_step(g, tau - 3), ndf);
+        // scale of this step's delta from the previous step's maximum (kept when that was exactly zero)
+        const unsigned mprev = __builtin_amdgcn_readfirstlane(*(LdsUC)(size_t)slot(g, tau + 1));
+        if (lane == 0) *(LdsAtom)(size_t)slot(g, tau + 2) = 0u;                 // next step's slot (last read a phase pair ago)
+        const unsigned ref = mprev ? mprev : lastref[g];
+        lastref[g] = ref;
+        int bexp = 7 - ((int)((ref >> 23) & 0xffu) - 127);
+        bexp = ref == 0u ? 0 : (bexp > 100 ? 100 : (bexp < -100 ? -100 : bexp));
+        if (tau < T_) {
+            const unsigned ab = (unsigned)(size_t)(LdsF4)(abuf + g * S::AB) + a_off;
+            const unsigned xb = x_slot < 0 ? (unsigned)(size_t)(LdsF4)zrow + (unsigned)(j * 16)
+                                           : (unsigned)(size_t)(LdsF4)(xbuf + g * S::XB) + x_off;
+            const mf4 p0 = *(LdsF4)(size_t)ab, p1 = *(LdsF4)(size_t)(ab + 64u), p2 = *(LdsF4)(size_t)(ab + 128u);
+            const mf4 q0 = *(LdsF4)(size_t)xb, q1 = *(LdsF4)(size_t)(xb + 64u), q2 = *(LdsF4)(size_t)(xb + 128u);
+            const mf4 acc = ((p0 + q0) + (p1 + q1)) + (p2 + q2);                   // W^T delta_{tau+1} 2^(a + bused)
+            const float usc = __builtin_bit_cast(float, (unsigned)(127 - wexp - bused[g]) << 23);
+            carry[g][0] = fmaf(acc.x, usc, carry[g][0]); carry[g][1] = fmaf(acc.y, usc, carry[g][1]);
+            carry[g][2] = fmaf(acc.z, usc, carry[g][2]); carry[g][3] = fmaf(acc.w, usc, carry[g][3]);
+        }
+        float delta[4], dm = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            float gg = 0.f;
+            if constexpr (win_on) gg = direct(g, v, tau);
+            const float at = gg + carry[g][v];
+            delta[v] = (er + v < M) ? eps[v] * dfc[g][v] * at : 0.f;
+            dm = fmaxf(dm, __builtin_fabsf(delta[v]));
+            carry[g][v] = fmaf(-eps[v], at, at);                                       // (1 - eps) a_t
+            dsum[g][v] += delta[v];
+            if constexpr (win_on) {
+                xn[g][v] = xc[g][v]; xc[g][v] = xm[g][v]; xm[g][v] = pxm[g][v]; pxm[g][v] = nxm[v];
+            }
+            dfc[g][v] = pdf[g][v];
+            pdf[g][v] = ndf[v];
+        }
+        if (b_live) {
+            const float rs = __builtin_bit_cast(float, (unsigned)(127 + bexp) << 23);
+            float hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float s = (live[g] ? delta[v] : 0.f) * rs;
+                hh[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) & 0xffffe000u);
+                const float d = s - hh[v];
+                mm[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) & 0xffffe000u);
+                ll[v] = d - mm[v];
+            }
+            const unsigned bw = (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off;
+            auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
+            *(LdsU2)(size_t)bw = (uv2){pk(hh[0], hh[1]), pk(hh[2], hh[3])};
+            *(LdsU2)(size_t)(bw + 64u) = (uv2){pk(mm[0], mm[1]), pk(mm[2], mm[3])};
+            *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(ll[0], ll[1]), pk(ll[2], ll[3])};
+        }
+        bused[g] = bexp;
+        const unsigned wm = wave_max_bits(live[g] ? dm : 0.f);
+        if (lane == 0) __hip_atomic_fetch_max((LdsAtom)(size_t)slot(g, tau), wm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tau >= 2) store4(rs_dlt, at_step(g, tau - 2), delta);                      // shifted: pairs with x_{tau-1}
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+    constexpr std::integral_constant<bool, false> W0{};
+    constexpr std::integral_constant<bool, true> W1{};
+    __syncthreads();                                                          // (B)
+    int tau = T_;
+    for (; tau >= a.skip + 1 && tau >= 1; --tau) {    // window steps first (time runs backwards)
+        serial(G0, W1, tau);                          // phase 2 (T - tau)
+        __syncthreads();
+        if (gpw == 2) serial(G1, W1, tau);            // phase 2 (T - tau) + 1
+        __syncthreads();
+    }
+    for (; tau >= 1; --tau) {
+        serial(G0, W0, tau);
+        __syncthreads();
+        if (gpw == 2) serial(G1, W0, tau);
+        __syncthreads();
+    }
+    if (a.g_ext) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (!live[g]) continue;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (er + v < M) a.g_ext[((size_t)b * a.NB + s0 + 4 * g + j) * M + er + v] = dsum[g][v];
+        }
+    }
+}
+
 static int split_pick_mk(int M) {
     const int ladder[] = {104, 152, 208};
     for (int mk : ladder) if (M <= mk) return mk;
@@ -362,6 +618,23 @@ hipError_t launch_gen_forward_split(const GenFwdArgs<float>& a, hipStream_t st) 
         case 104: return launch_split_mk<104>(a, rshift, st);
         case 152: return launch_split_mk<152>(a, rshift, st);
         case 208: return launch_split_mk<208>(a, rshift, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool gen_split_backward_supported(int M, int NB) { return !(M & 1) && NB >= 4 && split_pick_mk(M) != 0; }
+
+template <int MK>
+static hipError_t launch_split_bwd_mk(const GenBwdArgs<float>& a, hipStream_t st) {
+    const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
+    hipLaunchKernelGGL((gen_backward_split_kernel<MK>), dim3(a.B * ngroups), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+hipError_t launch_gen_backward_split(const GenBwdArgs<float>& a, hipStream_t st) {
+    switch (split_pick_mk(a.M)) {
+        case 104: return launch_split_bwd_mk<104>(a, st);
+        case 152: return launch_split_bwd_mk<152>(a, st);
+        case 208: return launch_split_bwd_mk<208>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -25,7 +25,8 @@ def make_gen_params(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=
     """Defaults: networks/wgan.py:39-63 (tau_E=10, tau_I=1, dt=0.1, seqlen=1200, skip_steps=1000).
     kernel: 0 library default (MFMA kernels for fp32 with NB >= 4 and enough draws, VALU tile kernels otherwise),
     1 tile, 2 fp32 MFMA (two 4-stimulus groups per workgroup), 3 fp32 MFMA (one group per workgroup), 4 / 5 forward on
-    the fp16-split MFMA kernel (asym_tanh only; the default where it applies unless SSN_FWD_SPLIT=0), adjoint as 2 / 3."""
+    the fp16-split MFMA kernel (asym_tanh only; the default where it applies unless SSN_FWD_SPLIT=0) and adjoint sweep
+    on its fp16-split form (any I/O function)."""
     return clib.GenParams(io_type=clib.IO_CODES[io_type], seqlen=int(seqlen), skip_steps=int(skip_steps),
                           kernel=int(kernel), k=float(k), n=float(n), tau_E=float(tau_E), tau_I=float(tau_I),
                           dt=float(dt), rate_soft_bound=float(rate_soft_bound),
