@@ -56,6 +56,23 @@ __device__ __forceinline__ float split_u_scale(unsigned maxbits, int rshift) {
     return __builtin_bit_cast(float, (unsigned)(127 - split_w_exp(maxbits) - rshift) << 23);
 }
 
+typedef float fv2 __attribute__((ext_vector_type(2)));
+// x * sc -> three fp16 parts by truncation (the masked values have 11 significant bits: their conversion is exact),
+// written to the lane's k slots of the B operand (part columns 64 bytes apart); packed fp32 arithmetic throughout
+__device__ __forceinline__ void split3_store(const float (&x)[4], fv2 sc01, fv2 sc23, unsigned bw) {
+    using LdsU2 = __attribute__((address_space(3))) uv2*;
+    const fv2 s01 = (fv2){x[0], x[1]} * sc01, s23 = (fv2){x[2], x[3]} * sc23;
+    auto top = [](fv2 v) { return __builtin_bit_cast(fv2, __builtin_bit_cast(uv2, v) & (uv2){0xffffe000u, 0xffffe000u}); };
+    auto pk = [](fv2 v) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)); };
+    const fv2 h01 = top(s01), h23 = top(s23);
+    const fv2 d01 = s01 - h01, d23 = s23 - h23;
+    const fv2 m01 = top(d01), m23 = top(d23);
+    const fv2 l01 = d01 - m01, l23 = d23 - m23;
+    *(LdsU2)(size_t)bw = (uv2){pk(h01), pk(h23)};
+    *(LdsU2)(size_t)(bw + 64u) = (uv2){pk(m01), pk(m23)};
+    *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(l01), pk(l23)};
+}
+
 template <int MK>
 struct Split16 {
     static constexpr int NRT = (MK + 15) / 16, NKT = (MK + 31) / 32;     // row tiles (16 rows), k tiles (32 columns)
@@ -235,6 +252,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<fl
     const bool b_live = er < 32 * S::NKT;
     const unsigned b_off = (unsigned)(((er / 32) * 4 + ((er & 31) >> 3)) * S::ROW + j * 16 + ((er & 7) >> 2) * 8);
     const float rs = __builtin_bit_cast(float, (unsigned)(127 + rshift) << 23);          // 2^rshift
+    const fv2 rs01 = {er < M ? rs : 0.f, er + 1 < M ? rs : 0.f}, rs23 = {er + 2 < M ? rs : 0.f, er + 3 < M ? rs : 0.f};
     using LdsF4 = const __attribute__((address_space(3))) mf4*;
     using LdsU2 = __attribute__((address_space(3))) uv2*;
 
@@ -268,7 +286,7 @@ __global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<fl
                 dp[g][v] = fmaf(win2 * dd, dd, dp[g][v]);
             }
             rc[g][v] = r1;
-            rnew[v] = (er + v < M) ? r1 : 0.f;
+            rnew[v] = r1;              // (rows >= M: never stored, and split with scale 0)
         }
         if constexpr (SAVE) {
             if (er + 3 < M) {       // whole quad inside the matrix (always when M % 4 == 0)
@@ -287,24 +305,8 @@ __global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<fl
                 }
             }
         }
-        // new state -> three fp16 parts by truncation (the masked values have 11 significant bits: their conversion is
-        // exact), written where the matrix lanes read their B operands
-        if (b_live) {
-            float hh[4], mm[4], ll[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float s = rnew[v] * rs;
-                hh[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) & 0xffffe000u);
-                const float d = s - hh[v];
-                mm[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) & 0xffffe000u);
-                ll[v] = d - mm[v];
-            }
-            const unsigned bw = (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off;
-            auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
-            *(LdsU2)(size_t)bw = (uv2){pk(hh[0], hh[1]), pk(hh[2], hh[3])};
-            *(LdsU2)(size_t)(bw + 64u) = (uv2){pk(mm[0], mm[1]), pk(mm[2], mm[3])};
-            *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(ll[0], ll[1]), pk(ll[2], ll[3])};
-        }
+        // new state -> three fp16 parts, written where the matrix lanes read their B operands (rows >= M: scale 0)
+        if (b_live) split3_store(rnew, rs01, rs23, (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off);
     };
     constexpr std::integral_constant<int, 0> G0{};
     constexpr std::integral_constant<int, 1> G1{};
@@ -537,21 +539,8 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
             pdf[g][v] = ndf[v];
         }
         if (b_live) {
-            const float rs = __builtin_bit_cast(float, (unsigned)(127 + bexp) << 23);
-            float hh[4], mm[4], ll[4];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float s = (live[g] ? delta[v] : 0.f) * rs;
-                hh[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) & 0xffffe000u);
-                const float d = s - hh[v];
-                mm[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d) & 0xffffe000u);
-                ll[v] = d - mm[v];
-            }
-            const unsigned bw = (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off;
-            auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y)); };
-            *(LdsU2)(size_t)bw = (uv2){pk(hh[0], hh[1]), pk(hh[2], hh[3])};
-            *(LdsU2)(size_t)(bw + 64u) = (uv2){pk(mm[0], mm[1]), pk(mm[2], mm[3])};
-            *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(ll[0], ll[1]), pk(ll[2], ll[3])};
+            const float rs = live[g] ? __builtin_bit_cast(float, (unsigned)(127 + bexp) << 23) : 0.f;
+            split3_store(delta, (fv2){rs, rs}, (fv2){rs, rs}, (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off);
         }
         bused[g] = bexp;
         const unsigned wm = wave_max_bits(live[g] ? dm : 0.f);
