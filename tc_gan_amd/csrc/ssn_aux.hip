@@ -300,8 +300,9 @@ template hipError_t launch_philox_uniform<double>(unsigned long long, unsigned l
 // ---------------------------------------------------------------------------------
 // The two penalty means of the fixed-time generator (networks/ssn.py:626, 632): out[0] = scale_dyn * sum(dyn_row),
 // out[1] = scale_rate * sum(rate_row), fp64, in ONE launch: every workgroup writes its fp64 partial sums to `ws`,
-// takes a ticket, and the workgroup that draws the last ticket adds the partials in workgroup order (deterministic)
-// and resets the ticket.  ws: [2 * PEN_BLOCKS] doubles + the ticket (one int, zero before the first launch).
+// takes a ticket, and the workgroup that draws the last ticket adds the partials as a fixed tree over the workgroup
+// index (deterministic) and resets the ticket.  ws: [2 * PEN_BLOCKS] doubles + the ticket (one int, zero before the
+// first launch).
 // ---------------------------------------------------------------------------------
 constexpr int PEN_BLOCKS = 256;
 template <typename T>
@@ -327,10 +328,17 @@ __global__ void __launch_bounds__(256) penalty_means_kernel(const T* __restrict_
     __syncthreads();
     if (!last) return;
     __threadfence();                                               // acquire: see every workgroup's partials
+    // the last workgroup adds the (at most 256) partials as a fixed tree: thread b takes workgroup b's pair
+    const bool have = threadIdx.x < gridDim.x;
+    red[0][threadIdx.x] = have ? __builtin_nontemporal_load(ws + 2 * threadIdx.x) : 0.0;
+    red[1][threadIdx.x] = have ? __builtin_nontemporal_load(ws + 2 * threadIdx.x + 1) : 0.0;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
-        double t0 = 0.0, t1 = 0.0;
-        for (int b = 0; b < (int)gridDim.x; ++b) { t0 += ws[2 * b]; t1 += ws[2 * b + 1]; }
-        out[0] = t0 * scale_dyn; out[1] = t1 * scale_rate;
+        out[0] = red[0][0] * scale_dyn; out[1] = red[1][0] * scale_rate;
         *ticket = 0;
     }
 }
