@@ -279,3 +279,51 @@ def test_split_adjoint_matches_fp32_adjoint_step_by_step(N, B, NB, T, skip, taus
         assert per_step[live].max() / per_step[live].min() > 1e6
     np.testing.assert_allclose(res[4][1], res[2][1], rtol=1e-5, atol=1e-6 * np.abs(res[2][1]).max())
     np.testing.assert_array_equal(res[5][0], d4)
+
+
+@pytest.mark.parametrize('soft,hard,contrast', [(200., 1000., 2000.), (2000., 20000., 5e4), (0.2, 0.5, 20.), (200., 1000., 20.)])
+def test_split_kernel_at_the_rate_bound_and_with_other_bounds(soft, hard, contrast):
+    """The state scale of the fp16-split forward comes from rate_hard_bound: saturated networks (rates at the bound),
+    a bound near the top of the fp16 range (scale 2^0) and a tiny one (scale 2^14) must all match the fp32 MFMA kernel
+    and the fp64 oracle."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    N, B, NB, T, skip = 100, 2, 8, 200, 150
+    jds, z, bws, con = _problem(N, B, NB, 3, T, skip, 2.0)
+    con = np.full_like(con, contrast)
+    gen = dict(GEN)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
+    ta_o = None
+    if (soft, hard) == (200., 1000.):                      # (the oracle's I/O function has the default bounds built in)
+        ta_o = og.euler_ssn(og.t64(W.cpu().numpy()), og.t64(ext.cpu().numpy()), seqlen=T, skip_steps=skip,
+                            rate_penalty_threshold=2.0, **gen)[0]
+    ta = {}
+    for kernel in (2, 4):
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=2.0, kernel=kernel,
+                                    rate_soft_bound=soft, rate_hard_bound=hard, **gen)
+        ta[kernel] = genops.gen_forward(W, ext, gp)['time_avg'].cpu().numpy().astype('float64')
+    assert np.isfinite(ta[4]).all() and ta[4].max() <= hard * (1 + 1e-6)
+    if contrast >= 2000.:
+        assert ta[4].max() > 0.9 * hard                    # really at the bound
+    np.testing.assert_allclose(ta[4], ta[2], rtol=2e-5, atol=2e-6 * ta[2].max())
+    if ta_o is not None:
+        np.testing.assert_allclose(ta[4], ta_o.numpy(), rtol=1e-4, atol=1e-5 * ta_o.numpy().max())
+
+
+def test_split_kernels_propagate_nan_and_terminate():
+    """A NaN in W must come out as NaN rates (the reference's drivers stop on it), not as finite garbage, and the
+    kernels must still drain."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    N, B, NB, T, skip = 100, 2, 8, 40, 20
+    jds, z, bws, con = _problem(N, B, NB, 3, T, skip, 2.0)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    W[1, 7, 9] = float('nan')
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
+    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=4, **GEN)
+    out = genops.gen_forward(W, ext, gp, save=True)
+    ta = out['time_avg'].cpu().numpy()
+    assert np.isfinite(ta[0]).all()                        # the other draw is untouched
+    assert np.isnan(ta[1]).any()
+    G = torch.ones((B, NB, 2 * N), device='cuda', dtype=torch.float32)
+    d = genops.gen_backward(W, out['traj'], out['df'], G, 1e-3, 1e-3, gp).cpu().numpy()
+    assert np.isfinite(d[0]).all() and np.isnan(d[1]).any()
