@@ -114,6 +114,13 @@ libssnode.ssn_io_eval_f64.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
 for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_stimulus_f64',
               'ssn_io_eval_f32', 'ssn_io_eval_f64'):
     getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_probe_scatter_f32', 'ssn_probe_scatter_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    getattr(libssnode, _name).restype = c_int
+libssnode.ssn_segment_sqnorms_f32.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+libssnode.ssn_segment_sqnorms_f32.restype = c_int
+libssnode.ssn_interpolate_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_interpolate_f32.restype = c_int
 for _name in ('ssn_philox_amp_f32', 'ssn_philox_amp_f64'):
     getattr(libssnode, _name).argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p,
                                           ctypes.c_ulonglong, c_int, c_int, c_void_p]
@@ -245,6 +252,7 @@ DECLARED_SYMBOLS = (
     'ssn_critic_input_grad_norm', 'ssn_philox_uniform_f32', 'ssn_philox_uniform_f64',
     'ssn_weight_grad_f32', 'ssn_weight_grad_f64', 'ssn_lu_solve_f32', 'ssn_lu_solve_f64',
     'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
+    'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
 )
 
 

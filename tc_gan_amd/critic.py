@@ -100,14 +100,14 @@ class Critic(object):
 
     # -- parameter statistics without a host wait (recorders.py:275-311 logs them after EVERY critic step) --------
     def param_sqnorms_device(self):
-        """Sum of squares per parameter tensor (device tensor, `param_shapes` order; three small kernels)."""
-        if getattr(self, '_seg_ids', None) is None:
+        """Sum of squares per parameter tensor (device tensor, `param_shapes` order; one launch: `ssn_segment_sqnorms_f32`)."""
+        if getattr(self, '_seg_bounds', None) is None:
             sizes = [int(np.prod(shape)) for _, shape in self.param_shapes()]
             self._seg_sizes = np.asarray(sizes, dtype='float64')
-            self._seg_ids = torch.repeat_interleave(torch.arange(len(sizes), device=self.device),
-                                                    torch.as_tensor(sizes, device=self.device))
-        out = torch.zeros(len(self._seg_sizes), device=self.device, dtype=torch.float32)
-        out.index_add_(0, self._seg_ids, self.params * self.params)
+            self._seg_bounds = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(self.device)
+        out = torch.empty(len(self._seg_sizes), device=self.device, dtype=torch.float32)
+        clib.check(libssnode.ssn_segment_sqnorms_f32(self.params.data_ptr(), self._seg_bounds.data_ptr(), int(out.numel()),
+                                                     out.data_ptr(), _stream()), 'ssn_segment_sqnorms_f32')
         return out
 
     def cache_param_nnorms(self, sqnorms_host):
@@ -135,6 +135,8 @@ class Critic(object):
 
     @staticmethod
     def _f32(t):
+        if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+            return t
         return torch.as_tensor(t).to('cuda', torch.float32).contiguous()
 
     def forward(self, x, cond):
@@ -172,6 +174,15 @@ class Critic(object):
             _stream()), 'ssn_critic_loss_grad')
         return self.stats
 
+    def interpolate(self, eps, xd, xg):
+        """The gradient-penalty points eps * xd + (1 - eps) * xg (cwgan.py:476-481); eps: one value per row."""
+        eps, xd, xg = self._f32(eps).reshape(-1), self._f32(xd), self._f32(xg)
+        assert xd.shape == xg.shape and eps.numel() == xd.shape[0]
+        xp = torch.empty_like(xd)
+        clib.check(libssnode.ssn_interpolate_f32(eps.data_ptr(), xd.data_ptr(), xg.data_ptr(), xp.data_ptr(),
+                                                 int(xd.shape[0]), int(xd.shape[1]), _stream()), 'ssn_interpolate_f32')
+        return xp
+
     def input_grad(self, x, cond, scale):
         """gx = scale * dD/dx summed over nothing (per sample), stats[0] = mean D(x)."""
         x, cond = self._f32(x), self._f32(cond)
@@ -191,12 +202,9 @@ class Critic(object):
         return gx, self.stats[0]
 
     def accuracy_device(self, xg, cg, xd, cd):
-        """mean D(xg) - mean D(xd) (cwgan.py:139-147) as a 1-element device tensor: ONE forward over the stacked rows
-        (every output row depends on its own input row only), no host wait."""
-        xg, cg, xd, cd = self._f32(xg), self._f32(cg), self._f32(xd), self._f32(cd)
-        d = self.forward(torch.cat([xg, xd]), torch.cat([cg, cd]))
-        ng = xg.shape[0]
-        return (d[:ng].mean() - d[ng:].mean()).reshape(1)
+        """mean D(xg) - mean D(xd) (cwgan.py:139-147) as a 1-element device tensor, no host wait (two forwards: every
+        output row depends on its own input row only, and stacking the rows would cost two more launches)."""
+        return (self.forward(xg, cg).mean() - self.forward(xd, cd).mean()).reshape(1)
 
     def accuracy(self, xg, cg, xd, cd):
         return float(self.accuracy_device(xg, cg, xd, cd)[0])

@@ -354,4 +354,67 @@ hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scal
 template hipError_t launch_penalty_means<float>(const float*, const float*, long, double, double, double*, double*, hipStream_t);
 template hipError_t launch_penalty_means<double>(const double*, const double*, long, double, double, double*, double*, hipStream_t);
 
+// ---------------------------------------------------------------------------------
+// Small per-step helpers of the GAN loop (one launch each instead of three to five element-wise ones).
+// segment_sqnorms: out[t] = sum of x[i]^2 over i in [bounds[t], bounds[t + 1]) -- the per-tensor parameter statistics that
+// recorders.py:275-311 logs after every critic step; one workgroup per tensor, fp64 partial sums, fixed tree.
+// interpolate: xp = eps * xd + (1 - eps) * xg per row (cwgan.py:476-481).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) segment_sqnorms_kernel(const float* __restrict__ x, const long* __restrict__ bounds,
+                                                             float* __restrict__ out) {
+    __shared__ double red[256];
+    const long lo = bounds[blockIdx.x], hi = bounds[blockIdx.x + 1];
+    double s = 0.0;
+    for (long i = lo + threadIdx.x; i < hi; i += 256) { const double v = (double)x[i]; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)red[0];
+}
+hipError_t launch_segment_sqnorms(const float* x, const long* bounds, int n, float* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(segment_sqnorms_kernel, dim3(n), dim3(256), 0, st, x, bounds, out);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(256) interpolate_kernel(const float* __restrict__ eps, const float* __restrict__ xd,
+                                                         const float* __restrict__ xg, float* __restrict__ xp, long n, int cols) {
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= n) return;
+    const float e = eps[i / cols];
+    xp[i] = e * xd[i] + (1.f - e) * xg[i];
+}
+hipError_t launch_interpolate(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, hipStream_t st) {
+    const long n = (long)rows * cols;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, eps, xd, xg, xp, n, cols);
+    return hipGetLastError();
+}
+
+// Adjoint of the conditional prober's gather tuning_curve[k][s] = time_avg[ids[k]][s][probes[k]] (cwgan.py:91-98):
+// g_ta[b][s][m] = sum over the samples k with ids[k] == b and probes[k] == m of g[k][s], zero elsewhere.  One workgroup
+// per model b zeroes its slab and lets thread s add the matching samples in k order: deterministic whatever the
+// collisions, no atomics, no sort, no host wait.
+template <typename T>
+__global__ void __launch_bounds__(64) probe_scatter_kernel(const T* __restrict__ g, const long* __restrict__ ids,
+                                                          const long* __restrict__ probes, T* __restrict__ g_ta, int n, int NB, int M) {
+    const int b = blockIdx.x;
+    T* slab = g_ta + (size_t)b * NB * M;
+    for (int i = threadIdx.x; i < NB * M; i += 64) slab[i] = (T)0;
+    __syncthreads();
+    for (int s = threadIdx.x; s < NB; s += 64)
+        for (int k = 0; k < n; ++k)
+            if (ids[k] == b) slab[(size_t)s * M + probes[k]] += g[(size_t)k * NB + s];
+}
+template <typename T>
+hipError_t launch_probe_scatter(const T* g, const long* ids, const long* probes, T* g_ta, int n, int B, int NB, int M, hipStream_t st) {
+    if (B <= 0 || NB <= 0 || M <= 0) return hipSuccess;
+    hipLaunchKernelGGL((probe_scatter_kernel<T>), dim3(B), dim3(64), 0, st, g, ids, probes, g_ta, n, NB, M);
+    return hipGetLastError();
+}
+template hipError_t launch_probe_scatter<float>(const float*, const long*, const long*, float*, int, int, int, int, hipStream_t);
+template hipError_t launch_probe_scatter<double>(const double*, const long*, const long*, double*, int, int, int, int, hipStream_t);
+
 }  // namespace ssn

@@ -875,6 +875,26 @@ int ssn_stimulus_amp_f64(const double* bw, const double* con, double smoothness,
     SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_probe_scatter_f32(const float* g, const long* ids, const long* probes, float* g_ta, int n, int B, int NB, int M, void* stream) {
+    if (n < 0 || B < 0 || NB < 0 || M < 0 || ((long)B * NB * M > 0 && !g_ta) || (n > 0 && (!g || !ids || !probes))) { g_last_error = "ssn_probe_scatter: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_probe_scatter<float>(g, ids, probes, g_ta, n, B, NB, M, (hipStream_t)stream));
+    return 0;
+}
+int ssn_probe_scatter_f64(const double* g, const long* ids, const long* probes, double* g_ta, int n, int B, int NB, int M, void* stream) {
+    if (n < 0 || B < 0 || NB < 0 || M < 0 || ((long)B * NB * M > 0 && !g_ta) || (n > 0 && (!g || !ids || !probes))) { g_last_error = "ssn_probe_scatter: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_probe_scatter<double>(g, ids, probes, g_ta, n, B, NB, M, (hipStream_t)stream));
+    return 0;
+}
+int ssn_segment_sqnorms_f32(const float* x, const long* bounds, int n, float* out, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !bounds || !out))) { g_last_error = "ssn_segment_sqnorms: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_segment_sqnorms(x, bounds, n, out, (hipStream_t)stream));
+    return 0;
+}
+int ssn_interpolate_f32(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, void* stream) {
+    if (rows < 0 || cols < 0 || ((long)rows * cols > 0 && (!eps || !xd || !xg || !xp))) { g_last_error = "ssn_interpolate: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_interpolate(eps, xd, xg, xp, rows, cols, (hipStream_t)stream));
+    return 0;
+}
 int ssn_penalty_means_f32(const float* dyn, const float* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, void* stream) {
     if (n < 0 || !ws || !out || (n > 0 && (!dyn || !rate))) { g_last_error = "ssn_penalty_means: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::launch_penalty_means<float>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream));

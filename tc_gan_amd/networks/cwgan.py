@@ -28,7 +28,7 @@ import torch
 from .. import clib
 from ..critic import Critic, Updater
 from ..gradient_expressions.utils import sample_sites_from_stim_space
-from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product, to_device
+from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product, to_device, to_device_packed
 from .ssn import TuningCurveGenerator
 from .utils import gridify_tc_samples
 from .wgan import DEFAULT_PARAMS as _WGAN_DEFAULTS
@@ -319,12 +319,10 @@ class ConditionalBPTTWassersteinGAN(object):
         pens = torch.stack([gen_out.model_rate_penalty.reshape(()).to(torch.float32),
                             gen_out.model_dynamics_penalty.reshape(()).to(torch.float32)])
         self.reducer.mean_(pens)
-        xd = to_device(local.tuning_curves, torch.float32)
-        cd = to_device(np.ascontiguousarray(local.conditions), torch.float32)
         per = local.batchsize
         r0 = self.reducer.rank * per if self.reducer.on else 0
-        eps = to_device(ctx.eps_full[r0:r0 + per], torch.float32)
-        xp = eps * xd + (1 - eps) * xg.to(torch.float32)                      # cwgan.py:481
+        xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
+        xp = self.disc.interpolate(eps, xd, xg)                               # cwgan.py:481
         ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
         ctx.skipped = False
         # cwgan.py:493-498 skips the critic update when the rate penalty of the batch exceeds `disc_rate_penalty_bound`.

@@ -267,11 +267,16 @@ class TuningCurveGenerator(object):
 
     def _probe(self, time_avg, prober_norm_probes=None, prober_model_ids=None, prober_cell_types=None):
         if self.conditional:
-            probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
-                                                       self.num_sites, type='uint16').astype(np.int64) \
-                + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
-            ids = self._cached_upload('ids', np.asarray(prober_model_ids).astype(np.int64), None)
-            pr = self._cached_upload('probes', probes, None)
+            # (the probe set of a run rarely changes from step to step: index arithmetic and uploads only when it does)
+            key = (np.asarray(prober_norm_probes, dtype='float64').tobytes(), np.asarray(prober_cell_types).tobytes(),
+                   np.asarray(prober_model_ids).tobytes())
+            hit = self.__dict__.get('_probe_cache')
+            if hit is None or hit[0] != key:
+                probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
+                                                           self.num_sites, type='uint16').astype(np.int64) \
+                    + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
+                hit = self._probe_cache = (key, to_device(np.asarray(prober_model_ids).astype(np.int64)), to_device(probes))
+            ids, pr = hit[1], hit[2]
             return time_avg[ids, :, pr], ids, pr                                       # cwgan.py:98
         if getattr(self, '_probes_dev', None) is None or self._probes_dev[0] is not self.probes:
             self._probes_dev = (self.probes, to_device(np.asarray(self.probes)))
@@ -315,12 +320,15 @@ class TuningCurveGenerator(object):
         g = g_tuning_curve.to(fwd['time_avg'].dtype)
         if self.conditional:
             # scatter-add of the probe gather (several samples may probe the same model/neuron):
-            # tuning_curve[n, :] = time_avg[ids[n], :, probes[n]].  index_add_ on the (model, neuron)-major view:
-            # atomics, no sort and no host wait (index_put_(accumulate=True) sorts the indices and synchronises)
+            # tuning_curve[n, :] = time_avg[ids[n], :, probes[n]]; one launch, samples added in order, no host wait
+            # (torch.index_add_ spends a millisecond on the host per call, index_put_(accumulate=True) synchronises)
             B, NB, M = fwd['time_avg'].shape
-            g_mn = torch.zeros((B * M, NB), device=g.device, dtype=g.dtype)
-            g_mn.index_add_(0, sv['ids'] * M + sv['probes'], g)
-            g_ta = g_mn.reshape(B, M, NB).permute(0, 2, 1).contiguous()
+            g = g.contiguous()
+            g_ta = torch.empty_like(fwd['time_avg'])
+            fn = clib.libssnode.ssn_probe_scatter_f32 if g.dtype == torch.float32 else clib.libssnode.ssn_probe_scatter_f64
+            clib.check(fn(g.data_ptr(), sv['ids'].data_ptr(), sv['probes'].data_ptr(), g_ta.data_ptr(), int(g.shape[0]),
+                          int(B), int(NB), int(M), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       'ssn_probe_scatter')
         else:
             g_ta = torch.zeros_like(fwd['time_avg'])
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)

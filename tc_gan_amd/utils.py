@@ -124,6 +124,23 @@ def log_timing_message(name, seconds):
     return '{} done in {:.3g} sec'.format(name, seconds)
 
 
+def to_device_packed(arrays, dtype):
+    """Several small host arrays -> CUDA tensors of `dtype` through ONE pinned staging buffer and ONE asynchronous copy
+    (the per-step inputs of a critic update: data minibatch, conditions, interpolation weights)."""
+    import torch
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    starts, total = [], 0
+    for a in arrays:                              # every piece starts on a 256-byte boundary, like a tensor of its own
+        starts.append(total)
+        total += -(-a.size // 64) * 64
+    host = torch.empty(int(total), dtype=dtype).pin_memory()
+    view = host.numpy()
+    for a, off in zip(arrays, starts):
+        view[off:off + a.size] = a.reshape(-1)
+    dev = host.to('cuda', non_blocking=True)
+    return [dev[off:off + a.size].reshape(a.shape) for a, off in zip(arrays, starts)]
+
+
 def to_device(x, dtype=None):
     """Host array -> CUDA tensor through pinned staging memory and an ASYNCHRONOUS copy, so that the host does
     not wait for the kernels already queued on the stream (a pageable-memory copy does); CUDA tensors pass through."""

@@ -264,3 +264,18 @@ def test_layer_by_layer_path_still_covers_small_widths():
                         'not layer_by_layer'], env=dict(os.environ, SSN_CRITIC_FUSED='0'), capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_step_helpers_segment_sqnorms_and_interpolate():
+    """`ssn_segment_sqnorms_f32` (per-tensor critic statistics, recorders.py:275-311) and `ssn_interpolate_f32`
+    (gradient-penalty points, cwgan.py:476-481) against their numpy definitions."""
+    from tc_gan_amd.critic import Critic
+    crit = Critic(8, [16, 32, 8], normalization='layer', seed=3)
+    got = crit.param_sqnorms_device().cpu().numpy()
+    want = [float((np.asarray(v, dtype='float64') ** 2).sum()) for v in crit.get_param_values()]
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    assert len(got) == len(crit.get_param_names())
+    rs = np.random.RandomState(0)
+    eps, xd, xg = rs.rand(37, 1).astype('float32'), rs.randn(37, 8).astype('float32'), rs.randn(37, 8).astype('float32')
+    xp = crit.interpolate(torch.as_tensor(eps).cuda(), torch.as_tensor(xd).cuda(), torch.as_tensor(xg).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(xp, eps * xd + (np.float32(1) - eps) * xg)

@@ -327,3 +327,24 @@ def test_split_kernels_propagate_nan_and_terminate():
     G = torch.ones((B, NB, 2 * N), device='cuda', dtype=torch.float32)
     d = genops.gen_backward(W, out['traj'], out['df'], G, 1e-3, 1e-3, gp).cpu().numpy()
     assert np.isfinite(d[0]).all() and np.isnan(d[1]).any()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_probe_scatter_is_the_adjoint_of_the_gather(dtype):
+    """`ssn_probe_scatter_*`: g_ta[ids[k], :, probes[k]] += g[k, :] with collisions, against numpy's add.at."""
+    import ctypes
+    from tc_gan_amd import clib
+    rs = np.random.RandomState(4)
+    n, B, NB, M = 300, 7, 5, 22
+    ids, probes = rs.randint(0, B, n), rs.randint(0, M, n)
+    probes[:40] = probes[0]; ids[:40] = ids[0]                       # many samples on one (model, neuron)
+    g = rs.randn(n, NB).astype(dtype)
+    want = np.zeros((B, NB, M), dtype='float64')
+    np.add.at(want, (ids[:, None], np.arange(NB)[None, :], probes[:, None]), g.astype('float64'))
+    td = getattr(torch, dtype)
+    out = torch.full((B, NB, M), 7.0, device='cuda', dtype=td)        # the kernel writes the whole tensor
+    fn = clib.libssnode.ssn_probe_scatter_f32 if dtype == 'float32' else clib.libssnode.ssn_probe_scatter_f64
+    gd, idd, prd = torch.as_tensor(g).cuda(), torch.as_tensor(ids).cuda(), torch.as_tensor(probes).cuda()
+    for _ in range(2):
+        clib.check(fn(gd.data_ptr(), idd.data_ptr(), prd.data_ptr(), out.data_ptr(), n, B, NB, M, None), 'scatter')
+        np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5 if dtype == 'float32' else 1e-13, atol=1e-6 if dtype == 'float32' else 1e-14)
