@@ -268,17 +268,32 @@ def last_error():
     return libssnode.ssn_last_error().decode()
 
 
+def stream_ptr():
+    """The current torch stream of the current device as the `void *stream` of the additive ABI.  (Goes to the two
+    C entry points directly: `torch.cuda.current_stream().cuda_stream` costs several microseconds of Python per call,
+    and every launch of the GAN loop needs it.)"""
+    import torch
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
 def check(rc, what):
     """Raise on a non-zero status of an additive-ABI call."""
     if rc != 0:
         raise SSNLibraryError('{} failed: status {} ({})'.format(what, rc, last_error()))
 
 
+_DEVICES_SEEN = 0
+
+
 def require_gpu():
-    """Fail loudly when the HIP runtime sees no device."""
+    """Fail loudly when the HIP runtime sees no device (a positive count is remembered: the hot loop asks per launch)."""
+    global _DEVICES_SEEN
+    if _DEVICES_SEEN > 0:
+        return _DEVICES_SEEN
     n = libssnode.ssn_device_count()
     if n <= 0:
         raise GPUUnavailableError(
             'libssnode found no HIP device (ssn_device_count() = {}; {}). '
             'tc_gan_amd has no CPU fallback.'.format(n, last_error()))
+    _DEVICES_SEEN = n
     return n

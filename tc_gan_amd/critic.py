@@ -18,7 +18,7 @@ PRECISION = {'bf16': 0, 'fp32': 1}
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return clib.stream_ptr()
 
 
 class Critic(object):

@@ -59,7 +59,7 @@ def ff_forward(params, RF_w, FF_con, FF_str, TH_sam, stim, box_width, keep=False
     q = torch.empty_like(out) if keep else None
     den = torch.empty_like(out) if keep else None
     fp = _params(params, nsam, nhid, ni, box_width)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = clib.stream_ptr()
     clib.check(libssnode.ssn_ff_forward_f32(RF_w.data_ptr(), FF_con.data_ptr(), FF_str.data_ptr(), TH_sam.data_ptr(),
                                             stim.data_ptr(), out.data_ptr(), q.data_ptr() if keep else None,
                                             den.data_ptr() if keep else None, ctypes.byref(fp), st), 'ssn_ff_forward_f32')
@@ -73,7 +73,7 @@ def ff_backward(params, saved, out, g_out):
     gq = (g_out.to(torch.float32) * (out > 0)).contiguous()
     nsam, ni, nhid = out.shape
     dsig = torch.empty((nsam, nhid, 2), device='cuda', dtype=torch.float32)
-    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    st = clib.stream_ptr()
     clib.check(libssnode.ssn_ff_backward_f32(saved['RF_w'].data_ptr(), saved['FF_con'].data_ptr(),
                                              saved['FF_str'].data_ptr(), saved['stim'].data_ptr(),
                                              saved['q'].data_ptr(), saved['den'].data_ptr(), gq.data_ptr(),

@@ -16,7 +16,7 @@ _DT = {torch.float32: ('f32', ctypes.c_float), torch.float64: ('f64', ctypes.c_d
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return clib.stream_ptr()
 
 
 def make_gen_params(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=0.1, seqlen=1200,
@@ -39,7 +39,7 @@ _PEN_SCRATCH = {}
 
 def _penalty_scratch(device):
     """Per (device, stream) scratch of ssn_penalty_means_* (partials + ticket; zeroed once, the kernel keeps the ticket zero)."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    key = (device.index, clib.stream_ptr().value)
     ws = _PEN_SCRATCH.get(key)
     if ws is None:
         ws = _PEN_SCRATCH[key] = torch.zeros(2 * 256 + 1, device=device, dtype=torch.float64)

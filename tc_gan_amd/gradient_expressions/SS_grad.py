@@ -38,13 +38,13 @@ def WRgrad_batch(R, W, DW, I, n, k, nz, nb, N, CGAN=False, io_type=DEFAULT_PARAM
     fn = libssnode.ssn_ss_grad_system_f64 if td == torch.float64 else libssnode.ssn_ss_grad_system_f32
     clib.check(fn(Rd.data_ptr(), Wd.data_ptr(), DWd.data_ptr(), int(DWd.shape[0] == nz),
                   Id.data_ptr(), int(bool(CGAN)), int(nz), int(nb), int(M), ctypes.byref(p), A.data_ptr(), rhs.data_ptr(),
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_ss_grad_system')
+                  clib.stream_ptr()), 'ssn_ss_grad_system')
     if nz * nb == 0:
         return rhs.reshape(nz, nb, M, 2, 2)
     info = torch.zeros(nz * nb, device='cuda', dtype=torch.int32)
     fn = libssnode.ssn_lu_solve_f64 if td == torch.float64 else libssnode.ssn_lu_solve_f32
     clib.check(fn(A.data_ptr(), rhs.data_ptr(), info.data_ptr(), int(nz * nb), int(M), 4,
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_lu_solve')
+                  clib.stream_ptr()), 'ssn_lu_solve')
     if int(info.count_nonzero()) != 0:          # (the reference's theano `solve` raises on a singular matrix too)
         raise np.linalg.LinAlgError('1 - Phi W is singular for {} of the {} (draw, stimulus) systems'
                                     .format(int(info.count_nonzero()), nz * nb))

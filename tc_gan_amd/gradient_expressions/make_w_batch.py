@@ -41,7 +41,7 @@ def _make_dW(which, Z, J, D, S, N, X, dtheta):
     ct, fn = (ctypes.c_double, libssnode.ssn_build_dw_f64) if td == torch.float64 else (ctypes.c_float, libssnode.ssn_build_dw_f32)
     arrs = [(ct * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (J, D, S)]
     clib.check(fn(z.data_ptr(), arrs[0], arrs[1], arrs[2], which, out.data_ptr(), nz, int(N),
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_build_dw')
+                  clib.stream_ptr()), 'ssn_build_dw')
     return out
 
 

@@ -80,7 +80,7 @@ class DeviceNoise(object):
         n = out.numel()
         fn = clib.libssnode.ssn_philox_uniform_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_uniform_f64
         clib.check(fn(self.seed, self.position + self.rank * n, out.data_ptr(), n,
-                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_philox_uniform')
+                      clib.stream_ptr()), 'ssn_philox_uniform')
         self.position += self.world * n
         return out
 
@@ -94,7 +94,7 @@ class DeviceNoise(object):
         fn = clib.libssnode.ssn_philox_amp_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_amp_f64
         clib.check(fn(self.seed, self.position + self.rank * n, v.data_ptr(), zin.data_ptr(), amp.data_ptr(), n,
                       int(local_shape[-1]), int(bool(bernoulli)),
-                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_philox_amp')
+                      clib.stream_ptr()), 'ssn_philox_amp')
         self.position += self.world * n
         return zin, amp
 
@@ -327,7 +327,7 @@ class TuningCurveGenerator(object):
             g_ta = torch.empty_like(fwd['time_avg'])
             fn = clib.libssnode.ssn_probe_scatter_f32 if g.dtype == torch.float32 else clib.libssnode.ssn_probe_scatter_f64
             clib.check(fn(g.data_ptr(), sv['ids'].data_ptr(), sv['probes'].data_ptr(), g_ta.data_ptr(), int(g.shape[0]),
-                          int(B), int(NB), int(M), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                          int(B), int(NB), int(M), clib.stream_ptr()),
                        'ssn_probe_scatter')
         else:
             g_ta = torch.zeros_like(fwd['time_avg'])

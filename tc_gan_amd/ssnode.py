@@ -114,7 +114,7 @@ def _device_tensor(a, dtype):
 
 def _stream_ptr():
     torch = _torch()
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return clib.stream_ptr()
 
 
 def _params(io_type, k, n, tau=(1., 1.), dt=1., max_iter=0, atol=0.,

@@ -34,7 +34,7 @@ def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32'
         assert amp.shape == (B, 2 * num_sites)
     clib.check(fn(bw.data_ptr(), con.data_ptr(), ct(smoothness), amp.data_ptr() if amp is not None else None,
                   ext.data_ptr(), int(B), int(NB), int(num_sites),
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_stimulus')
+                  clib.stream_ptr()), 'ssn_stimulus')
     return ext
 
 

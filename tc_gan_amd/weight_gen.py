@@ -26,7 +26,7 @@ def generate_weight_batch(N, J, delta, sigma, z, dtype='float32'):
         ct, fn = ctypes.c_double, libssnode.ssn_build_w_f64
     arrs = [(ct * 4)(*numpy.asarray(a, dtype='double').reshape(4)) for a in (J, delta, sigma)]
     clib.check(fn(dz.data_ptr(), arrs[0], arrs[1], arrs[2], W.data_ptr(), int(dz.shape[0]), int(N),
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'ssn_build_w')
+                  clib.stream_ptr()), 'ssn_build_w')
     return W
 
 
