@@ -34,7 +34,8 @@
 #include "ssn_mfma_io.h"
 
 #ifndef SSN_SPLIT_ABLATE
-#define SSN_SPLIT_ABLATE 0      // diagnostic builds: 1 = no serial part, 2 = no chains (wrong results, timing only)
+#define SSN_SPLIT_ABLATE 0      // diagnostic builds: 1 = no serial part, 2 = no chains, 4 = sums not stored, 8 = one B tile
+                                // read seven times (wrong results, timing only)
 #endif
 
 namespace ssn {
@@ -162,7 +163,8 @@ __device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, 
             const unsigned bb = (unsigned)(size_t)(LdsH8)(bbuf + g * S::BB) + boff_b;
             hv8 bt[S::NKT];
 #pragma unroll
-            for (int kt = 0; kt < S::NKT; ++kt) bt[kt] = *(LdsH8)(size_t)(bb + (unsigned)(kt * 4 * S::BROW));
+            for (int kt = 0; kt < S::NKT; ++kt)
+                bt[kt] = *(LdsH8)(size_t)(bb + (unsigned)(((SSN_SPLIT_ABLATE & 8) ? 0 : kt) * 4 * S::BROW));
             mf4 acc[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
@@ -182,7 +184,7 @@ __device__ __forceinline__ void split_matrix_wave(const float* __restrict__ Wd, 
             for (int t = 0; t < NT; ++t) {
                 char* dst = (t == 0 && HEAD_SHARED) ? xbuf + g * S::XB + (WV - 1) * 4 * S::ROW
                                                     : abuf + g * S::AB + (RT0 + t) * 4 * S::ROW;
-                *(LdsF4)(size_t)((unsigned)(size_t)(LdsF4)dst + boff) = acc[t];
+                if (!(SSN_SPLIT_ABLATE & 4) || acc[t].x == 12345.f) *(LdsF4)(size_t)((unsigned)(size_t)(LdsF4)dst + boff) = acc[t];
             }
         }
         __syncthreads();
