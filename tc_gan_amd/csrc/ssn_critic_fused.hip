@@ -78,7 +78,7 @@ __device__ __forceinline__ void block_gemm(const float* __restrict__ Ain, int ld
         for (int i = 0; i < HR; ++i) acc[i] = 0.f;
         // one workgroup per CU and four waves: nothing hides a load's latency but the loads themselves -- eight weights
         // are requested before the FMAs of the first (the k loop is a chain of L2 round trips otherwise)
-        constexpr int U = 8;
+        constexpr int U = 32;
         const float* wp = NT ? W + (size_t)n * ldw : W + n;      // element k: wp[k] (NT) / wp[k * ldw] (NN)
         const size_t ks = NT ? 1 : (size_t)ldw;
         int k = 0;
