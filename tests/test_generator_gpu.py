@@ -348,3 +348,36 @@ def test_probe_scatter_is_the_adjoint_of_the_gather(dtype):
     for _ in range(2):
         clib.check(fn(gd.data_ptr(), idd.data_ptr(), prd.data_ptr(), out.data_ptr(), n, B, NB, M, None), 'scatter')
         np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-5 if dtype == 'float32' else 1e-13, atol=1e-6 if dtype == 'float32' else 1e-14)
+
+
+def test_split_kernels_random_shapes_against_the_fp32_mfma_kernels():
+    """Seeded sweep over sizes the parametrised cases do not name: every even 2N class of the three tile grids (<= 104,
+    <= 152, <= 208), 4 .. 11 stimuli (ragged last group), 1 .. 3 draws, windows that start at step 0 or end at the last
+    step -- forward outputs, trajectory, f' and the adjoint's delta of the fp16-split kernels (4 / 5) against the fp32
+    MFMA kernels (2 / 3) on identical inputs."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    rs = np.random.RandomState(2026)
+    for case in range(14):
+        N = int(rs.choice([rs.randint(2, 53), rs.randint(53, 77), rs.randint(77, 105)]))
+        B, NB = int(rs.randint(1, 4)), int(rs.randint(4, 12))
+        T = int(rs.randint(3, 40))
+        skip = int(rs.choice([0, T - 1, rs.randint(0, T)]))
+        jds, z, bws, con = _problem(N, B, NB, 100 + case, T, skip, 1.0)
+        W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+        ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
+        G = torch.as_tensor(rs.randn(B, NB, 2 * N), device='cuda', dtype=torch.float32)
+        res = {}
+        for kernel in (2, 4, 5):
+            gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=1.0, kernel=kernel, **GEN)
+            out = genops.gen_forward(W, ext, gp, save=True)
+            keep = [out[k].cpu().numpy().astype('float64') for k in ('time_avg', 'traj', 'df')]
+            keep += [float(out['dynamics_penalty']) if T - skip > 1 else 0.0, float(out['rate_penalty'])]
+            d, gx = genops.gen_backward(W, out['traj'], out['df'], G, 1e-2, 1e-2, gp, want_g_ext=True)
+            res[kernel] = keep + [d.cpu().numpy().astype('float64'), gx.cpu().numpy().astype('float64')]
+        tag = 'case %d: N=%d B=%d NB=%d T=%d skip=%d' % (case, N, B, NB, T, skip)
+        for kernel in (4, 5):
+            for got, want in zip(res[kernel], res[2]):
+                got, want = np.asarray(got), np.asarray(want)
+                assert np.isfinite(got).all(), tag
+                scale = np.abs(want).max() if want.size else 0.0
+                np.testing.assert_allclose(got, want, rtol=2e-5, atol=3e-6 * scale + 1e-30, err_msg=tag)
