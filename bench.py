@@ -218,6 +218,19 @@ def run_c3(args, rank, world, local_rank, paper=False):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.isfinite(info.gen_loss)
+    # the same loop with the generator's W.r on the fp32 matrix instructions (W carried with all 24 bits) for a few
+    # iterations, so that the line holds both numbers (`fp32_mfma` below); the split kernels stay the measured default
+    fp32_ms = None
+    if not paper and args.steps >= 2:
+        gan.gen.kernel = 2
+        one_iter()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            one_iter()
+        torch.cuda.synchronize()
+        fp32_ms = (time.perf_counter() - t1) / 2 * 1e3
+        gan.gen.kernel = 0
     # dominant kernel: gen_forward_kernel, timed alone with HIP events on the launch stream
     bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
     kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
@@ -258,6 +271,9 @@ def run_c3(args, rank, world, local_rank, paper=False):
         'roofline': _forward_roofline(variant, achieved, traffic, kernel_ms, M, 7 * units * iters_per_s * world),
         'last_gen_loss': info.gen_loss,
     }
+    if fp32_ms is not None and variant in (4, 5):
+        out['fp32_mfma'] = {'ms_per_step': fp32_ms, 'value': world * 1e3 / fp32_ms,
+                            'note': 'same loop, generator forward and adjoint on the fp32 MFMA kernels (2 iterations, this rank)'}
     out['world_size'] = world
     return out
 

@@ -197,10 +197,15 @@ class TuningCurveGenerator(object):
         if rest:
             raise ValueError('Unknown parameters: {}'.format(rest))
 
+    # kernel family of the forward / adjoint launches (`ssn_gen_params.kernel`): 0 = library default (the fp16-split MFMA
+    # kernels where they apply), 2 = fp32 MFMA kernels, 1 = VALU tile kernels; an attribute so that benchmarks and tests
+    # can time one against the other on the same generator
+    kernel = 0
+
     def gen_params(self, rate_penalty_threshold=200.0):
         return genops.make_gen_params(io_type=self.io_type, k=self.k, n=self.n, tau_E=self.tau_E, tau_I=self.tau_I,
                                       dt=self.dt, seqlen=self.seqlen, skip_steps=self.skip_steps,
-                                      rate_penalty_threshold=rate_penalty_threshold)
+                                      rate_penalty_threshold=rate_penalty_threshold, kernel=self.kernel)
 
     # -- noise -----------------------------------------------------------------------------
     def gen_noise(self, rng, stimulator_bandwidths, **_):
