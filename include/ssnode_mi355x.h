@@ -88,7 +88,7 @@ const char *ssn_last_error(void);            /* thread-local, "" if none */
 /* Which register-resident kernel family covers a (M, NB, dtype) solve: 2 = "tile" kernel
  * (fp32: 2N <= 208, fp64: 2N <= 208), 1 = DPP kernel only, 0 = none (generic streaming
  * kernel).  The automatic dispatch of ssn_solve_batch_* additionally prefers the fp32 MFMA
- * kernel (variant 5) for NB >= 4, 104 < 2N <= 208 and >= 192 (draw, 8 stimuli) workgroups.
+ * kernels (variant 6 where it applies, else 5) for NB >= 4, 104 < 2N <= 208 and >= 192 (draw, 8 stimuli) workgroups.
  * dtype_bytes is 4 or 8. */
 int         ssn_solver_fast_path(int M, int NB, int dtype_bytes);
 
@@ -115,7 +115,8 @@ int ssn_solve_batch_f64(const double *W, const double *ext, int ext_per_draw,
 /* Force a kernel variant (testing / A-B benchmarking): 0 = generic streaming
  * kernel, 1 = register-stationary DPP kernel, 2 = register-stationary tile kernel
  * (shape chosen by the library), 3 = tile kernel with split VGPR/LDS residency,
- * 4 = tile kernel with the whole tile in VGPRs, 5 = fp32 MFMA kernel (NB >= 4);
+ * 4 = tile kernel with the whole tile in VGPRs, 5 = fp32 MFMA kernel (NB >= 4), 6 = fp16-split MFMA kernel
+ * (NB >= 4, asym_tanh, dt <= tau: W carried as two fp16 parts, the state as three, exact products);
  * error if the size has no instantiation; negative = automatic (MFMA kernel for
  * large fp32 batches with NB >= 4, otherwise tile > DPP > streaming). */
 int ssn_solve_batch_f32_variant(int variant, const float *W, const float *ext, int ext_per_draw,

@@ -26,6 +26,12 @@ int fail(hipError_t e, const char* where) {
         if (e__ != hipSuccess) return fail(e__, #expr);   \
     } while (0)
 
+// SSN_FWD_SPLIT=0 keeps the automatic choice on the fp32 MFMA kernel (A/B timing, and for anyone who wants W carried
+// with all 24 bits)
+static bool forward_split_default() {
+    static const bool on = [] { const char* e = getenv("SSN_FWD_SPLIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
 template <typename T>
 int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T* r, T* r_prev, int* codes,
                      int* steps, int B, int NB, int M, const ssn_solver_params* p, void* stream) {
@@ -43,11 +49,14 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     hipStream_t st = (hipStream_t)stream;
     // variant: -1 auto (MFMA for large fp32 NB >= 4 batches, else tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
     // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs,
-    // 5 fp32 MFMA kernel (NB >= 4)
+    // 5 fp32 MFMA kernel (NB >= 4), 6 fp16-split MFMA kernel (NB >= 4, asym_tanh)
     const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
     bool mfma_ok = false;
     if constexpr (sizeof(T) == 4) mfma_ok = ssn::gen_mfma_supported(M, NB);
-    if ((variant == 1 && !regw_ok) || (variant >= 2 && variant <= 4 && !tile_ok) || (variant == 5 && !mfma_ok) || variant > 5) {
+    bool split_ok = false;
+    if constexpr (sizeof(T) == 4) split_ok = mfma_ok && ssn::solve_split_supported(a);
+    if ((variant == 1 && !regw_ok) || (variant >= 2 && variant <= 4 && !tile_ok) || (variant == 5 && !mfma_ok) ||
+        (variant == 6 && !split_ok) || variant > 6) {
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
@@ -56,13 +65,14 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     // split tile kernel (which runs one workgroup per (draw, stimulus) and so keeps small batches busier)
     if (variant < 0) {
         const bool big = (long)B * ((NB + 7) / 8) >= 192 && M > 104;
-        variant = (mfma_ok && big) ? 5 : (tile_ok ? 2 : (regw_ok ? 1 : 0));
+        variant = (mfma_ok && big) ? ((split_ok && forward_split_default()) ? 6 : 5) : (tile_ok ? 2 : (regw_ok ? 1 : 0));
     }
     switch (variant) {
         case 2: SSN_TRY(ssn::launch_tile<T>(a, st, 0)); break;
         case 3: SSN_TRY(ssn::launch_tile<T>(a, st, 1)); break;
         case 4: SSN_TRY(ssn::launch_tile<T>(a, st, 2)); break;
         case 5: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_mfma(a, st)); } break;
+        case 6: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_split(a, st)); } break;
         case 1: SSN_TRY(ssn::launch_regw<T>(a, st)); break;
         default: SSN_TRY(ssn::launch_stream<T>(a, st)); break;
     }
@@ -404,12 +414,6 @@ ssn::IoConsts<T> gen_io_consts(const ssn_gen_params& g) {
 // (two groups when that already gives >= 192 workgroups, one group when only that fills the chip -- 128 draws x 8
 // stimuli of the paper's runs -- else the tile kernels, which run one workgroup per (draw, stimulus)), 1 tile kernels,
 // 2 MFMA with two groups per workgroup, 3 MFMA with one group per workgroup.
-// SSN_FWD_SPLIT=0 keeps the automatic choice on the fp32 MFMA kernel (A/B timing, and for anyone who wants W carried
-// with all 24 bits)
-static bool forward_split_default() {
-    static const bool on = [] { const char* e = getenv("SSN_FWD_SPLIT"); return !(e && e[0] == '0'); }();
-    return on;
-}
 static int mfma_groups_for(int kernel, bool mfma_ok, int B, int NB) {
     if (kernel == 2 || kernel == 4) return 2;
     if (kernel == 3 || kernel == 5) return 1;

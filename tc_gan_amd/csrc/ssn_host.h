@@ -72,6 +72,8 @@ hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st);
 int gen_split_rshift(const GenFwdArgs<float>& a);
 hipError_t launch_gen_forward_split(const GenFwdArgs<float>& a, hipStream_t st);
 bool gen_split_backward_supported(int M, int NB);
+bool solve_split_supported(const SolveArgs<float>& a);
+hipError_t launch_solve_split(const SolveArgs<float>& a, hipStream_t st);
 hipError_t launch_gen_backward_split(const GenBwdArgs<float>& a, hipStream_t st);
 hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st);
 hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st);
