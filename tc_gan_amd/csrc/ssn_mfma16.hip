@@ -1,4 +1,4 @@
-// Generator forward (fixed-time SSN recurrence, NB >= 4 stimuli per weight draw) with W . r on the fp16 matrix cores
+// The SSN recurrence for NB >= 4 stimuli per weight draw (generator forward first) with W . r on the fp16 matrix cores
 // as an EXACT-PRODUCT SPLIT: fp32 operands are carried as sums of fp16 numbers, every partial product of two fp16
 // numbers is exact in the fp32 accumulator, and the fp16 MFMA runs at 16x the rate of the fp32 one that
 // ssn_mfma.hip uses (v_mfma_f32_16x16x32_f16: 16 cycles per 16 x 16 x 32 tile per SIMD).
@@ -27,6 +27,10 @@
 //
 // Only the saturating I/O function (asym_tanh, the default of every driver) bounds the rates, hence the choice of the
 // r scale; the other two run the fp32 MFMA kernel.
+//
+// Three kernels share the matrix-wave code: gen_forward_split_kernel (this comment), gen_backward_split_kernel (adjoint
+// sweep: W^T, delta with a scale that follows max |delta| step by step; any I/O function) and solve_split_kernel (the
+// fixed-point solver with its stop protocol; scale from max(rate bound, max |r0|)).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "ssn_device.h"
