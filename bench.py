@@ -448,6 +448,8 @@ def main():
             out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                                                     'higher_is_better', 'scaling', 'dtype', 'data', 'config', 'roofline',
                                                     'last_gen_loss')}
+            if 'fp32_mfma' in sec:
+                out['secondary']['fp32_mfma'] = sec['fp32_mfma']
     # what actually ran: the process group's own size and backend (1 / none for a single process)
     out['world_size'] = dist.get_world_size() if world > 1 else 1
     out['dist_backend'] = dist.get_backend() if world > 1 else None
