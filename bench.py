@@ -161,17 +161,23 @@ def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iter
 def _forward_roofline(variant, achieved, traffic, kernel_ms, M, steps_in_loop):
     """Roofline object of the generator forward.  `achieved` is ALGORITHMIC: (2 M + 8) flop per neuron-step.
     fp32 MFMA kernel (v_mfma_f32_4x4x1): peak = fp32 matrix peak = fp32 vector peak = 157.3 TFLOP/s.
-    fp16-split kernel (v_mfma_f32_16x16x32_f16): priced against the fp16 dense peak, 16x that; the kernel EXECUTES
-    8 fp16 flops per algorithmic flop (W as 2 fp16 parts x 4 operand columns per stimulus: 3 state parts + 1 unused)
-    on tiles padded from M x M to 16 ceil(M / 16) x 32 ceil(M / 32)."""
+    fp16-split kernels (v_mfma_f32_16x16x32_f16): priced against the fp16 dense peak, 16x that; they EXECUTE 4 fp16 flops
+    per algorithmic flop in the wide form (W as 2 fp16 parts x 2 state parts, all 16 operand columns used by 8 stimuli),
+    8 in the alternating form (2 x 4 columns per stimulus: 3 state parts + 1 unused), on tiles padded from M x M to
+    16 ceil(M / 16) x 32 ceil(M / 32)."""
     groups = {2: 'two 4-stimulus groups per workgroup', 3: 'one 4-stimulus group per workgroup'}
-    if variant in (4, 5):
+    if variant in (4, 5, 6, 7):
         peak = 16 * PEAK_FP32_VALU_TFLOPS
         pad = (16 * -(-M // 16)) * (32 * -(-M // 32)) / float(M * M)
-        executed = achieved * (2 * M) / (2 * M + 8) * 8 * pad
+        # executed fp16 flops per algorithmic flop: W parts x operand columns per stimulus
+        form, per_flop, state = {4: ('all 8 stimuli in one chain per step', 2 * 2, '2 parts (22 bits)'),
+                                 7: ('all 8 stimuli in one chain per step', 3 * 2, '3 parts (exact)'),
+                                 5: (groups[3], 2 * 4, '3 parts (exact)'),
+                                 6: (groups[2] + ', alternating', 2 * 4, '3 parts (exact)')}[variant]
+        executed = achieved * (2 * M) / (2 * M + 8) * per_flop * pad
         return {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'traffic': traffic, 'kernel': 'gen_forward_split_kernel (fp16-split MFMA, %s)' % groups[variant - 2],
-                'mfma_dtype': 'f16 (W = 2 parts, state = 3 parts, exact products, fp32 accumulate)',
+                'traffic': traffic, 'kernel': 'gen_forward_%s_kernel (fp16-split MFMA, %s)' % ('wide' if variant in (4, 7) else 'split', form),
+                'mfma_dtype': 'f16 (W = 2 parts = 22 bits, state = %s, exact products, fp32 accumulate)' % state,
                 'executed_mfma_tflops': executed, 'executed_frac': executed / peak,
                 'frac_of_fp32_peak': achieved / PEAK_FP32_VALU_TFLOPS,
                 'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8, 'ssn_steps_per_s_in_loop': steps_in_loop}
@@ -260,7 +266,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
         'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '%d-model GAN iterations/s' % models,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (critic GEMMs bf16%s)' % ('; generator forward W.r on fp16 matrix cores as an exact-product split, W 22 bits' if variant in (4, 5) else ''),
+        'dtype': 'f32 (critic GEMMs bf16%s)' % ('; generator W.r on fp16 matrix cores as an exact-product split of 22-bit operands' if variant in (4, 5, 6, 7) else ''),
         'data': 'synthetic',
         'config': {'workload': ('C3 paper shape (scripts/fig4/gan/run.json): 2N=202, 128 models x 8 bandwidths per GPU, '
                                 'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
@@ -271,7 +277,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
         'roofline': _forward_roofline(variant, achieved, traffic, kernel_ms, M, 7 * units * iters_per_s * world),
         'last_gen_loss': info.gen_loss,
     }
-    if fp32_ms is not None and variant in (4, 5):
+    if fp32_ms is not None and variant in (4, 5, 6, 7):
         out['fp32_mfma'] = {'ms_per_step': fp32_ms, 'value': world * 1e3 / fp32_ms,
                             'note': 'same loop, generator forward and adjoint on the fp32 MFMA kernels (2 iterations, this rank)'}
     out['world_size'] = world
@@ -565,7 +571,7 @@ def run_solver(args, rank, world, local_rank):
                      'algorithmic_hbm_bytes': B * (4 * M * M + 12 * M * NB)},
     }
     if int(fast) == 6:       # fp16-split MFMA solver: priced like the split generator forward (see _forward_roofline)
-        rl = _forward_roofline(4, achieved, traffic, kernel_ms, M, None)
+        rl = _forward_roofline(6, achieved, traffic, kernel_ms, M, None)
         rl.pop('ssn_steps_per_s_in_loop')
         rl['kernel'] = 'solve_split_kernel (fp16-split MFMA, two 4-stimulus groups per workgroup)'
         rl['algorithmic_hbm_bytes'] = B * (4 * M * M + 12 * M * NB)

@@ -172,7 +172,10 @@ typedef struct ssn_gen_params {
                                   * same with one 4-stimulus group per workgroup (few draws: more workgroups), 4 / 5
                                   * forward: fp16-split MFMA kernel (W carried as two fp16 parts = 22 significant bits,
                                   * the state as three = exact, every product exact, fp32 accumulation; asym_tanh only)
-                                  * with two / one group per workgroup; backward: the adjoint sweep in the same form
+                                  * with two / one group per workgroup -- with two groups all 8 stimuli share one MFMA
+                                  * chain per step and the state enters it as two fp16 parts (22 bits, like W); 6 = two
+                                  * groups in the alternating form, which carries the state as three parts (exact);
+                                  * backward: the adjoint sweep in the same form
                                   * (W^T as two fp16 parts, delta as three with a scale that follows max |delta| step
                                   * by step; any I/O function).  The default picks 4 / 5 where they apply unless
                                   * SSN_FWD_SPLIT=0 is set in the environment. */
@@ -185,7 +188,8 @@ typedef struct ssn_gen_params {
 /* 1 if the register-stationary generator kernels cover this size (2N <= 208 fp32, <= 104 fp64). */
 int ssn_gen_supported(int M, int dtype_bytes);
 /* Which fp32 forward kernel ssn_gen_forward_f32 runs for this call shape and p->kernel (the numbering of p->kernel:
- * 1 VALU tile / streaming kernels, 2 / 3 fp32 MFMA, 4 / 5 fp16-split MFMA); save != 0: with trajectory stores;
+ * 1 VALU tile / streaming kernels, 2 / 3 fp32 MFMA, 4 / 5 / 6 fp16-split MFMA: 4 two groups in the wide form, 5 one
+ * group, 6 two groups in the alternating form; 7: wide form with an exact state, SSN_FWD_WIDE=3); save != 0: with trajectory stores;
  * -1: the call would be refused.  For benchmarks and tests that must name the kernel they measured. */
 int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ssn_gen_params *p);
 

@@ -33,6 +33,8 @@ struct GenFwdArgs {
     T eps_E, eps_I, theta;
     IoConsts<T> io;
     int mfma_groups = 2;   // MFMA kernels: stimulus groups of 4 per workgroup (2, or 1 to spread few draws over the chip)
+    int split_narrow = 0;  // fp16-split forward with two groups: 1 = the alternating two-group form (state as three parts,
+                           // exact) instead of the wide form (all 8 stimuli in one chain, state as two parts)
 };
 // BPTT adjoint sweep (ssn_gen.hip)
 template <typename T>
@@ -71,6 +73,7 @@ hipError_t launch_gen_forward_mfma(const GenFwdArgs<float>& a, hipStream_t st);
 // ssn_mfma16.hip: fp16-split matrix-core forward; gen_split_rshift < 0: not applicable (I/O function without a rate bound, sizes)
 int gen_split_rshift(const GenFwdArgs<float>& a);
 hipError_t launch_gen_forward_split(const GenFwdArgs<float>& a, hipStream_t st);
+int gen_split_wide_parts();   // two-group launches: 2 / 3 = wide form with that many state parts, 0 = alternating form
 bool gen_split_backward_supported(int M, int NB);
 bool solve_split_supported(const SolveArgs<float>& a);
 hipError_t launch_solve_split(const SolveArgs<float>& a, hipStream_t st);

@@ -32,6 +32,7 @@
 // sweep: W^T, delta with a scale that follows max |delta| step by step; any I/O function) and solve_split_kernel (the
 // fixed-point solver with its stop protocol; scale from max(rate bound, max |r0|)).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include "ssn_device.h"
 #include "ssn_host.h"
@@ -336,6 +337,275 @@ __global__ void __launch_bounds__(512, 2) gen_forward_split_kernel(GenFwdArgs<fl
         if (!(SSN_SPLIT_ABLATE & 1)) serial(G0, W1, it);
         __syncthreads();
         if (!(SSN_SPLIT_ABLATE & 1) && gpw == 2) serial(G1, W1, it);
+        __syncthreads();
+    }
+
+    const float inv = 1.f / (float)(T_ - a.skip);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!live[g]) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (er + v >= M) continue;
+            const size_t o = ((size_t)b * a.NB + s0 + 4 * g + j) * M + er + v;
+            a.time_avg[o] = ta[g][v] * inv;
+            a.dyn_row[o] = dp[g][v];
+            a.rate_row[o] = rpn[g][v];
+        }
+    }
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// "Wide" form of the split forward: ALL 8 stimuli of a draw in the 16 operand columns -- column s = r_h, column 8 + s =
+// r_m of stimulus s -- so one chain of 2 MFMAs per tile serves a whole step (the two-group form above spends 2 per tile
+// per group of four).  RP = 3 keeps the state exact with a third MFMA per tile: A = W_h against a second operand whose
+// columns s hold r_l (the product lands in the accumulator column of W_h . r_h); RP = 2 drops r_l: the state enters the
+// product with 22 significant bits, like W.  No second group to alternate with: a step is [chain] barrier [serial parts
+// of both groups] barrier, the matrix waves idle through the serial parts and vice versa -- fewer MFMAs against no
+// overlap.  Two groups per workgroup only (a.mfma_groups == 2).
+// ---------------------------------------------------------------------------------------------------------------
+template <int RP>
+__device__ __forceinline__ void wide_store(const float (&x)[4], fv2 sc01, fv2 sc23, unsigned bw, unsigned second) {
+    using LdsU2 = __attribute__((address_space(3))) uv2*;
+    const fv2 s01 = (fv2){x[0], x[1]} * sc01, s23 = (fv2){x[2], x[3]} * sc23;
+    auto top = [](fv2 v) { return __builtin_bit_cast(fv2, __builtin_bit_cast(uv2, v) & (uv2){0xffffe000u, 0xffffe000u}); };
+    auto pk = [](fv2 v) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)); };
+    const fv2 h01 = top(s01), h23 = top(s23);
+    const fv2 d01 = s01 - h01, d23 = s23 - h23;
+    *(LdsU2)(size_t)bw = (uv2){pk(h01), pk(h23)};
+    if constexpr (RP == 3) {
+        const fv2 m01 = top(d01), m23 = top(d23);
+        *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(m01), pk(m23)};
+        *(LdsU2)(size_t)(bw + second) = (uv2){pk(d01 - m01), pk(d23 - m23)};
+    } else {
+        *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(d01), pk(d23)};         // the remainder, rounded toward zero to 11 bits
+    }
+}
+
+template <int MK, int WV, int RP>
+__device__ __forceinline__ void wide_matrix_wave(const float* __restrict__ Wd, int M, int lane, int T_, char* bbuf, char* abuf,
+                                                 char* xbuf, unsigned* wmax) {
+    using S = Split16<MK>;
+    constexpr int U0 = S::start(WV), U1 = S::start(WV + 1), NU = U1 - U0;
+    constexpr int RT0 = U0 / S::NKT, RT1 = (U1 - 1) / S::NKT, NT = RT1 - RT0 + 1;
+    constexpr bool HEAD_SHARED = (U0 % S::NKT) != 0;
+    const int li = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wd), 0, M * M * 4, 0x00020000);
+    auto fetch = [&](int u, float (&w)[8]) {
+        const int row = 16 * (u / S::NKT) + li, k0 = 32 * (u % S::NKT) + 8 * lg;
+        const int voff = ((row < M ? row : M - 1) * M + k0) * 4;
+        const mf4 lo = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        const mf4 hi = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 0, 0));
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = (row < M && k0 + e < M) ? v[e] : 0.f;
+    };
+    float mx = 0.f;
+    for (int u = U0; u < U1; ++u) {
+        float w[8];
+        fetch(u, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
+    }
+    atomicMax(wmax, __builtin_bit_cast(unsigned, mx));
+    __syncthreads();                                                          // (A)
+    const float sa = split_w_scale(*wmax);
+    hv8 Ah[NU], Am[NU];
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui) {
+        float w[8];
+        fetch(U0 + ui, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = w[e] * sa;
+            const _Float16 h = (_Float16)sc;
+            Ah[ui][e] = h;
+            Am[ui][e] = (_Float16)(sc - (float)h);
+        }
+    }
+    using LdsH8 = const __attribute__((address_space(3))) hv8*;
+    using LdsF4 = __attribute__((address_space(3))) mf4*;
+    const unsigned boff = (unsigned)(lg * S::ROW + li * 16);
+    const unsigned bb = (unsigned)(size_t)(LdsH8)bbuf + (unsigned)(lg * S::BROW + li * 16);
+    __syncthreads();                                                          // (B)
+    for (int it = 0; it < T_; ++it) {
+        mf4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < S::NKT; ++kt) {
+            const hv8 b1 = *(LdsH8)(size_t)(bb + (unsigned)(kt * 4 * S::BROW));
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int u = (RT0 + t) * S::NKT + kt;
+                    if (u >= U0 && u < U1)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(part ? Am[u - U0] : Ah[u - U0], b1, acc[t], 0, 0, 0);
+                }
+            }
+            if constexpr (RP == 3) {
+                const hv8 b2 = *(LdsH8)(size_t)(bb + (unsigned)(S::BB + kt * 4 * S::BROW));
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int u = (RT0 + t) * S::NKT + kt;
+                    if (u >= U0 && u < U1) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah[u - U0], b2, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            char* dst = (t == 0 && HEAD_SHARED) ? xbuf + (WV - 1) * 4 * S::ROW : abuf + (RT0 + t) * 4 * S::ROW;
+            *(LdsF4)(size_t)((unsigned)(size_t)(LdsF4)dst + boff) = acc[t];
+        }
+        __syncthreads();                              // sums stored: the serial waves take over
+        __syncthreads();                              // new state stored
+    }
+}
+
+template <int MK, bool SAVE, int RP>
+__global__ void __launch_bounds__(512, 2) gen_forward_wide_kernel(GenFwdArgs<float> a, int rshift) {
+    using S = Split16<MK>;
+    __shared__ __align__(16) char lds[S::LDS];          // (laid out for two groups; this kernel uses the first halves)
+    char* const bbuf = lds;                               // B1: columns s (r_h) and 8 + s (r_m) of stimulus s; B2 = bbuf + BB: r_l
+    char* const abuf = lds + 2 * S::BB;
+    char* const xbuf = abuf + 2 * S::AB;
+    char* const zrow = xbuf + 2 * S::XB;
+    unsigned* const wmax = reinterpret_cast<unsigned*>(zrow + S::ROW);
+    const int M = a.M, N = a.M / 2, T_ = a.seqlen;
+    const int gpw = a.mfma_groups;                // stimulus groups of 4 in this workgroup (2; 1: group 1 idle)
+    const int ngroups = (a.NB + 4 * gpw - 1) / (4 * gpw);
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 4 * gpw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < S::LDS / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
+    __syncthreads();                              // (zeroed before any wave records max |W|)
+
+    if (wave < S::WM) {
+        const float* Wd = a.W + (size_t)b * M * M;
+        switch (wave) {
+            case 0: wide_matrix_wave<MK, 0, RP>(Wd, M, lane, T_, bbuf, abuf, xbuf, wmax); break;
+            case 1: wide_matrix_wave<MK, 1, RP>(Wd, M, lane, T_, bbuf, abuf, xbuf, wmax); break;
+            case 2: wide_matrix_wave<MK, 2, RP>(Wd, M, lane, T_, bbuf, abuf, xbuf, wmax); break;
+            default: wide_matrix_wave<MK, 3, RP>(Wd, M, lane, T_, bbuf, abuf, xbuf, wmax); break;
+        }
+        return;
+    }
+
+    // ================================ serial wave ================================
+    const int sw = wave - S::WM;
+    const int blk = lane >> 2, j = lane & 3;
+    const int er = 64 * sw + 4 * blk;             // first of the 4 rows this lane finishes
+    const IoSelect io(a.io);
+    float eps[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) eps[v] = (er + v < N) ? a.eps_E : a.eps_I;
+    bool live[2];
+    float rc[2][4], ex[2][4], ta[2][4], dp[2][4], rpn[2][4];
+    int toff[2];                                  // byte offset of (my stimulus, step 0, row er) within this draw's block
+    const size_t blk_elems = (size_t)a.NB * T_ * M;
+    __amdgpu_buffer_rsrc_t rs_traj, rs_df;
+    if constexpr (SAVE) {
+        rs_traj = __builtin_amdgcn_make_buffer_rsrc(a.traj + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+        rs_df = __builtin_amdgcn_make_buffer_rsrc(a.df + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB && g < gpw;
+        toff[g] = (live[g] && er < M) ? (int)(((size_t)s * T_ * M + er) * 4) : -1;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            rc[g][v] = ta[g][v] = dp[g][v] = rpn[g][v] = 0.f;
+            ex[g][v] = (live[g] && er + v < M) ? a.ext[((size_t)b * a.NB + s) * M + er + v] : 0.f;
+        }
+    }
+    // LDS addresses of this lane (bytes, relative to a group's buffer)
+    const int rt = er / 16 < S::NRT ? er / 16 : S::NRT - 1, rq = (er / 4) & 3;
+    const unsigned a_off = (unsigned)((rt * 4 + rq) * S::ROW + j * 16);       // column 4 part + j: + 64 part
+    int x_slot = -1;                                                          // extra slot of my row tile, if shared
+#pragma unroll
+    for (int w = 1; w < S::WM; ++w)
+        if (S::start(w) % S::NKT != 0 && S::start(w) / S::NKT == rt) x_slot = w - 1;
+    const unsigned x_off = (unsigned)((x_slot * 4 + rq) * S::ROW + j * 16);
+    const bool b_live = er < 32 * S::NKT;
+    const unsigned b_off = (unsigned)(((er / 32) * 4 + ((er & 31) >> 3)) * S::BROW + j * 16 + ((er & 7) >> 2) * 8);
+    const float rs = __builtin_bit_cast(float, (unsigned)(127 + rshift) << 23);          // 2^rshift
+    const fv2 rs01 = {er < M ? rs : 0.f, er + 1 < M ? rs : 0.f}, rs23 = {er + 2 < M ? rs : 0.f, er + 3 < M ? rs : 0.f};
+    using LdsF4 = const __attribute__((address_space(3))) mf4*;
+    using LdsU2 = __attribute__((address_space(3))) uv2*;
+
+    __syncthreads();                                                          // (A) max |W| of the draw is known
+    const float usc = split_u_scale(*wmax, rshift);                           // 2^-(a + rshift)
+
+    auto serial = [&](auto G, auto WIN, int it) {
+        constexpr int g = decltype(G)::value;
+        constexpr bool win_on = decltype(WIN)::value;
+        // columns 4 g + j (W . r_h, and W_h . r_l on top when RP = 3) and 8 + 4 g + j (W . r_m) of the one sums buffer
+        const unsigned ab = (unsigned)(size_t)(LdsF4)abuf + a_off + (unsigned)(64 * g);
+        const unsigned xb = x_slot < 0 ? (unsigned)(size_t)(LdsF4)zrow + (unsigned)(j * 16)
+                                       : (unsigned)(size_t)(LdsF4)xbuf + x_off + (unsigned)(64 * g);
+        const mf4 p0 = *(LdsF4)(size_t)ab, p1 = *(LdsF4)(size_t)(ab + 128u);
+        const mf4 q0 = *(LdsF4)(size_t)xb, q1 = *(LdsF4)(size_t)(xb + 128u);
+        const mf4 acc = (p0 + q0) + (p1 + q1);
+        const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
+        const float win2 = (it > a.skip) ? 1.f : 0.f;
+        float rnew[4], dfn[4] = {0.f, 0.f, 0.f, 0.f};
+        float uu[4], ff[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uu[v] = fmaf(accs[v], usc, ex[g][v]);
+        io.template eval4<SAVE>(uu, ff, dfn);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float f = ff[v];
+            const float r1 = fmaf(eps[v], f - rc[g][v], rc[g][v]);             // (1 - eps) r + eps f(u)
+            const float dd = r1 - rc[g][v];
+            if constexpr (win_on) {
+                ta[g][v] += r1;
+                rpn[g][v] += fmaxf(r1 - a.theta, 0.f);
+                dp[g][v] = fmaf(win2 * dd, dd, dp[g][v]);
+            }
+            rc[g][v] = r1;
+            rnew[v] = r1;              // (rows >= M: never stored, and split with scale 0)
+        }
+        if constexpr (SAVE) {
+            if (er + 3 < M) {       // whole quad inside the matrix (always when M % 4 == 0)
+                const int off = toff[g] < 0 ? -1 : toff[g] + it * M * 4;
+                const mf4 rv = {rnew[0], rnew[1], rnew[2], rnew[3]}, dv = {dfn[0], dfn[1], dfn[2], dfn[3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                    unsigned __attribute__((ext_vector_type(4))), rv), rs_traj, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(
+                    unsigned __attribute__((ext_vector_type(4))), dv), rs_df, off, 0, 0);
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int off = (toff[g] < 0 || er + v >= M) ? -1 : toff[g] + (it * M + v) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rnew[v]), rs_traj, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[v]), rs_df, off, 0, 0);
+                }
+            }
+        }
+        // new state -> three fp16 parts, written where the matrix lanes read their B operands (rows >= M: scale 0)
+        if (b_live) wide_store<RP>(rnew, rs01, rs23, (unsigned)(size_t)(LdsU2)bbuf + b_off + (unsigned)(64 * g), (unsigned)S::BB);
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+    __syncthreads();                                  // (B)
+    constexpr std::integral_constant<bool, false> W0{};
+    constexpr std::integral_constant<bool, true> W1{};
+    const int nskip = a.skip < T_ ? (a.skip > 0 ? a.skip : 0) : T_;
+    for (int it = 0; it < nskip; ++it) {
+        __syncthreads();                              // the chain of step it is done
+        serial(G0, W0, it);
+        serial(G1, W0, it);
+        __syncthreads();
+    }
+    for (int it = nskip; it < T_; ++it) {
+        __syncthreads();
+        serial(G0, W1, it);
+        serial(G1, W1, it);
         __syncthreads();
     }
 
@@ -860,9 +1130,26 @@ int gen_split_rshift(const GenFwdArgs<float>& a) {
     return sh;
 }
 
+// two-group launches: 2 = wide form with the state as two fp16 parts (default), 3 = wide form with three (exact state,
+// three MFMAs per tile: no faster than the alternating form), 0 = alternating two-group form; SSN_FWD_WIDE overrides
+int gen_split_wide_parts() {
+    static const int rp = [] { const char* e = getenv("SSN_FWD_WIDE"); return (e && (e[0] == '0' || e[0] == '2' || e[0] == '3')) ? e[0] - '0' : 2; }();
+    return rp;
+}
 template <int MK>
 static hipError_t launch_split_mk(const GenFwdArgs<float>& a, int rshift, hipStream_t st) {
     const int ngroups = (a.NB + 4 * a.mfma_groups - 1) / (4 * a.mfma_groups);
+    if (a.mfma_groups == 2 && !a.split_narrow && gen_split_wide_parts()) {
+        const bool three = gen_split_wide_parts() == 3;
+        if (a.traj) {
+            if (three) hipLaunchKernelGGL((gen_forward_wide_kernel<MK, true, 3>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
+            else hipLaunchKernelGGL((gen_forward_wide_kernel<MK, true, 2>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
+        } else {
+            if (three) hipLaunchKernelGGL((gen_forward_wide_kernel<MK, false, 3>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
+            else hipLaunchKernelGGL((gen_forward_wide_kernel<MK, false, 2>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
+        }
+        return hipGetLastError();
+    }
     if (a.traj) hipLaunchKernelGGL((gen_forward_split_kernel<MK, true>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
     else hipLaunchKernelGGL((gen_forward_split_kernel<MK, false>), dim3(a.B * ngroups), dim3(512), 0, st, a, rshift);
     return hipGetLastError();
