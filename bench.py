@@ -400,7 +400,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c3paper', 'c5'])
     ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 tile (library picks the shape), '
-                    '3 tile/split residency, 4 tile/all-register, 5 fp32 MFMA (NB >= 4), 6 fp16-split MFMA (NB >= 4)')
+                    '3 tile/split residency, 4 tile/all-register, 5 fp32 MFMA (NB >= 4), 6 fp16-split MFMA (NB >= 4), 7 the same in the alternating form')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
     ap.add_argument('--secondary-steps', type=int, default=5,
@@ -562,21 +562,22 @@ def run_solver(args, rank, world, local_rank):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': desc + ', asym_tanh, atol=0, fp32, W rebuilt from resident z each step',
                    'neurons': M, 'batch_per_gpu': B, 'stimuli_per_draw': NB, 'euler_steps': T,
-                   'kernel': {6: 'solve_split_kernel (fp16-split MFMA)', 5: 'solve_mfma_kernel', 4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
+                   'kernel': {7: 'solve_split_kernel (fp16-split MFMA, alternating groups)', 6: 'solve_wide_kernel (fp16-split MFMA)', 5: 'solve_mfma_kernel', 4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
                    'parallelism': 'draws sharded over %d GPU(s), no data-path collective' % world},
         # fp32 VALU peak = fp32 MFMA (v_mfma_f32_4x4x1) peak = 157.3 TFLOP/s (MI355X_MICROARCH.md)
-        'roofline': {'bound': 'mfma' if int(fast) in (5, 6) else 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
+        'roofline': {'bound': 'mfma' if int(fast) in (5, 6, 7) else 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
                      'kernel_ms': kernel_ms, 'flops_per_unit': flops_per_unit,
                      'algorithmic_hbm_bytes': B * (4 * M * M + 12 * M * NB)},
     }
-    if int(fast) == 6:       # fp16-split MFMA solver: priced like the split generator forward (see _forward_roofline)
-        rl = _forward_roofline(6, achieved, traffic, kernel_ms, M, None)
+    if int(fast) in (6, 7):  # fp16-split MFMA solver: priced like the split generator forward (see _forward_roofline)
+        wide = int(fast) == 6 and os.environ.get('SSN_FWD_WIDE', '2') != '0'
+        rl = _forward_roofline(4 if wide else 6, achieved, traffic, kernel_ms, M, None)
         rl.pop('ssn_steps_per_s_in_loop')
-        rl['kernel'] = 'solve_split_kernel (fp16-split MFMA, two 4-stimulus groups per workgroup)'
+        rl['kernel'] = rl['kernel'].replace('gen_forward_wide_kernel', 'solve_wide_kernel').replace('gen_forward_split_kernel', 'solve_split_kernel')
         rl['algorithmic_hbm_bytes'] = B * (4 * M * M + 12 * M * NB)
         out['roofline'] = rl
-        out['dtype'] = 'f32 (W.r on fp16 matrix cores as an exact-product split, W 22 bits)'
+        out['dtype'] = 'f32 (W.r on fp16 matrix cores as an exact-product split of 22-bit operands)'
     out['world_size'] = world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(len(os.sched_getaffinity(0)), 16)           # the 1-GPU box's CPU share

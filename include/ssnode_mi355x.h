@@ -116,7 +116,8 @@ int ssn_solve_batch_f64(const double *W, const double *ext, int ext_per_draw,
  * kernel, 1 = register-stationary DPP kernel, 2 = register-stationary tile kernel
  * (shape chosen by the library), 3 = tile kernel with split VGPR/LDS residency,
  * 4 = tile kernel with the whole tile in VGPRs, 5 = fp32 MFMA kernel (NB >= 4), 6 = fp16-split MFMA kernel
- * (NB >= 4, asym_tanh, dt <= tau: W carried as two fp16 parts, the state as three, exact products);
+ * (NB >= 4, asym_tanh, dt <= tau: W and the state carried as two fp16 parts each, exact products, all 8 stimuli in one
+ * chain per step), 7 = the same in the alternating two-group form (state as three parts, exact);
  * error if the size has no instantiation; negative = automatic (MFMA kernel for
  * large fp32 batches with NB >= 4, otherwise tile > DPP > streaming). */
 int ssn_solve_batch_f32_variant(int variant, const float *W, const float *ext, int ext_per_draw,
@@ -175,7 +176,7 @@ typedef struct ssn_gen_params {
                                   * with two / one group per workgroup -- with two groups all 8 stimuli share one MFMA
                                   * chain per step and the state enters it as two fp16 parts (22 bits, like W); 6 = two
                                   * groups in the alternating form, which carries the state as three parts (exact);
-                                  * backward: the adjoint sweep in the same form
+                                  * backward: the adjoint sweep in the alternating form
                                   * (W^T as two fp16 parts, delta as three with a scale that follows max |delta| step
                                   * by step; any I/O function).  The default picks 4 / 5 where they apply unless
                                   * SSN_FWD_SPLIT=0 is set in the environment. */

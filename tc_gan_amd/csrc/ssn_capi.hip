@@ -49,14 +49,14 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     hipStream_t st = (hipStream_t)stream;
     // variant: -1 auto (MFMA for large fp32 NB >= 4 batches, else tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
     // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs,
-    // 5 fp32 MFMA kernel (NB >= 4), 6 fp16-split MFMA kernel (NB >= 4, asym_tanh)
+    // 5 fp32 MFMA kernel (NB >= 4), 6 fp16-split MFMA kernel (NB >= 4, asym_tanh; wide form), 7 the same in the alternating form
     const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
     bool mfma_ok = false;
     if constexpr (sizeof(T) == 4) mfma_ok = ssn::gen_mfma_supported(M, NB);
     bool split_ok = false;
     if constexpr (sizeof(T) == 4) split_ok = mfma_ok && ssn::solve_split_supported(a);
     if ((variant == 1 && !regw_ok) || (variant >= 2 && variant <= 4 && !tile_ok) || (variant == 5 && !mfma_ok) ||
-        (variant == 6 && !split_ok) || variant > 6) {
+        ((variant == 6 || variant == 7) && !split_ok) || variant > 7) {
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
@@ -73,6 +73,7 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
         case 4: SSN_TRY(ssn::launch_tile<T>(a, st, 2)); break;
         case 5: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_mfma(a, st)); } break;
         case 6: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_split(a, st)); } break;
+        case 7: if constexpr (sizeof(T) == 4) { a.split_narrow = 1; SSN_TRY(ssn::launch_solve_split(a, st)); } break;
         case 1: SSN_TRY(ssn::launch_regw<T>(a, st)); break;
         default: SSN_TRY(ssn::launch_stream<T>(a, st)); break;
     }
@@ -487,6 +488,7 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
         if (const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB)) {
             a.mfma_groups = groups;
             const bool split_ok = ssn::gen_split_backward_supported(M, NB);
+            a.split_narrow = g->kernel == 6;
             const bool split = split_ok && (g->kernel >= 4 || (g->kernel == 0 && forward_split_default()));
             if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
             else SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));

@@ -17,6 +17,7 @@ struct SolveArgs {
     int B, NB, M, N;
     IoConsts<T> io;
     StepConsts<T> st;
+    int split_narrow = 0;   // fp16-split solver: 1 = alternating two-group form (state as three parts) instead of the wide form
 };
 
 // Fixed-time generator forward (ssn_gen.hip)
@@ -47,6 +48,7 @@ struct GenBwdArgs {
     int B, NB, M, seqlen, skip;
     T eps_E, eps_I, theta, c_dyn, c_rate;
     int mfma_groups = 2;
+    int split_narrow = 0;  // as GenFwdArgs::split_narrow
 };
 template <typename T>
 struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };

@@ -1113,6 +1113,255 @@ __global__ void __launch_bounds__(512, 2) solve_split_kernel(SolveArgs<float> a)
     }
 }
 
+
+// Wide form of the split solver (see gen_forward_wide_kernel): all 8 stimuli in one chain per step, the state as two fp16
+// parts; a step is [chain] barrier [serial parts of both groups] barrier, the stop flags of a step are read by every
+// wave at the start of the next one.
+template <int MK, int WV>
+__device__ __forceinline__ void solve_wide_matrix_wave(const SolveArgs<float>& a, int b, int lane, char* bbuf, char* abuf,
+                                                        char* xbuf, unsigned* wmax, int (*flags)[8], int s0) {
+    using S = Split16<MK>;
+    constexpr int U0 = S::start(WV), U1 = S::start(WV + 1), NU = U1 - U0;
+    constexpr int RT0 = U0 / S::NKT, RT1 = (U1 - 1) / S::NKT, NT = RT1 - RT0 + 1;
+    constexpr bool HEAD_SHARED = (U0 % S::NKT) != 0;
+    const int M = a.M, max_iter = a.st.max_iter;
+    const int li = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
+    auto fetch = [&](int u, float (&w)[8]) {
+        const int row = 16 * (u / S::NKT) + li, k0 = 32 * (u % S::NKT) + 8 * lg;
+        const int voff = ((row < M ? row : M - 1) * M + k0) * 4;
+        const mf4 lo = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        const mf4 hi = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + 16, 0, 0));
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = (row < M && k0 + e < M) ? v[e] : 0.f;
+    };
+    float mx = 0.f;
+    for (int u = U0; u < U1; ++u) {
+        float w[8];
+        fetch(u, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
+    }
+    atomicMax(wmax, __builtin_bit_cast(unsigned, mx));
+    __syncthreads();                                                          // (A)
+    const float sa = split_w_scale(*wmax);
+    hv8 Ah[NU], Am[NU];
+#pragma unroll
+    for (int ui = 0; ui < NU; ++ui) {
+        float w[8];
+        fetch(U0 + ui, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = w[e] * sa;
+            const _Float16 h = (_Float16)sc;
+            Ah[ui][e] = h;
+            Am[ui][e] = (_Float16)(sc - (float)h);
+        }
+    }
+    using LdsH8 = const __attribute__((address_space(3))) hv8*;
+    using LdsF4 = __attribute__((address_space(3))) mf4*;
+    const unsigned boff = (unsigned)(lg * S::ROW + li * 16), boff_b = (unsigned)(lg * S::BROW + li * 16);
+    auto chain = [&]() {
+        const unsigned bb = (unsigned)(size_t)(LdsH8)bbuf + boff_b;
+        hv8 bt[S::NKT];
+#pragma unroll
+        for (int kt = 0; kt < S::NKT; ++kt) bt[kt] = *(LdsH8)(size_t)(bb + (unsigned)(kt * 4 * S::BROW));
+        mf4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < S::NKT; ++kt) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int u = (RT0 + t) * S::NKT + kt;
+                    if (u >= U0 && u < U1)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(part ? Am[u - U0] : Ah[u - U0], bt[kt], acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            char* dst = (t == 0 && HEAD_SHARED) ? xbuf + (WV - 1) * 4 * S::ROW : abuf + (RT0 + t) * 4 * S::ROW;
+            *(LdsF4)(size_t)((unsigned)(size_t)(LdsF4)dst + boff) = acc[t];
+        }
+    };
+    // bookkeeping identical in every wave (see solve_mfma_kernel)
+    bool my_frozen = lane >= 8 || s0 + lane >= a.NB;
+    unsigned frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
+    auto verdict = [&](int g, int f) {
+        const bool fnc = (f & 0xffff) != 0, fhb = (f >> 16) != 0;
+        const bool stop = lane < 8 && (lane >> 2) == g && !my_frozen && (!fnc || fhb);
+        my_frozen = my_frozen || stop;
+        frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
+    };
+    __syncthreads();                                                          // (B)
+    for (int it = 0; it <= max_iter; ++it) {
+        if (it >= 1) {                                // flags of step it - 1, both groups: complete since the last barrier
+            const int f4 = flags[(it - 1) % 3][lane & 7];
+            verdict(0, f4);
+            verdict(1, f4);
+        }
+        if (frozen == 0xffu) break;
+        if (it < max_iter) chain();
+        __syncthreads();                              // sums stored
+        __syncthreads();                              // new states stored
+    }
+}
+
+template <int MK>
+__global__ void __launch_bounds__(512, 2) solve_wide_kernel(SolveArgs<float> a) {
+    using S = Split16<MK>;
+    __shared__ __align__(16) char lds[S::LDS + 128];
+    char* const bbuf = lds;
+    char* const abuf = lds + 2 * S::BB;
+    char* const xbuf = abuf + 2 * S::AB;
+    char* const zrow = xbuf + 2 * S::XB;
+    unsigned* const wmax = reinterpret_cast<unsigned*>(zrow + S::ROW);       // [0] max |W|, [1] max |r0|
+    int (*flags)[8] = reinterpret_cast<int (*)[8]>(zrow + S::ROW + 32);       // [3][8]
+    const int M = a.M, N = a.N, max_iter = a.st.max_iter;
+    const int ngroups = (a.NB + 7) / 8;
+    const int b = blockIdx.x / ngroups;
+    const int s0 = (blockIdx.x % ngroups) * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < (S::LDS + 128) / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
+    __syncthreads();
+
+    if (wave < S::WM) {
+        switch (wave) {
+            case 0: solve_wide_matrix_wave<MK, 0>(a, b, lane, bbuf, abuf, xbuf, wmax, flags, s0); break;
+            case 1: solve_wide_matrix_wave<MK, 1>(a, b, lane, bbuf, abuf, xbuf, wmax, flags, s0); break;
+            case 2: solve_wide_matrix_wave<MK, 2>(a, b, lane, bbuf, abuf, xbuf, wmax, flags, s0); break;
+            default: solve_wide_matrix_wave<MK, 3>(a, b, lane, bbuf, abuf, xbuf, wmax, flags, s0); break;
+        }
+        return;
+    }
+
+    // ================================ serial wave ================================
+    const int sw = wave - S::WM;
+    const int blk = lane >> 2, j = lane & 3;
+    const int er = 64 * sw + 4 * blk;
+    int my_code = 1, my_steps = max_iter;
+    bool my_frozen = lane >= 8 || s0 + lane >= a.NB;
+    unsigned frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
+    auto verdict = [&](int g, int it, int f) {
+        const bool fnc = (f & 0xffff) != 0, fhb = (f >> 16) != 0;
+        const bool stop = lane < 8 && (lane >> 2) == g && !my_frozen && (!fnc || fhb);
+        my_code = stop ? (fnc ? 2 : 0) : my_code;
+        my_steps = stop ? it + 1 : my_steps;
+        my_frozen = my_frozen || stop;
+        frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
+    };
+    float eps[4], rc[2][4], rp[2][4], ex[2][4];
+    bool live[2], rowok[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { eps[v] = (er + v < N) ? a.st.eps_E : a.st.eps_I; rowok[v] = er + v < M; }
+    float r0max = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int s = s0 + 4 * g + j;
+        live[g] = s < a.NB;
+        const size_t vec = ((size_t)b * a.NB + (live[g] ? s : 0)) * M;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const bool ok = live[g] && er + v < M;
+            rc[g][v] = rp[g][v] = ok ? a.r[vec + er + v] : 0.f;
+            ex[g][v] = ok ? a.ext[(a.ext_per_draw ? vec : (size_t)s * M) + er + v] : 0.f;
+            r0max = fmaxf(r0max, __builtin_fabsf(rc[g][v]));
+        }
+    }
+    {
+        const unsigned wm0 = wave_max_bits(r0max);
+        if (lane == 0) atomicMax(wmax + 1, wm0);
+    }
+    const IoSelect io(a.io);
+    const int rt = er / 16 < S::NRT ? er / 16 : S::NRT - 1, rq = (er / 4) & 3;
+    const unsigned a_off = (unsigned)((rt * 4 + rq) * S::ROW + j * 16);
+    int x_slot = -1;
+#pragma unroll
+    for (int w = 1; w < S::WM; ++w)
+        if (S::start(w) % S::NKT != 0 && S::start(w) / S::NKT == rt) x_slot = w - 1;
+    const unsigned x_off = (unsigned)((x_slot * 4 + rq) * S::ROW + j * 16);
+    const bool b_live = er < 32 * S::NKT;
+    const unsigned b_off = (unsigned)(((er / 32) * 4 + ((er & 31) >> 3)) * S::BROW + j * 16 + ((er & 7) >> 2) * 8);
+    using LdsF4 = const __attribute__((address_space(3))) mf4*;
+    using LdsU2 = __attribute__((address_space(3))) uv2*;
+    __syncthreads();                                                          // (A) max |W|, max |r0|
+    // state scale: bound 2^rshift < 2^14 for bound = max(rate_hard_bound, max |r0|)
+    const float bound = fmaxf(a.io.hard, __builtin_bit_cast(float, wmax[1]));
+    int rshift = 13 - ((int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu) - 127);
+    rshift = rshift > 100 ? 100 : (rshift < -100 ? -100 : rshift);
+    const float usc = split_u_scale(*wmax, rshift);
+    const float rs = __builtin_bit_cast(float, (unsigned)(127 + rshift) << 23);
+    const fv2 rs01 = {er < M ? rs : 0.f, er + 1 < M ? rs : 0.f}, rs23 = {er + 2 < M ? rs : 0.f, er + 3 < M ? rs : 0.f};
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+        if (b_live) wide_store<2>(rc[g], rs01, rs23, (unsigned)(size_t)(LdsU2)bbuf + b_off + (unsigned)(64 * g), 0u);
+    auto serial = [&](auto G, int it) {
+        constexpr int g = decltype(G)::value;
+        const unsigned ab = (unsigned)(size_t)(LdsF4)abuf + a_off + (unsigned)(64 * g);      // columns 4 g + j and 8 + 4 g + j
+        const unsigned xb = x_slot < 0 ? (unsigned)(size_t)(LdsF4)zrow + (unsigned)(j * 16)
+                                       : (unsigned)(size_t)(LdsF4)xbuf + x_off + (unsigned)(64 * g);
+        const mf4 p0 = *(LdsF4)(size_t)ab, p1 = *(LdsF4)(size_t)(ab + 128u);
+        const mf4 q0 = *(LdsF4)(size_t)xb, q1 = *(LdsF4)(size_t)(xb + 128u);
+        const mf4 acc = (p0 + q0) + (p1 + q1);
+        const float accs[4] = {acc.x, acc.y, acc.z, acc.w};
+        float uu[4], ff[4], dummy[4], r1[4], dabs[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) uu[v] = fmaf(accs[v], usc, ex[g][v]);
+        io.template eval4<false>(uu, ff, dummy);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            r1[v] = rc[g][v] + (-rc[g][v] + ff[v]) * eps[v];                   // ssnode.c:64-67
+            dabs[v] = rowok[v] ? fabsf(r1[v] - rc[g][v]) : -1.f;
+        }
+        if (sw == 0 && lane < 4) flags[(it + 1) % 3][4 * g + lane] = 0;
+        if (live[g] && !((frozen >> (4 * g + j)) & 1u) && er < M) {
+            const float dmax = fmaxf(fmaxf(dabs[0], dabs[1]), fmaxf(dabs[2], dabs[3]));
+            const float rmax = fmaxf(fmaxf(r1[0], r1[1]), fmaxf(r1[2], r1[3]));
+            short* fw = reinterpret_cast<short*>(&flags[it % 3][4 * g + j]);
+            if (dmax >= a.st.atol) fw[0] = 1;
+            if (a.st.check_hard && rmax >= a.st.hard_stop) fw[1] = 1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { rp[g][v] = rc[g][v]; rc[g][v] = rowok[v] ? r1[v] : rc[g][v]; }
+            wide_store<2>(rc[g], rs01, rs23, (unsigned)(size_t)(LdsU2)bbuf + b_off + (unsigned)(64 * g), 0u);
+        }
+    };
+    constexpr std::integral_constant<int, 0> G0{};
+    constexpr std::integral_constant<int, 1> G1{};
+    __syncthreads();                                                          // (B)
+    for (int it = 0; it <= max_iter; ++it) {
+        if (it >= 1) {
+            const int f4 = flags[(it - 1) % 3][lane & 7];
+            verdict(0, it - 1, f4);
+            verdict(1, it - 1, f4);
+        }
+        if (frozen == 0xffu) break;
+        __syncthreads();                              // the chain of step it is done
+        if (it < max_iter) { serial(G0, it); serial(G1, it); }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!live[g]) continue;
+        const size_t unit = (size_t)b * a.NB + s0 + 4 * g + j;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if (er + v >= M) continue;
+            a.r[unit * M + er + v] = rc[g][v];
+            if (a.r_prev) a.r_prev[unit * M + er + v] = rp[g][v];
+        }
+    }
+    if (sw == 0 && lane < 8 && s0 + lane < a.NB) {
+        const size_t unit = (size_t)b * a.NB + s0 + lane;
+        a.codes[unit] = my_code;
+        if (a.steps) a.steps[unit] = my_steps;
+    }
+}
+
 static int split_pick_mk(int M) {
     const int ladder[] = {104, 152, 208};
     for (int mk : ladder) if (M <= mk) return mk;
@@ -1171,7 +1420,8 @@ bool solve_split_supported(const SolveArgs<float>& a) {
 }
 template <int MK>
 static hipError_t launch_solve_split_mk(const SolveArgs<float>& a, hipStream_t st) {
-    hipLaunchKernelGGL((solve_split_kernel<MK>), dim3(a.B * ((a.NB + 7) / 8)), dim3(512), 0, st, a);
+    if (gen_split_wide_parts() && !a.split_narrow) hipLaunchKernelGGL((solve_wide_kernel<MK>), dim3(a.B * ((a.NB + 7) / 8)), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((solve_split_kernel<MK>), dim3(a.B * ((a.NB + 7) / 8)), dim3(512), 0, st, a);
     return hipGetLastError();
 }
 hipError_t launch_solve_split(const SolveArgs<float>& a, hipStream_t st) {

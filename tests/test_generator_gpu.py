@@ -249,6 +249,46 @@ def test_split_kernel_error_against_fp64_is_that_of_the_fp32_kernels(case):
     np.testing.assert_allclose(ta[4], ta[6], rtol=1e-5, atol=2e-6 * ta[6].max())
 
 
+@pytest.mark.parametrize('N,B,NB,T,skip,taus', [(100, 2, 8, 300, 200, (10., 1.)), (101, 1, 6, 120, 100, (10., 1.)),
+                                                (50, 2, 8, 400, 390, (10., 1.)), (100, 2, 8, 300, 280, (0.5, 0.25))])
+def test_split_adjoint_matches_fp32_adjoint_step_by_step(N, B, NB, T, skip, taus):
+    """gen_backward_split_kernel (W^T as two fp16 parts, delta as three, scale following max |delta| with one step of
+    lag) against the fp32 MFMA adjoint on the SAME trajectory: delta_t of every step, normalised by that step's own
+    maximum.  With the short time constants of the last case the adjoint decays by many orders of magnitude before the
+    penalty window, which is what the moving scale has to follow."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    gen = dict(GEN, tau_E=taus[0], tau_I=taus[1])
+    jds, z, bws, con = _problem(N, B, NB, 5, T, skip, 1.0)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
+    rs = np.random.RandomState(2)
+    G = torch.as_tensor(rs.randn(B, NB, 2 * N) * (rs.rand(B, NB, 2 * N) < 0.05), device='cuda', dtype=torch.float32)
+    gp2 = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=1.0, kernel=2, **gen)
+    out = genops.gen_forward(W, ext, gp2, save=True)
+    res = {}
+    for kernel in (2, 4, 5, 6):
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=1.0, kernel=kernel, **gen)
+        d, gx = genops.gen_backward(W, out['traj'], out['df'].clone(), G, 1e-3, 1e-3, gp, want_g_ext=True)
+        res[kernel] = (d.cpu().numpy().astype('float64'), gx.cpu().numpy().astype('float64'))
+    d2, d4 = res[2][0], res[4][0]
+    assert np.isfinite(d4).all() and np.isfinite(d2).all()
+    per_step = np.abs(d2).max(axis=(0, 1, 3))                       # [T]; the last slot of the shifted stream is zero
+    assert per_step[:-1].max() > 0
+    live = per_step > 1e-30
+    err = np.abs(d4 - d2).max(axis=(0, 1, 3))[live] / per_step[live]
+    print('adjoint: max over steps of |split - fp32| / max|delta_t| = %.2e, dynamic range of max|delta_t| %.1e'
+          % (err.max(), per_step[live].max() / per_step[live].min()))
+    assert err.max() < 5e-6
+    if taus[0] < 1:
+        assert per_step[live].max() / per_step[live].min() > 1e6
+    np.testing.assert_allclose(res[4][1], res[2][1], rtol=1e-5, atol=1e-6 * np.abs(res[2][1]).max())
+    # (the adjoint has one form: kernels 4, 5 and 6 differ only in the groups per workgroup)
+    np.testing.assert_array_equal(res[5][0], res[6][0])
+    np.testing.assert_array_equal(res[4][0], res[6][0])
+    err6 = np.abs(res[6][0] - d2).max(axis=(0, 1, 3))[live] / per_step[live]
+    assert err6.max() < 5e-6
+
+
 @pytest.mark.parametrize('soft,hard,contrast', [(200., 1000., 2000.), (2000., 20000., 5e4), (0.2, 0.5, 20.), (200., 1000., 20.)])
 def test_split_kernel_at_the_rate_bound_and_with_other_bounds(soft, hard, contrast):
     """The state scale of the fp16-split forward comes from rate_hard_bound: saturated networks (rates at the bound),

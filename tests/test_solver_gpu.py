@@ -189,6 +189,8 @@ def test_test_inf_message():
     # variant 6: fp16-split MFMA kernel (asym_tanh only; W two fp16 parts, state three, exact products)
     (100, 8, 6, 'float32'), (100, 4, 6, 'float32'), (50, 5, 6, 'float32'), (101, 9, 6, 'float32'), (16, 11, 6, 'float32'),
     (76, 8, 6, 'float32'), (52, 8, 6, 'float32'),
+    # variant 7: the same in the alternating two-group form (state as three fp16 parts)
+    (100, 8, 7, 'float32'), (50, 5, 7, 'float32'), (101, 9, 7, 'float32'), (76, 8, 7, 'float32'),
     # fp64 resident shapes beyond 2N = 104: 4 rows per lane, 5-7 waves, one workgroup per CU (2N = 204 is the reference's
     # default N = 102: the truth-data path of every CLI run)
     (102, 1, 2, 'float64'), (102, 8, 2, 'float64'), (100, 3, 2, 'float64'), (76, 2, 2, 'float64'), (60, 1, 2, 'float64'),
@@ -200,7 +202,7 @@ def test_test_inf_message():
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
     from tc_gan_amd.ssnode import fixed_points_batch
-    if variant == 6 and io_type != 'asym_tanh':
+    if variant in (6, 7) and io_type != 'asym_tanh':
         pytest.skip('the fp16-split solver needs the rate bound of asym_tanh (refused otherwise: test below)')
     B, T = 6, 300
     Ws, exts = _inputs(N, B, NB, seed=N * 31 + NB)
@@ -216,14 +218,14 @@ def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
 
 @pytest.mark.parametrize('dtype,variant', [('float64', 0), ('float64', 1), ('float64', 2), ('float32', 1),
                                            ('float32', 2), ('float32', 0), ('float32', 3), ('float32', 4), ('float32', 5),
-                                           ('float32', 6)])
+                                           ('float32', 6), ('float32', 7)])
 def test_converging_batch_codes_steps_states(oracle_lib, dtype, variant):
     """Default solver settings (atol 1e-5, dt 8e-4): per-pair convergence step and state."""
     from tc_gan_amd.ssnode import fixed_points_batch
     N, B, NB = 50, 5, 8
     Ws, exts = _inputs(N, B, NB, seed=7)
     for io_type in ('asym_power', 'asym_tanh'):
-        if variant == 6 and io_type != 'asym_tanh':
+        if variant in (6, 7) and io_type != 'asym_tanh':
             continue
         want, wcodes, wsteps = _oracle_batch(oracle_lib, Ws, exts, io_type, 100000, 1e-5,
                                              hard=np.inf if io_type != 'asym_tanh' else 1000.)
