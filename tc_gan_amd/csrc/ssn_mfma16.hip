@@ -30,7 +30,9 @@
 //
 // Three kernels share the matrix-wave code: gen_forward_split_kernel (this comment), gen_backward_split_kernel (adjoint
 // sweep: W^T, delta with a scale that follows max |delta| step by step; any I/O function) and solve_split_kernel (the
-// fixed-point solver with its stop protocol; scale from max(rate bound, max |r0|)).
+// fixed-point solver with its stop protocol; scale from max(rate bound, max |r0|)).  Forward and solver also exist in a
+// WIDE form (gen_forward_wide_kernel, solve_wide_kernel: all 8 stimuli of a draw in one chain per step, the state as two
+// fp16 parts), which is what two-group launches run by default.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <type_traits>
