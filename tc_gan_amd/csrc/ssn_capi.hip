@@ -416,7 +416,7 @@ ssn::IoConsts<T> gen_io_consts(const ssn_gen_params& g) {
 // stimuli of the paper's runs -- else the tile kernels, which run one workgroup per (draw, stimulus)), 1 tile kernels,
 // 2 MFMA with two groups per workgroup, 3 MFMA with one group per workgroup.
 static int mfma_groups_for(int kernel, bool mfma_ok, int B, int NB) {
-    if (kernel == 2 || kernel == 4 || kernel == 6) return 2;
+    if (kernel == 2 || kernel == 4 || kernel == 6 || kernel == 8) return 2;
     if (kernel == 3 || kernel == 5) return 1;
     if (kernel != 0 || !mfma_ok) return 0;
     if ((long)B * ((NB + 7) / 8) >= 192) return 2;
@@ -442,12 +442,12 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
     if constexpr (sizeof(T) == 4) {
         // (trajectory stores address one draw's block with 32-bit byte offsets)
         const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (!traj || (long)NB * g->seqlen * M < (1L << 29));
-        if (g->kernel >= 2 && g->kernel <= 6 && !mfma_ok) {
+        if (g->kernel >= 2 && g->kernel <= 8 && (!mfma_ok || g->kernel == 7)) {
             g_last_error = "ssn_gen_forward: the MFMA kernels need fp32, NB >= 4 and 2N <= 208";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
         }
         const bool split_ok = mfma_ok && ssn::gen_split_rshift(a) >= 0;
-        if (g->kernel >= 4 && g->kernel <= 6 && !split_ok) {
+        if (g->kernel >= 4 && g->kernel <= 8 && !split_ok) {
             g_last_error = "ssn_gen_forward: the fp16-split MFMA kernel needs the saturating I/O function (asym_tanh), "
                            "rate_hard_bound < 3e4 and dt <= tau";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
@@ -456,7 +456,8 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
             a.mfma_groups = groups;
             a.split_narrow = g->kernel == 6;
             const bool split = g->kernel >= 4 || (g->kernel == 0 && split_ok && forward_split_default());
-            if (split) SSN_TRY(ssn::launch_gen_forward_split(a, (hipStream_t)stream));
+            if (g->kernel == 8) SSN_TRY(ssn::launch_gen_forward_duo(a, (hipStream_t)stream));
+            else if (split) SSN_TRY(ssn::launch_gen_forward_split(a, (hipStream_t)stream));
             else SSN_TRY(ssn::launch_gen_forward_mfma(a, (hipStream_t)stream));
             return 0;
         }
@@ -481,7 +482,7 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
     a.c_dyn = (T)c_dyn; a.c_rate = (T)c_rate;
     if constexpr (sizeof(T) == 4) {
         const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (long)NB * g->seqlen * M < (1L << 29);
-        if (g->kernel >= 2 && g->kernel <= 6 && !mfma_ok) {
+        if (g->kernel >= 2 && g->kernel <= 8 && !mfma_ok) {
             g_last_error = "ssn_gen_backward: the MFMA kernel needs fp32, NB >= 4 and 2N <= 208";
             return SSN_ERR_BASE + (int)hipErrorInvalidValue;
         }
@@ -740,9 +741,10 @@ int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ss
     a.io = gen_io_consts<float>(*g);
     const bool mfma_ok = ssn::gen_mfma_supported(M, NB) && (!save || (long)NB * seqlen * M < (1L << 29));
     const bool split_ok = mfma_ok && ssn::gen_split_rshift(a) >= 0;
-    if ((g->kernel >= 2 && g->kernel <= 6 && !mfma_ok) || (g->kernel >= 4 && !split_ok)) return -1;
+    if ((g->kernel >= 2 && g->kernel <= 8 && !mfma_ok) || (g->kernel >= 4 && !split_ok) || g->kernel == 7) return -1;
     const int groups = mfma_groups_for(g->kernel, mfma_ok, B, NB);
     if (!groups) return 1;
+    if (g->kernel == 8) return 8;
     const bool split = g->kernel >= 4 || (g->kernel == 0 && split_ok && forward_split_default());
     if (split && groups == 2 && (g->kernel == 6 || ssn::gen_split_wide_parts() == 0)) return 6;
     if (split && groups == 2 && ssn::gen_split_wide_parts() == 3) return 7;

@@ -59,6 +59,40 @@ struct IoSelect {
             }
         }
     }
+    // The same for NV values at once (the two-draw kernels of ssn_duo.hip finish 6 or 8 values per lane and step).
+    template <bool WANT_DF, int NV>
+    __device__ __forceinline__ void evaln(const float (&v)[NV], float (&f)[NV], float (&df)[NV]) const {
+        float pw[NV], rv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            pw[i] = __builtin_amdgcn_exp2f(fmaf(n, __builtin_amdgcn_logf(v[i]), log2k));
+            asm volatile("" : "+v"(pw[i]));
+        }
+        if (WANT_DF) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                rv[i] = n * pw[i] * __builtin_amdgcn_rcpf(v[i]);
+                asm volatile("" : "+v"(rv[i]));
+            }
+        }
+        float vmax = v[0];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f[i] = (v[i] < 0.f) ? 0.f : pw[i];
+            if (WANT_DF) df[i] = (v[i] > 0.f) ? rv[i] : 0.f;
+            if (i) asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(v[i]));      // (ignores NaN operands)
+        }
+        if (__builtin_amdgcn_ballot_w64(vmax > v0_low) != 0) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d = v[i] - v0;
+                const float th = tanh_pos(gain * d);
+                const bool high = v[i] > v0_low;
+                f[i] = high ? fmaf(c_tanh, th, fmaf(c_lin, d, soft)) : f[i];
+                if (WANT_DF) df[i] = high ? fmaf(c_tanh_gain, 1.f - th * th, c_lin) : df[i];
+            }
+        }
+    }
 };
 
 }  // namespace ssn

@@ -40,10 +40,15 @@ def _problem(N, B, NB, seed, T, skip, theta):
     (10, 3, 8, 'float32', 4), (33, 2, 5, 'float32', 4), (104, 1, 4, 'float32', 4), (90, 2, 8, 'float32', 4),
     (65, 1, 6, 'float32', 4), (102, 2, 8, 'float32', 4), (52, 2, 8, 'float32', 5), (100, 2, 8, 'float32', 5),
     # 6: two groups in the alternating form (state as three fp16 parts, exact); 4 is the wide form (two parts)
-    (100, 2, 8, 'float32', 6), (76, 1, 11, 'float32', 6), (33, 2, 5, 'float32', 6), (101, 1, 6, 'float32', 6)])
+    (100, 2, 8, 'float32', 6), (76, 1, 11, 'float32', 6), (33, 2, 5, 'float32', 6), (101, 1, 6, 'float32', 6),
+    # 8: two draws per workgroup, every wave both roles (csrc/ssn_duo.hip): odd and even unit counts, ragged stimulus
+    # groups, all three tile grids
+    (100, 2, 8, 'float32', 8), (100, 3, 8, 'float32', 8), (101, 1, 6, 'float32', 8), (76, 1, 11, 'float32', 8),
+    (10, 3, 8, 'float32', 8), (33, 2, 5, 'float32', 8), (104, 1, 4, 'float32', 8), (90, 2, 8, 'float32', 8),
+    (65, 1, 6, 'float32', 8), (102, 2, 8, 'float32', 8), (52, 5, 8, 'float32', 8), (50, 2, 9, 'float32', 8)])
 def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
     from tc_gan_amd import genops, stimuli, weight_gen
-    if kernel in (4, 5, 6) and io_type != 'asym_tanh':
+    if kernel in (4, 5, 6, 8) and io_type != 'asym_tanh':
         pytest.skip('the fp16-split kernel needs the rate bound of asym_tanh (refusal: test_split_kernel_refuses_...)')
     T, skip, theta = 60, 40, 2.0
     jds, z, bws, con = _problem(N, B, NB, N + NB, T, skip, theta)
@@ -78,7 +83,7 @@ def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
 def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype, kernel):
     """dL/dJ, dL/dD, dL/dS for L = sum(G * time_avg) + c_d * dyn_pen + c_r * rate_pen."""
     from tc_gan_amd import genops, stimuli, weight_gen
-    if kernel in (4, 5, 6) and io_type != 'asym_tanh':
+    if kernel in (4, 5, 6, 8) and io_type != 'asym_tanh':
         pytest.skip('the fp16-split kernel needs the rate bound of asym_tanh')
     T, skip, theta = 50, 30, 1.0
     jds, z, bws, con = _problem(N, B, NB, 7 * N + NB, T, skip, theta)
@@ -137,6 +142,32 @@ def test_compare_with_ssnode(num_sites, batchsize, seqlen, tol):
     np.testing.assert_allclose(out.model_time_avg.cpu().numpy(), fps, rtol=tol, atol=tol)
 
 
+@pytest.mark.parametrize('kernel', [2, 3, 4, 5, 6, 8])
+def test_compare_with_ssnode_on_every_matrix_core_kernel(kernel):
+    """The reference's long-horizon cross-test (networks/tests/test_euler_ssn.py:79-86: num_sites 100, seqlen 10000,
+    rtol = atol = 1e-4 against ssnode.sample_fixed_points(atol=1e-10)) with the forward kernel FORCED: with three draws the
+    library's own choice is the VALU tile kernel, so the case above never reaches the kernels that run every full-size
+    generator step -- fp32 MFMA (2 / 3), fp16-split wide form (4: W and state 22 bits), alternating forms (5 / 6: state
+    exact) and the two-draw form (8: state 23 bits by round to nearest)."""
+    from tc_gan_amd import genops, ssnode
+    from tc_gan_amd.networks.ssn import TuningCurveGenerator
+    from tc_gan_amd.networks.wgan import DEFAULT_PARAMS, grid_stimulator_inputs
+    jds = on.new_JDS()
+    num_sites, batchsize, seqlen, tol = 100, 3, 10000, 1e-4
+    bandwidths, contrasts = DEFAULT_PARAMS['bandwidths'], DEFAULT_PARAMS['contrasts']
+    con, bw = grid_stimulator_inputs(contrasts, bandwidths, batchsize)
+    zs, fps, info = ssnode.sample_fixed_points(batchsize, N=num_sites, bandwidths=bandwidths, contrast=contrasts,
+                                               seed=num_sites * batchsize, io_type='asym_tanh', atol=1e-10, **jds)
+    gen = TuningCurveGenerator(num_sites=num_sites, num_tcdom=len(bandwidths), smoothness=DEFAULT_PARAMS['smoothness'],
+                               J=jds['J'], D=jds['D'], S=jds['S'], k=DEFAULT_PARAMS['k'], n=DEFAULT_PARAMS['n'],
+                               tau_E=10, tau_I=1, dt=0.1, io_type='asym_tanh', seqlen=seqlen, skip_steps=seqlen - 1,
+                               batchsize=batchsize, probes=[0], include_time_avg=True)
+    gen.kernel = kernel
+    assert genops.forward_variant(batchsize, len(bandwidths), 2 * num_sites, gen.gen_params()) == kernel
+    out = gen.forward(stimulator_bandwidths=bw, stimulator_contrasts=con, model_zs=zs)
+    np.testing.assert_allclose(out.model_time_avg.cpu().numpy(), fps, rtol=tol, atol=tol)
+
+
 def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
     """C3 sizes (2N = 200, 8 stimuli, seqlen 1200 / skip 1000; 256 draws instead of 1024 to bound the 4 GB of
     trajectory per kernel): the fp32-MFMA kernels (two groups per workgroup and one), the fp16-split MFMA kernels (4, 5)
@@ -151,7 +182,7 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
     ext = stimuli.stimulus_batch(bws, np.full_like(bws, 20.0), P['smoothness'], N, dtype='float32')
     gta = torch.as_tensor(rs.rand(B, NB, 2 * N), device='cuda', dtype=torch.float32)
     res = {}
-    for kernel in (1, 2, 3, 4, 5, 6):
+    for kernel in (1, 2, 3, 4, 5, 6, 8):
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=kernel, **GEN)
         out = genops.gen_forward(W, ext, gp, save=True)
         delta = genops.gen_backward(W, out['traj'], out['df'], gta, 1e-3, 1e-3, gp)
@@ -161,7 +192,7 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
         del out, delta, gW
         torch.cuda.empty_cache()
     assert np.isfinite(res[1][0]).all() and res[1][0].max() > 1.0
-    for kernel in (2, 3, 4, 5, 6):
+    for kernel in (2, 3, 4, 5, 6, 8):
         np.testing.assert_allclose(res[kernel][0], res[1][0], rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(res[kernel][1], res[1][1], rtol=1e-3)
         np.testing.assert_allclose(res[kernel][2], res[1][2], rtol=1e-4)
@@ -207,13 +238,14 @@ def test_split_kernel_refuses_unbounded_io_functions():
     jds, z, bws, con = _problem(50, 2, 8, 3, 20, 10, 1.0)
     W = weight_gen.generate_weight_batch(50, jds['J'], jds['D'], jds['S'], z, dtype='float32')
     ext = stimuli.stimulus_batch(bws, con, P['smoothness'], 50, dtype='float32')
-    for io_type in ('asym_power', 'asym_linear'):
-        gp = genops.make_gen_params(seqlen=20, skip_steps=10, kernel=4, **dict(GEN, io_type=io_type))
+    for kernel in (4, 8):
+        for io_type in ('asym_power', 'asym_linear'):
+            gp = genops.make_gen_params(seqlen=20, skip_steps=10, kernel=kernel, **dict(GEN, io_type=io_type))
+            with pytest.raises(clib.SSNLibraryError):
+                genops.gen_forward(W, ext, gp)
+        gp = genops.make_gen_params(seqlen=20, skip_steps=10, kernel=kernel, **dict(GEN, dt=1.5))     # dt > tau_I: no bound
         with pytest.raises(clib.SSNLibraryError):
             genops.gen_forward(W, ext, gp)
-    gp = genops.make_gen_params(seqlen=20, skip_steps=10, kernel=4, **dict(GEN, dt=1.5))     # dt > tau_I: no bound
-    with pytest.raises(clib.SSNLibraryError):
-        genops.gen_forward(W, ext, gp)
 
 
 @pytest.mark.parametrize('case', ['plain', 'weak', 'tiny', 'strong-diagonal'])
@@ -235,16 +267,17 @@ def test_split_kernel_error_against_fp64_is_that_of_the_fp32_kernels(case):
     ta_o, dyn_o, rate_o = og.euler_ssn(og.t64(W.cpu().numpy()), og.t64(ext.cpu().numpy()), seqlen=T, skip_steps=skip,
                                        rate_penalty_threshold=2.0, **GEN)
     err, ta = {}, {}
-    for kernel in (2, 4, 5, 6):
+    for kernel in (2, 4, 5, 6, 8):
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=2.0, kernel=kernel, **GEN)
         ta[kernel] = genops.gen_forward(W, ext, gp)['time_avg'].cpu().numpy().astype('float64')
         assert np.isfinite(ta[kernel]).all()
         err[kernel] = np.abs(ta[kernel] - ta_o.numpy()).max() / np.abs(ta_o.numpy()).max()
-    print('%s: max error / max rate against fp64: fp32 MFMA %.2e, fp16-split wide (state 22 bits) %.2e, alternating '
-          '(state exact) %.2e' % (case, err[2], err[4], err[6]))
+    print('%s: max error / max rate against fp64: fp32 MFMA %.2e, fp16-split wide (state 22 bits, truncated) %.2e, alternating '
+          '(state exact) %.2e, two-draw form (state 23 bits, round to nearest) %.2e' % (case, err[2], err[4], err[6], err[8]))
     assert ta_o.numpy().max() > 0.1
-    assert err[2] < 2e-5 and err[4] < 2e-5 and err[6] < 2e-5
-    assert err[4] < 2.0 * err[2] + 2e-7 and err[6] < 2.0 * err[2] + 2e-7
+    assert err[2] < 2e-5 and err[4] < 2e-5 and err[6] < 2e-5 and err[8] < 2e-5
+    assert err[4] < 2.0 * err[2] + 2e-7 and err[6] < 2.0 * err[2] + 2e-7 and err[8] < 2.0 * err[2] + 2e-7
+    np.testing.assert_allclose(ta[8], ta[6], rtol=1e-5, atol=2e-6 * ta[6].max())
     np.testing.assert_array_equal(ta[6], ta[5])           # the alternating form with two groups per workgroup or one
     np.testing.assert_allclose(ta[4], ta[6], rtol=1e-5, atol=2e-6 * ta[6].max())
 
@@ -306,11 +339,13 @@ def test_split_kernel_at_the_rate_bound_and_with_other_bounds(soft, hard, contra
         ta_o = og.euler_ssn(og.t64(W.cpu().numpy()), og.t64(ext.cpu().numpy()), seqlen=T, skip_steps=skip,
                             rate_penalty_threshold=2.0, **gen)[0]
     ta = {}
-    for kernel in (2, 4, 6):
+    for kernel in (2, 4, 6, 8):
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=2.0, kernel=kernel,
                                     rate_soft_bound=soft, rate_hard_bound=hard, **gen)
         ta[kernel] = genops.gen_forward(W, ext, gp)['time_avg'].cpu().numpy().astype('float64')
     assert np.isfinite(ta[4]).all() and ta[4].max() <= hard * (1 + 1e-6)
+    assert np.isfinite(ta[8]).all() and ta[8].max() <= hard * (1 + 1e-6)
+    np.testing.assert_allclose(ta[8], ta[2], rtol=2e-5, atol=2e-6 * ta[2].max())
     if contrast >= 2000.:
         assert ta[4].max() > 0.9 * hard                    # really at the bound
     np.testing.assert_allclose(ta[4], ta[2], rtol=2e-5, atol=2e-6 * ta[2].max())
@@ -328,14 +363,15 @@ def test_split_kernels_propagate_nan_and_terminate():
     W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
     W[1, 7, 9] = float('nan')
     ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
-    gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=4, **GEN)
-    out = genops.gen_forward(W, ext, gp, save=True)
-    ta = out['time_avg'].cpu().numpy()
-    assert np.isfinite(ta[0]).all()                        # the other draw is untouched
-    assert np.isnan(ta[1]).any()
-    G = torch.ones((B, NB, 2 * N), device='cuda', dtype=torch.float32)
-    d = genops.gen_backward(W, out['traj'], out['df'], G, 1e-3, 1e-3, gp).cpu().numpy()
-    assert np.isfinite(d[0]).all() and np.isnan(d[1]).any()
+    for kernel in (4, 8):                                      # (8: the two draws share a workgroup)
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=kernel, **GEN)
+        out = genops.gen_forward(W, ext, gp, save=True)
+        ta = out['time_avg'].cpu().numpy()
+        assert np.isfinite(ta[0]).all()                        # the other draw is untouched
+        assert np.isnan(ta[1]).any()
+        G = torch.ones((B, NB, 2 * N), device='cuda', dtype=torch.float32)
+        d = genops.gen_backward(W, out['traj'], out['df'], G, 1e-3, 1e-3, gp).cpu().numpy()
+        assert np.isfinite(d[0]).all() and np.isnan(d[1]).any()
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])
@@ -376,7 +412,7 @@ def test_split_kernels_random_shapes_against_the_fp32_mfma_kernels():
         ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
         G = torch.as_tensor(rs.randn(B, NB, 2 * N), device='cuda', dtype=torch.float32)
         res = {}
-        for kernel in (2, 4, 5, 6):
+        for kernel in (2, 4, 5, 6, 8):
             gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=1.0, kernel=kernel, **GEN)
             out = genops.gen_forward(W, ext, gp, save=True)
             keep = [out[k].cpu().numpy().astype('float64') for k in ('time_avg', 'traj', 'df')]
@@ -384,7 +420,7 @@ def test_split_kernels_random_shapes_against_the_fp32_mfma_kernels():
             d, gx = genops.gen_backward(W, out['traj'], out['df'], G, 1e-2, 1e-2, gp, want_g_ext=True)
             res[kernel] = keep + [d.cpu().numpy().astype('float64'), gx.cpu().numpy().astype('float64')]
         tag = 'case %d: N=%d B=%d NB=%d T=%d skip=%d' % (case, N, B, NB, T, skip)
-        for kernel in (4, 5, 6):
+        for kernel in (4, 5, 6, 8):
             for got, want in zip(res[kernel], res[2]):
                 got, want = np.asarray(got), np.asarray(want)
                 assert np.isfinite(got).all(), tag

@@ -445,3 +445,21 @@ def test_split_solver_initial_states_beyond_the_rate_bound_and_refusals():
     assert np.isfinite(a.x).all()
     with pytest.raises(clib.SSNLibraryError):
         fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=10, atol=0.0, io_type='asym_power', dtype='float32', variant=6)
+
+
+@pytest.mark.parametrize('variant', [2, 5, 6, 7, 8])
+def test_fp32_solver_kernels_reach_the_fp64_fixed_points(variant):
+    """The reference pins its fixed-time network against `sample_fixed_points(atol=1e-10)` at 1e-4 after 10000 steps
+    (networks/tests/test_euler_ssn.py:79-86).  The same bar for the fp32 fixed-point solver kernels themselves, each
+    FORCED (tile 2, fp32 MFMA 5, fp16-split wide 6 / alternating 7, two-draw form 8): 10000 Euler steps of the
+    solver's own form (ssnode.c:64-67) from r = 0 on the fp32 weights against the fp64 fixed points of the same draws."""
+    from tc_gan_amd import ssnode, stimuli, weight_gen
+    N, B = 100, 3
+    jds = on.new_JDS()
+    zs, fps, _ = ssnode.sample_fixed_points(B, N=N, seed=N * B, io_type='asym_tanh', atol=1e-10, **jds)
+    exts = stimuli.input(P['bandwidths'], np.linspace(-0.5, 0.5, N), P['smoothness'], P['contrast'], P['offset'])
+    Ws = np.stack([weight_gen.generate_weight(N, jds['J'], jds['D'], jds['S'], z) for z in zs])
+    res = ssnode.fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=10000, atol=0.0, io_type='asym_tanh',
+                                    dtype='float32', variant=variant)
+    np.testing.assert_array_equal(res.codes, 1)
+    np.testing.assert_allclose(res.x, np.asarray(fps), rtol=1e-4, atol=1e-4)

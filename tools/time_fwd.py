@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""HIP-event timing of the plain generator forward at the C3 shape (1024 draws x 8 stimuli x 1200 steps, 2N = 200) for
+a list of kernel codes.  usage: tools/time_fwd.py [kernel ...] [--save] [--draws B]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tc_gan_amd import genops  # noqa: E402
+
+
+def timed(fn, n=5):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    args = sys.argv[1:]
+    save = '--save' in args
+    B = int(args[args.index('--draws') + 1]) if '--draws' in args else 1024
+    kernels = [int(a) for a in args if a.isdigit() and (args.index(a) == 0 or args[args.index(a) - 1] != '--draws')] or [4, 8]
+    NB, M, T, skip = 8, 200, 1200, 1000
+    g = torch.Generator(device='cuda'); g.manual_seed(1)
+    W = (torch.rand((B, M, M), device='cuda', generator=g) - 0.6) * 0.02
+    ext = torch.rand((B, NB, M), device='cuda', generator=g) * 20
+    ref = None
+    for k in kernels:
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=k)
+        ms = timed(lambda: genops.gen_forward(W, ext, gp, save=save))
+        ta = genops.gen_forward(W, ext, gp)['time_avg']
+        if ref is None:
+            ref = ta
+        print('kernel %d: forward%s %.3f ms   max |time_avg - first kernel| %.3e (max %.3e)' % (
+            k, ' + stores' if save else '', ms, float((ta - ref).abs().max()), float(ref.abs().max())), flush=True)
+
+
+if __name__ == '__main__':
+    main()
