@@ -127,6 +127,22 @@ int ssn_solve_batch_f64_variant(int variant, const double *W, const double *ext,
                                 double *r, double *r_prev, int *codes, int *steps,
                                 int B, int NB, int M, const ssn_solver_params *p, void *stream);
 
+/* The variant (numbering above) that ssn_solve_batch_f32 / _f64 (dtype_bytes 4 / 8) picks by itself for this call shape
+ * and these parameters under the current operand-precision setting; -1: the call would be refused.  Nothing is launched.
+ * For benchmarks and logs that must name the kernel that ran. */
+int ssn_solve_batch_variant_for(int B, int NB, int M, int dtype_bytes, const ssn_solver_params *p);
+
+/* Operand precision of the AUTOMATIC kernel choice (ssn_solve_batch_* without a variant, ssn_gen_params.kernel = 0) on the
+ * fp32 paths with NB >= 4 stimuli per draw.  Process-wide, atomic, takes effect with the next call; explicit variants /
+ * kernel codes are never overridden.
+ *   1 (initial value): the fp16-split matrix-core kernels where they apply (saturating I/O function, dt <= tau): W and the
+ *      state enter the products as two fp16 parts each (23 significant bits by round to nearest in the two-draw form,
+ *      22 by truncation of the state in the older wide form), every product exact, fp32 accumulation;
+ *   0: fp32 operands only (fp32 MFMA / VALU kernels): the reference's floatX arithmetic.
+ * The environment variable SSN_FWD_SPLIT=0 selects 0 as the initial value.  Returns the previous setting. */
+int ssn_set_operand_precision(int mode);
+int ssn_get_operand_precision(void);
+
 /* Host-buffer convenience forms of the above (numpy callers): allocate,
  * copy in, solve, copy out, synchronise.  Same argument meaning, host
  * pointers.  The PCIe copies are inside the call. */

@@ -7,6 +7,7 @@ same argtypes/restype for the eight reference symbols, plus the additive
 batched ABI declared in ``include/ssnode_mi355x.h``.
 """
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_long, c_void_p
+import collections
 import ctypes
 import os
 
@@ -253,7 +254,52 @@ DECLARED_SYMBOLS = (
     'ssn_weight_grad_f32', 'ssn_weight_grad_f64', 'ssn_lu_solve_f32', 'ssn_lu_solve_f64',
     'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
     'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
+    'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for',
 )
+
+libssnode.ssn_set_operand_precision.argtypes = [c_int]
+libssnode.ssn_set_operand_precision.restype = c_int
+libssnode.ssn_get_operand_precision.argtypes = []
+libssnode.ssn_get_operand_precision.restype = c_int
+libssnode.ssn_solve_batch_variant_for.argtypes = [c_int, c_int, c_int, c_int, POINTER(SolverParams)]
+libssnode.ssn_solve_batch_variant_for.restype = c_int
+
+#: names of the generator kernel families (`ssn_gen_params.kernel`, include/ssnode_mi355x.h) as the Python API and the
+#: command line spell them: TuningCurveGenerator(gen_kernel=...), --gen-kernel
+GEN_KERNELS = collections.OrderedDict([
+    ('auto', 0),          # library's choice under the current operand-precision setting
+    ('tile', 1),          # VALU tile kernels, fp32 operands
+    ('mfma-fp32', 2),     # fp32 matrix-core kernels (two 4-stimulus groups per workgroup), fp32 operands
+    ('mfma-fp32-1g', 3),  # the same, one group per workgroup (few draws)
+    ('split-wide', 4),    # fp16-split matrix-core kernel, all 8 stimuli in one chain (W and state 22-23 bits)
+    ('split-1g', 5),      # fp16-split, one group per workgroup (state exact)
+    ('split-alt', 6),     # fp16-split, two alternating groups (state exact)
+    ('duo', 8),           # fp16-split, two draws per workgroup (W and state 23 bits by round to nearest)
+])
+OPERAND_PRECISIONS = {'fp32': 0, 'split': 1}
+
+
+def gen_kernel_code(kernel):
+    """'auto' / 'duo' / ... or the integer code -> the integer code of `ssn_gen_params.kernel`."""
+    if isinstance(kernel, str):
+        if kernel not in GEN_KERNELS:
+            raise ValueError('Unknown generator kernel {!r}; choose from {}'.format(kernel, ', '.join(GEN_KERNELS)))
+        return GEN_KERNELS[kernel]
+    kernel = int(kernel)
+    if kernel not in GEN_KERNELS.values():
+        raise ValueError('Unknown generator kernel code {}'.format(kernel))
+    return kernel
+
+
+def set_operand_precision(mode):
+    """'fp32' or 'split': operand precision of the library's AUTOMATIC kernel choice (`ssn_set_operand_precision`);
+    returns the previous setting by name.  Explicit kernel choices are not affected."""
+    prev = libssnode.ssn_set_operand_precision(OPERAND_PRECISIONS[mode])
+    return 'split' if prev else 'fp32'
+
+
+def get_operand_precision():
+    return 'split' if libssnode.ssn_get_operand_precision() else 'fp32'
 
 
 class GPUUnavailableError(RuntimeError):

@@ -1,5 +1,6 @@
 // extern "C" surface of libssnode.so (see include/ssnode_mi355x.h).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,17 +27,21 @@ int fail(hipError_t e, const char* where) {
         if (e__ != hipSuccess) return fail(e__, #expr);   \
     } while (0)
 
-// SSN_FWD_SPLIT=0 keeps the automatic choice on the fp32 MFMA kernel (A/B timing, and for anyone who wants W carried
-// with all 24 bits)
-static bool forward_split_default() {
-    static const bool on = [] { const char* e = getenv("SSN_FWD_SPLIT"); return !(e && e[0] == '0'); }();
-    return on;
+// Operand precision of the AUTOMATIC kernel choice (kernel = 0, variant < 0): process-wide state behind
+// ssn_set_operand_precision / ssn_get_operand_precision (include/ssnode_mi355x.h).  1 = the fp16-split matrix-core kernels
+// where they apply (W and state as two fp16 parts each), 0 = fp32 operands only.  The environment variable SSN_FWD_SPLIT=0
+// only sets the INITIAL value; callers change it at run time through the API and explicit kernel codes ignore it.
+static std::atomic<int>& operand_precision_state() {
+    static std::atomic<int> st{[] { const char* e = getenv("SSN_FWD_SPLIT"); return (e && e[0] == '0') ? 0 : 1; }()};
+    return st;
 }
+static bool forward_split_default() { return operand_precision_state().load(std::memory_order_relaxed) != 0; }
 template <typename T>
 int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T* r, T* r_prev, int* codes,
-                     int* steps, int B, int NB, int M, const ssn_solver_params* p, void* stream) {
-    if (B == 0 || NB == 0) return 0;   // empty batch: nothing to do (pointers may be null)
-    if (!p || !W || !ext || !r || !codes || B < 0 || NB < 0 || M <= 0 || (M & 1) || p->io_type < 0 ||
+                     int* steps, int B, int NB, int M, const ssn_solver_params* p, void* stream, bool dry_run = false) {
+    // dry_run: no pointers, nothing is launched; returns the variant the call would run (ssn_solve_batch_variant_for)
+    if ((B == 0 || NB == 0) && !dry_run) return 0;   // empty batch: nothing to do (pointers may be null)
+    if (!p || (!dry_run && (!W || !ext || !r || !codes)) || B < 0 || NB < 0 || M <= 0 || (M & 1) || p->io_type < 0 ||
         p->io_type > 2 || p->max_iter < 0) {
         g_last_error = "ssn_solve_batch: invalid argument";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
@@ -49,14 +54,15 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     hipStream_t st = (hipStream_t)stream;
     // variant: -1 auto (MFMA for large fp32 NB >= 4 batches, else tile > regw > stream), 0 streaming, 1 register-stationary DPP, 2 tile (shape chosen by
     // the library), 3 tile with split VGPR/LDS residency where instantiated, 4 tile with the whole W tile in VGPRs,
-    // 5 fp32 MFMA kernel (NB >= 4), 6 fp16-split MFMA kernel (NB >= 4, asym_tanh; wide form), 7 the same in the alternating form
+    // 5 fp32 MFMA kernel (NB >= 4), 6 fp16-split MFMA kernel (NB >= 4, asym_tanh; wide form), 7 the same in the alternating form,
+    // 8 fp16-split MFMA kernel with two draws per workgroup (ssn_duo.hip)
     const bool tile_ok = ssn::tile_supported<T>(M, NB), regw_ok = ssn::regw_supported<T>(M, NB);
     bool mfma_ok = false;
     if constexpr (sizeof(T) == 4) mfma_ok = ssn::gen_mfma_supported(M, NB);
     bool split_ok = false;
     if constexpr (sizeof(T) == 4) split_ok = mfma_ok && ssn::solve_split_supported(a);
     if ((variant == 1 && !regw_ok) || (variant >= 2 && variant <= 4 && !tile_ok) || (variant == 5 && !mfma_ok) ||
-        ((variant == 6 || variant == 7) && !split_ok) || variant > 7) {
+        ((variant == 6 || variant == 7 || variant == 8) && !split_ok) || variant > 8) {
         g_last_error = "ssn_solve_batch: requested kernel variant has no instantiation for this size";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
@@ -67,6 +73,7 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
         const bool big = (long)B * ((NB + 7) / 8) >= 192 && M > 104;
         variant = (mfma_ok && big) ? ((split_ok && forward_split_default()) ? 6 : 5) : (tile_ok ? 2 : (regw_ok ? 1 : 0));
     }
+    if (dry_run) return variant;
     switch (variant) {
         case 2: SSN_TRY(ssn::launch_tile<T>(a, st, 0)); break;
         case 3: SSN_TRY(ssn::launch_tile<T>(a, st, 1)); break;
@@ -74,6 +81,7 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
         case 5: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_mfma(a, st)); } break;
         case 6: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_split(a, st)); } break;
         case 7: if constexpr (sizeof(T) == 4) { a.split_narrow = 1; SSN_TRY(ssn::launch_solve_split(a, st)); } break;
+        case 8: if constexpr (sizeof(T) == 4) { SSN_TRY(ssn::launch_solve_duo(a, st)); } break;
         case 1: SSN_TRY(ssn::launch_regw<T>(a, st)); break;
         default: SSN_TRY(ssn::launch_stream<T>(a, st)); break;
     }
@@ -731,6 +739,18 @@ int ssn_moment_loss_grad_f32(const float* x, const double* sums, double global_b
     }
     SSN_TRY(ssn::launch_moment_loss_grad(x, sums, global_batch, data_moments, weights, B, D, gx, out, (hipStream_t)stream));
     return 0;
+}
+
+int ssn_set_operand_precision(int mode) {
+    return operand_precision_state().exchange(mode ? 1 : 0);
+}
+int ssn_get_operand_precision(void) { return operand_precision_state().load(); }
+int ssn_solve_batch_variant_for(int B, int NB, int M, int dtype_bytes, const ssn_solver_params* p) {
+    if (B <= 0 || NB <= 0) return -1;
+    const int v = dtype_bytes == 8
+        ? solve_batch_impl<double>(-1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, B, NB, M, p, nullptr, true)
+        : solve_batch_impl<float>(-1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, B, NB, M, p, nullptr, true);
+    return v >= SSN_ERR_BASE ? -1 : v;
 }
 
 int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ssn_gen_params* g) {

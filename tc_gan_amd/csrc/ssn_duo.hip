@@ -38,7 +38,16 @@
                                 // 4 / 8 = serial part / chain at s_setprio 1
 #endif
 
+#ifndef SSN_DUO_STAMP
+#define SSN_DUO_STAMP 0         // diagnostic build: s_memtime stamps of workgroup 0 (waves 0 and 4) summed per segment into
+                                // duo_stamps[] (read back by ssn_debug_duo_stamps; tools/time_fwd.py prints them)
+#endif
+
 namespace ssn {
+
+#if SSN_DUO_STAMP
+__device__ unsigned long long duo_stamps[16];
+#endif
 
 typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
 typedef _Float16 hv2 __attribute__((ext_vector_type(2)));
@@ -64,6 +73,12 @@ struct Duo16 {
     static constexpr int XS = 1024;                                      // one partial-sum slot: 64 lanes x 16 B
     static constexpr int SYNC = 2 * BB + (WM - 1) * XS;                  // free-running form: [0] finished (wave, step) pairs, [1 + w] steps whose partial sum wave w has stored
     static constexpr int DRAW = SYNC + 32;                               // per draw: two B images (step parity), slots of waves 0 .. WM - 2, sync words
+    // Kernels whose serial part needs more registers than the plain forward's (trajectory stores, the solver's stop
+    // protocol) keep the low parts (W_m) of the last NL units of every wave in LDS instead of registers (one 16-byte operand
+    // per lane and unit, re-read every step) -- otherwise they spill into the time loop.  Measured at C3 / C2 with 8 stimuli:
+    // plain forward 3.38 ms with NL = 0 against 3.67 with 4 (the extra reads sit on the chain's critical path, and it did not
+    // spill); forward with stores 6.1 -> 5.6 ms, solver 40.2 -> 34.3 ms with NL = 4.
+    static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? 4 : 0; }
     static constexpr int LDS = 2 * DRAW + 16;
     static_assert(start(1) >= NKT, "a row tile is shared by at most two waves");
 };
@@ -93,13 +108,83 @@ __device__ __forceinline__ float dpp_ror8(float x) {                  // lane li
 }
 
 // x 2^rshift = h + m by round to nearest, two values per call; returns the packed fp16 pairs
+// (plain fp32 instructions on purpose: beside a partner wave's MFMA stream a packed v_pk_*_f32 costs several times its
+// two scalar halves -- MI355X_MICROARCH.md, cycle constants; this file is built with -fno-slp-vectorize for the same reason)
 __device__ __forceinline__ void duo_split2(float x0, float x1, float rs, unsigned& h, unsigned& m) {
-    const fv2 s = (fv2){x0, x1} * (fv2){rs, rs};
-    const hv2 hh = __builtin_convertvector(s, hv2);
-    const fv2 d = s - __builtin_convertvector(hh, fv2);
+    const float s0 = x0 * rs, s1 = x1 * rs;
+    const hv2 hh = __builtin_convertvector((fv2){s0, s1}, hv2);
+    const float d0 = s0 - (float)hh[0], d1 = s1 - (float)hh[1];
     h = __builtin_bit_cast(unsigned, hh);
-    m = __builtin_bit_cast(unsigned, __builtin_convertvector(d, hv2));
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector((fv2){d0, d1}, hv2));
 }
+
+// A wave's share of W (two fp16 parts of W 2^a) and its MFMA chain.
+template <int MK, int WV, int NL>
+struct DuoOperands {
+    using S = Duo16<MK>;
+    using WS = DuoWave<MK, WV>;
+    static constexpr int NU = WS::NU, NT = WS::NT, RT0 = WS::RT0, U0 = WS::U0, U1 = WS::U1, NR = NU - NL;
+    using LdsH8 = __attribute__((address_space(3))) hv8*;
+    hv8 Ah[NU], Am[NR > 0 ? NR : 1];
+    unsigned wl;                                  // LDS byte address of this lane's slot of the first LDS-resident unit
+
+    // pass 1 over the wave's units: max |W|
+    static __device__ __forceinline__ float max_abs(const __amdgpu_buffer_rsrc_t& rsrc, int M, int li, int lg) {
+        float mx = 0.f;
+        for (int u = U0; u < U1; ++u) {
+            float w[8];
+            duo_fetch(rsrc, M, 16 * (u / S::NKT) + li, 32 * (u % S::NKT) + 8 * lg, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
+        }
+        return mx;
+    }
+    // pass 2: W 2^a = W_h + W_m by round to nearest
+    __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t& rsrc, int M, int li, int lg, float sa, char* wlds, int lane) {
+        wl = (unsigned)(size_t)(LdsH8)wlds + (unsigned)(lane * 16);
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui) {
+            float w[8];
+            duo_fetch(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, w);
+            hv8 m;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sc = w[e] * sa;
+                const _Float16 h = (_Float16)sc;
+                Ah[ui][e] = h;
+                m[e] = (_Float16)(sc - (float)h);
+            }
+            if (ui < NR) Am[ui < NR ? ui : 0] = m;
+            else *(LdsH8)(size_t)(wl + (unsigned)((ui - NR) * 1024)) = m;
+        }
+    }
+    // acc[t] = (W_h + W_m)[row tile RT0 + t, my k range] . B, B read from the image at LDS byte address rd (per lane)
+    __device__ __forceinline__ void chain(unsigned rd, mf4 (&acc)[NT]) const {
+        using LdsB = const __attribute__((address_space(3))) hv8*;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < S::NKT; ++kt) {
+            const hv8 b1 = *(LdsB)(size_t)(rd + (unsigned)(kt * 4 * S::BROW));
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int u = (RT0 + t) * S::NKT + kt;
+                    if (u >= U0 && u < U1) {
+                        const int ui = u - U0;
+                        hv8 aop;
+                        if (part == 0) aop = Ah[ui];
+                        else if (ui < NR) aop = Am[ui < NR ? ui : 0];
+                        else aop = *(LdsB)(size_t)(wl + (unsigned)((ui - NR) * 1024));
+                        if (SSN_DUO_ABLATE & 2) acc[t].x += (float)aop[0] * (float)b1[0];   // (one FMA per MFMA)
+                        else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aop, b1, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+};
 
 // Hand-over words in LDS (free-running form).  DS instructions of one wave execute in program order, so a counter bumped
 // after the data stores of the same wave is seen only after them; the waiting side reads the word, then the data.
@@ -122,42 +207,44 @@ __device__ __forceinline__ void duo_wait_ge(unsigned addr, int target, bool& dea
     }
 }
 
+// f(u), f'(u) for the NE values of a lane; eight values go through in two halves (fewer values in flight at once: the
+// wave that finishes four row tiles is the one short of registers)
+template <bool WANT_DF, int NE>
+__device__ __forceinline__ void duo_eval(const IoSelect& io, const float (&uu)[NE], float (&ff)[NE], float (&dfn)[NE]) {
+    if constexpr (NE == 8) {
+        float u4[4], f4[4], d4[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { u4[i] = uu[4 * h + i]; d4[i] = 0.f; }
+            io.template evaln<WANT_DF, 4>(u4, f4, d4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ff[4 * h + i] = f4[i]; dfn[4 * h + i] = d4[i]; }
+        }
+    } else {
+        io.template evaln<WANT_DF, NE>(uu, ff, dfn);
+    }
+}
+
 template <int MK, int WV, bool SAVE, bool FREE>
 __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int rshift, int d, int b, int s0, bool valid,
-                                                 int lane, char* dlds, unsigned* wmax) {
+                                                 int lane, char* dlds, char* wlds, unsigned* wmax) {
     using S = Duo16<MK>;
     using WS = DuoWave<MK, WV>;
-    constexpr int NU = WS::NU, NT = WS::NT, NTF = WS::NTF, RT0 = WS::RT0, U0 = WS::U0, U1 = WS::U1;
+    constexpr int NT = WS::NT, NTF = WS::NTF, RT0 = WS::RT0;
     constexpr int NE = 2 * NTF;
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
     const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
     // ---- W: pass 1 = max |W| of the draw, pass 2 = the two fp16 parts of W 2^a
-    float mx = 0.f;
-    for (int u = U0; u < U1; ++u) {
-        float w[8];
-        duo_fetch(rsrc, M, 16 * (u / S::NKT) + li, 32 * (u % S::NKT) + 8 * lg, w);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
-    }
-    atomicMax(wmax, __builtin_bit_cast(unsigned, mx));
+    using Ops = DuoOperands<MK, WV, S::nl(SAVE)>;
+    atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)));
     __syncthreads();                                                          // (A)
     const int wexp = duo_w_exp(*wmax);
     const float sa = duo_pow2(wexp), usc = duo_pow2(-wexp - rshift), rs = duo_pow2(rshift);
-    hv8 Ah[NU], Am[NU];
-#pragma unroll
-    for (int ui = 0; ui < NU; ++ui) {
-        float w[8];
-        duo_fetch(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, w);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float sc = w[e] * sa;
-            const _Float16 h = (_Float16)sc;
-            Ah[ui][e] = h;
-            Am[ui][e] = (_Float16)(sc - (float)h);
-        }
-    }
+    Ops ops;
+    ops.load(rsrc, M, li, lg, sa, wlds, lane);
     // ---- the values this lane finishes: row tile RT0 + tf, rows 4 lg + 2 hi + e, stimulus s0 + st
     const IoSelect io(a.io);
     const int s = s0 + st;
@@ -194,24 +281,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     auto chain = [&](int it) {
         // free-running form: all four waves of the draw must have stored the state of step it - 1 (image it & 1)
         if (FREE && it > 0) duo_wait_ge(sync, S::WM * it, dead);
-        const unsigned rd = b_rd + (FREE ? (unsigned)((it & 1) * S::BB) : 0u);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kt = 0; kt < S::NKT; ++kt) {
-            const hv8 b1 = *(LdsH8)(size_t)(rd + (unsigned)(kt * 4 * S::BROW));
-#pragma unroll
-            for (int part = 0; part < 2; ++part) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int u = (RT0 + t) * S::NKT + kt;
-                    if (u >= U0 && u < U1) {
-                        if (SSN_DUO_ABLATE & 2) acc[t].x += (float)(part ? Am[u - U0] : Ah[u - U0])[0] * (float)b1[0];   // (one FMA per MFMA)
-                        else acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(part ? Am[u - U0] : Ah[u - U0], b1, acc[t], 0, 0, 0);
-                    }
-                }
-            }
-        }
+        ops.chain(b_rd + (FREE ? (unsigned)((it & 1) * S::BB) : 0u), acc);
         if constexpr (WS::TAIL_SHARED) {
             *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
             if (FREE) duo_signal_set(sync + 4u * (1 + WV), (unsigned)(it + 1), lane);
@@ -226,7 +296,8 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             if constexpr (WS::HEAD_SHARED) {
                 if (tf == 0) {
                     if (FREE) duo_wait_ge(sync + 4u * WV, it + 1, dead);          // wave WV - 1 has stored its partial sum of step it
-                    sm += *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                    const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                    sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
                 }
             }
             // lane s (hi = 0) keeps rows 0, 1 and offers rows 2, 3 of its part; lane 8 + s keeps 2, 3 and offers 0, 1
@@ -241,7 +312,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 #pragma unroll
             for (int i = 0; i < NE; ++i) ff[i] = uu[i];
         } else {
-            io.template evaln<SAVE, NE>(uu, ff, dfn);
+            duo_eval<SAVE, NE>(io, uu, ff, dfn);
         }
         const float win2 = (it > a.skip) ? 1.f : 0.f;
 #pragma unroll
@@ -283,12 +354,37 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
         for (int it = nskip; it < T_; ++it) { chain(it); serial(W1, it); }
     } else {
         if (d) __syncthreads();                        // draw 1 runs one phase behind draw 0
+#if SSN_DUO_STAMP
+        unsigned long long tc = 0, tb1 = 0, ts = 0, tb2 = 0;
+        for (int it = 0; it < nskip; ++it) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            chain(it);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            serial(W0, it);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            tc += t1 - t0; tb1 += t2 - t1; ts += t3 - t2; tb2 += t4 - t3;
+        }
+        if (blockIdx.x == 0 && WV == 0 && lane == 0) {
+            duo_stamps[4 * d + 0] = tc; duo_stamps[4 * d + 1] = tb1; duo_stamps[4 * d + 2] = ts; duo_stamps[4 * d + 3] = tb2;
+            duo_stamps[8] = (unsigned long long)nskip;
+        }
+        if (blockIdx.x == 0 && WV == 3 && lane == 0) {
+            duo_stamps[9 + 3 * d + 0] = tc; duo_stamps[9 + 3 * d + 1] = ts; duo_stamps[9 + 3 * d + 2] = tb1 + tb2;
+        }
+#else
         for (int it = 0; it < nskip; ++it) {
             chain(it);
             __syncthreads();
             serial(W0, it);
             __syncthreads();
         }
+#endif
         for (int it = nskip; it < T_; ++it) {
             chain(it);
             __syncthreads();
@@ -316,7 +412,8 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 template <int MK, bool SAVE, bool FREE>
 __global__ void __launch_bounds__(512, 2) gen_forward_duo_kernel(GenFwdArgs<float> a, int rshift) {
     using S = Duo16<MK>;
-    __shared__ __align__(16) char lds[S::LDS];
+    constexpr int WL = S::nl(SAVE) * 1024;          // LDS-resident part of W, per wave
+    __shared__ __align__(16) char lds[S::LDS + 8 * WL + 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (uniform: buffer descriptors stay in SGPRs)
     const int d = wave >> 2;
@@ -329,18 +426,234 @@ __global__ void __launch_bounds__(512, 2) gen_forward_duo_kernel(GenFwdArgs<floa
     for (int c = threadIdx.x; c < S::LDS / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
     __syncthreads();                                // (zeroed before any wave records max |W|; state 0 = the B images)
     char* const dlds = lds + d * S::DRAW;
+    char* const wlds = lds + S::LDS + wave * WL;
     unsigned* const wmax = reinterpret_cast<unsigned*>(lds + 2 * S::DRAW) + d;
     switch (wave & 3) {
-        case 0: duo_forward_wave<MK, 0, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wmax); break;
-        case 1: duo_forward_wave<MK, 1, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wmax); break;
-        case 2: duo_forward_wave<MK, 2, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wmax); break;
-        default: duo_forward_wave<MK, 3, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wmax); break;
+        case 0: duo_forward_wave<MK, 0, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        case 1: duo_forward_wave<MK, 1, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        case 2: duo_forward_wave<MK, 2, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        default: duo_forward_wave<MK, 3, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
     }
 }
 
-// SSN_DUO_FREE=0: the lock-step form (one workgroup barrier per phase) instead of the free-running one (A/B timing)
+// ---------------------------------------------------------------------------------------------------------------
+// The fixed-point solver (ext/ssnode.c:64-187 semantics: Euler form r + (-r + f(u)) dt / tau, convergence and rate-bound
+// tests per step, every (draw, stimulus) pair stops at its own step) in the two-draw form, lock-step phases.
+// Stop protocol as solve_mfma_kernel / solve_wide_kernel: per draw three rotating flag words per stimulus in LDS (low
+// half: some row not converged; high half: some row at the rate bound), written in the serial phase of step t, read by
+// all four waves of the draw at the start of its next chain phase (one barrier later), cleared one step ahead.  A draw
+// whose 8 stimuli are all frozen (or that reached max_iter) idles through the phases until the other draw of the
+// workgroup is done too: each draw publishes `finished` in a word of the slot of the current phase parity, every wave
+// reads both words of the previous phase's slot with its flag read and leaves the loop at the END of the phase in which
+// it saw both set -- the same decision in all 8 waves, because nobody writes the slot being read.
+// ---------------------------------------------------------------------------------------------------------------
+template <int MK, int WV>
+__device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d, int b, int s0, bool valid, int lane,
+                                               char* dlds, char* wlds, char* plds, char* wwlds) {
+    using S = Duo16<MK>;
+    using WS = DuoWave<MK, WV>;
+    constexpr int NT = WS::NT, NTF = WS::NTF, RT0 = WS::RT0;
+    constexpr int NE = 2 * NTF;
+    const int M = a.M, N = a.N, max_iter = a.st.max_iter;
+    const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
+    using LdsW = __attribute__((address_space(3))) unsigned*;
+    using LdsI = __attribute__((address_space(3))) int*;
+    using LdsS = __attribute__((address_space(3))) short*;
+    const LdsW wmax = (LdsW)wlds + 2 * d;                                        // [0] max |W|, [1] max |r0| of this draw
+    const LdsW done = (LdsW)wlds + 4;                                           // [phase parity][draw]
+    const LdsI flags = (LdsI)(dlds + S::SYNC);                                  // [3][8] of this draw
+    // previous state of this lane's values (r_prev output): kept in LDS, 32 B per lane, rewritten with every applied step
+    using LdsF4s = __attribute__((address_space(3))) mf4*;
+    const LdsF4s rp_slot = (LdsF4s)(plds + (size_t)(WV * 64 + lane) * 32);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
+    using Ops = DuoOperands<MK, WV, S::nl(true)>;
+    __hip_atomic_fetch_max(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+    // ---- the values this lane finishes
+    const IoSelect io(a.io);
+    const int s = s0 + st;
+    const bool live = valid && s < a.NB;
+    float rc[NE], ex[NE], eps[NE];
+    bool rowok[NE];
+    float r0max = 0.f;
+    {
+        const size_t vec = ((size_t)b * a.NB + (s < a.NB ? s : 0)) * M;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
+            rowok[i] = row < M;
+            const bool ok = s < a.NB && row < M;
+            rc[i] = ok ? a.r[vec + row] : 0.f;
+            ex[i] = ok ? a.ext[(a.ext_per_draw ? vec : (size_t)s * M) + row] : 0.f;
+            eps[i] = row < N ? a.st.eps_E : a.st.eps_I;
+            r0max = fmaxf(r0max, __builtin_fabsf(rc[i]));
+        }
+    }
+    __hip_atomic_fetch_max(wmax + 1, __builtin_bit_cast(unsigned, r0max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    auto store_prev = [&]() {
+        rp_slot[0] = (mf4){rc[0], rc[1], NE > 2 ? rc[2 % NE] : 0.f, NE > 2 ? rc[3 % NE] : 0.f};
+        if constexpr (NE > 4) rp_slot[1] = (mf4){rc[4 % NE], rc[5 % NE], NE > 6 ? rc[6 % NE] : 0.f, NE > 6 ? rc[7 % NE] : 0.f};
+    };
+    store_prev();                                        // (zero steps: previous = initial state)
+    __syncthreads();                                                          // (A) max |W|, max |r0| of both draws
+    // state scale: bound 2^rshift < 2^14 for bound = max(rate_hard_bound, max |r0|): every later state is a convex
+    // combination of values inside that bound
+    const float bound = fmaxf(a.io.hard, __builtin_bit_cast(float, wmax[1]));
+    int rshift = 13 - ((int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xffu) - 127);
+    rshift = rshift > 100 ? 100 : (rshift < -100 ? -100 : rshift);
+    const int wexp = duo_w_exp(wmax[0]);
+    const float sa = duo_pow2(wexp), usc = duo_pow2(-wexp - rshift), rs = duo_pow2(rshift);
+    Ops ops;
+    ops.load(rsrc, M, li, lg, sa, wwlds, lane);
+    using LdsH8 = const __attribute__((address_space(3))) hv8*;
+    using LdsF4 = __attribute__((address_space(3))) mf4*;
+    using LdsU = __attribute__((address_space(3))) unsigned*;
+    const unsigned bimg = (unsigned)(size_t)(LdsH8)dlds;
+    const unsigned xs = bimg + (unsigned)(2 * S::BB) + (unsigned)(lane * 16);
+    const unsigned b_rd = bimg + (unsigned)(lg * S::BROW + li * 16);
+    const unsigned b_wr = bimg + (unsigned)((lg >> 1) * S::BROW + st * 16 + (lg & 1) * 8 + hi * 4);
+    auto store_state = [&]() {
+#pragma unroll
+        for (int tf = 0; tf < NTF; ++tf) {
+            const int rt = RT0 + tf;
+            unsigned h, m;
+            duo_split2(rc[2 * tf], rc[2 * tf + 1], rs, h, m);
+            const unsigned wr = b_wr + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW);
+            *(LdsU)(size_t)wr = h;
+            *(LdsU)(size_t)(wr + 128u) = m;
+        }
+    };
+    store_state();                                       // the initial state as the first B operand
+
+    mf4 acc[NT];
+    auto chain = [&]() {
+        ops.chain(b_rd, acc);
+        if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
+    };
+    // bookkeeping identical in the four waves of the draw: lane s < 8 holds the verdict of stimulus s0 + s
+    int my_code = 1, my_steps = max_iter;
+    bool my_frozen = lane >= 8 || !valid || s0 + lane >= a.NB;
+    unsigned frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
+    auto verdict = [&](int it, int f) {            // f: flag word of step it for stimulus `lane`
+        const bool fnc = (f & 0xffff) != 0, fhb = (f >> 16) != 0;
+        const bool stop = lane < 8 && !my_frozen && (!fnc || fhb);
+        my_code = stop ? (fnc ? 2 : 0) : my_code;
+        my_steps = stop ? it + 1 : my_steps;
+        my_frozen = my_frozen || stop;
+        frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
+    };
+    auto serial = [&](int it) {
+        float uu[NE], ff[NE], dfn[NE];
+#pragma unroll
+        for (int tf = 0; tf < NTF; ++tf) {
+            mf4 sm = acc[tf];
+            if constexpr (WS::HEAD_SHARED) {
+                if (tf == 0) {
+                    const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                    sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
+                }
+            }
+            const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
+            const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
+            uu[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
+            uu[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
+        }
+        duo_eval<false, NE>(io, uu, ff, dfn);
+        float r1[NE], dmax = -1.f, rmax = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            r1[i] = rc[i] + (-rc[i] + ff[i]) * eps[i];                           // ssnode.c:64-67
+            dmax = fmaxf(dmax, rowok[i] ? fabsf(r1[i] - rc[i]) : -1.f);
+            rmax = fmaxf(rmax, rowok[i] ? r1[i] : -__builtin_inff());
+        }
+        if (WV == 0 && lane < 8) flags[((it + 1) % 3) * 8 + lane] = 0;
+        if (live && !((frozen >> st) & 1u)) {
+            const LdsS fw = (LdsS)(flags + (it % 3) * 8 + st);
+            if (dmax >= a.st.atol) fw[0] = 1;                                    // ssnode.c:84-90 (a NaN difference does not count)
+            if (a.st.check_hard && rmax >= a.st.hard_stop) fw[1] = 1;
+            store_prev();
+#pragma unroll
+            for (int i = 0; i < NE; ++i) rc[i] = rowok[i] ? r1[i] : rc[i];
+            store_state();
+        }
+    };
+    __syncthreads();                                                          // (B)
+    bool finished = !valid;
+    int it = 0;
+    for (int p = 0;; ++p) {
+        // flags of my draw's last finished step (lanes 0-7) and both `done` words of the previous phase (lanes 8, 9)
+        const bool chain_phase = ((p + d) & 1) == 0;
+        int word = 0;
+        {
+            const LdsI src = lane < 8 ? flags + ((it + 2) % 3) * 8 + lane : (LdsI)(done + ((p + 1) & 1) * 2 + (lane & 1));
+            if (lane < 10) word = *src;
+        }
+        if (chain_phase && p >= d) {
+            if (!finished && it >= 1) verdict(it - 1, word);
+            if (frozen == 0xffu || it >= max_iter) finished = true;
+            if (!finished) chain();
+        } else if (p >= d) {
+            if (!finished) serial(it);
+            ++it;
+        }
+        if (WV == 0 && lane == 0) done[(p & 1) * 2 + d] = finished ? 1u : 0u;
+        const bool both = p >= 1 && __builtin_amdgcn_readlane(word, 8) != 0 && __builtin_amdgcn_readlane(word, 9) != 0;
+        __syncthreads();
+        if (both) break;
+    }
+    if (valid && s < a.NB) {
+        const size_t unit = (size_t)b * a.NB + s;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
+            if (row >= M) continue;
+            a.r[unit * M + row] = rc[i];
+            if (a.r_prev) a.r_prev[unit * M + row] = ((const __attribute__((address_space(3))) float*)rp_slot)[i];
+        }
+    }
+    if (WV == 0 && valid && lane < 8 && s0 + lane < a.NB) {
+        const size_t unit = (size_t)b * a.NB + s0 + lane;
+        a.codes[unit] = my_code;
+        if (a.steps) a.steps[unit] = my_steps;
+    }
+}
+
+template <int MK>
+__global__ void __launch_bounds__(512, 2) solve_duo_kernel(SolveArgs<float> a) {
+    using S = Duo16<MK>;
+    // per draw: images, slots, [3][8] flags, previous states of its 4 waves (32 B per lane); then max words, done words
+    constexpr int PER_DRAW = S::DRAW + 128 + 4 * 64 * 32;
+    constexpr int WL = S::nl(true) * 1024;
+    __shared__ __align__(16) char lds[2 * PER_DRAW + 64 + 8 * WL];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int d = wave >> 2;
+    const int ngroups = (a.NB + 7) / 8;
+    const long nunits = (long)a.B * ngroups;
+    long unit = 2L * blockIdx.x + d;
+    const bool valid = unit < nunits;
+    if (!valid) unit = nunits - 1;
+    const int b = (int)(unit / ngroups), s0 = (int)(unit % ngroups) * 8;
+    for (int c = threadIdx.x; c < (int)sizeof(lds) / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
+    __syncthreads();
+    char* const dlds = lds + d * PER_DRAW;
+    char* const plds = dlds + S::DRAW + 128;
+    char* const wlds = lds + 2 * PER_DRAW;
+    char* const wwlds = lds + 2 * PER_DRAW + 64 + wave * WL;
+    switch (wave & 3) {
+        case 0: duo_solve_wave<MK, 0>(a, d, b, s0, valid, lane, dlds, wlds, plds, wwlds); break;
+        case 1: duo_solve_wave<MK, 1>(a, d, b, s0, valid, lane, dlds, wlds, plds, wwlds); break;
+        case 2: duo_solve_wave<MK, 2>(a, d, b, s0, valid, lane, dlds, wlds, plds, wwlds); break;
+        default: duo_solve_wave<MK, 3>(a, d, b, s0, valid, lane, dlds, wlds, plds, wwlds); break;
+    }
+}
+
+// SSN_DUO_FREE=1: the free-running form (per-draw LDS counters, no workgroup barrier in the time loop) instead of the
+// lock-step one (one workgroup barrier per phase).  Same results bit for bit; measured 3.50 against 3.38 ms at C3, so the
+// lock-step form is the default and this one stays for A/B timing.
 static bool duo_free_running() {
-    static const bool on = [] { const char* e = getenv("SSN_DUO_FREE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = getenv("SSN_DUO_FREE"); return e && e[0] == '1'; }();
     return on;
 }
 static int duo_pick_mk(int M) {
@@ -374,4 +687,27 @@ hipError_t launch_gen_forward_duo(const GenFwdArgs<float>& a, hipStream_t st) {
     }
 }
 
+template <int MK>
+static hipError_t launch_duo_solve_mk(const SolveArgs<float>& a, hipStream_t st) {
+    const long nunits = (long)a.B * ((a.NB + 7) / 8);
+    hipLaunchKernelGGL((solve_duo_kernel<MK>), dim3((unsigned)((nunits + 1) / 2)), dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+// applicability: solve_split_supported (ssn_mfma16.hip)
+hipError_t launch_solve_duo(const SolveArgs<float>& a, hipStream_t st) {
+    if (!solve_split_supported(a)) return hipErrorInvalidValue;
+    switch (duo_pick_mk(a.M)) {
+        case 104: return launch_duo_solve_mk<104>(a, st);
+        case 152: return launch_duo_solve_mk<152>(a, st);
+        case 208: return launch_duo_solve_mk<208>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 }  // namespace ssn
+
+#if SSN_DUO_STAMP
+extern "C" int ssn_debug_duo_stamps(unsigned long long* out16) {
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(ssn::duo_stamps), 16 * sizeof(unsigned long long));
+}
+#endif

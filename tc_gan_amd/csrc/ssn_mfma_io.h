@@ -83,13 +83,20 @@ struct IoSelect {
             if (i) asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(v[i]));      // (ignores NaN operands)
         }
         if (__builtin_amdgcn_ballot_w64(vmax > v0_low) != 0) {
+            // all NV saturating values unconditionally (pinned: left alone the compiler puts each one under its own
+            // `v > v0` branch, NV dependent exp / rcp chains one after the other), then selects
+            float th[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                th[i] = tanh_pos(gain * fmaxf(v[i] - v0, 0.f));
+                asm volatile("" : "+v"(th[i]));
+            }
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const float d = v[i] - v0;
-                const float th = tanh_pos(gain * d);
                 const bool high = v[i] > v0_low;
-                f[i] = high ? fmaf(c_tanh, th, fmaf(c_lin, d, soft)) : f[i];
-                if (WANT_DF) df[i] = high ? fmaf(c_tanh_gain, 1.f - th * th, c_lin) : df[i];
+                f[i] = high ? fmaf(c_tanh, th[i], fmaf(c_lin, d, soft)) : f[i];
+                if (WANT_DF) df[i] = high ? fmaf(c_tanh_gain, 1.f - th[i] * th[i], c_lin) : df[i];
             }
         }
     }

@@ -555,7 +555,7 @@ def make_gan(config):
         unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'),
         z_device_seed=take('z_device_seed', None), shard=(reducer.rank, reducer.world),
-        ssn_type=ssn_type, V=V, dist_in=dist_in)
+        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=take('gen_kernel', 'auto'))
     rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
     disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
     seed = take('seed', 0)

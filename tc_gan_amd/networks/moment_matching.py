@@ -196,7 +196,7 @@ def make_moment_matcher(config):
         include_time_avg=take('include_time_avg', False), unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'), z_device_seed=take('z_device_seed', None),
         shard=(reducer.rank, reducer.world),
-        ssn_type=ssn_type, V=V, dist_in=dist_in)
+        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=take('gen_kernel', 'auto'))
     bounds = {name: (take(name + '_min', 1e-3), take(name + '_max', 10.0)) for name in 'JDS'}
     bounds['V'] = (float(np.min(take('V_min', 0))), float(np.max(take('V_max', 1))))
     upd_cfg = {k: take(k) for k in ('learning_rate', 'update_name', 'update_config', 'reg_l2_penalty', 'reg_l2_decay',

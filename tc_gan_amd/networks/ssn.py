@@ -116,8 +116,12 @@ class TuningCurveGenerator(object):
     def __init__(self, num_sites, num_tcdom, smoothness, J, D, S, k, n, tau_E, tau_I, dt, io_type,
                  seqlen, skip_steps, batchsize, probes=None, include_rate_penalty=True,
                  include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None, shard=(0, 1),
-                 ssn_type='default', V=0, dist_in='bernoulli'):
+                 ssn_type='default', V=0, dist_in='bernoulli', gen_kernel='auto'):
         clib.require_gpu()
+        # kernel family of the forward / adjoint launches (`ssn_gen_params.kernel`, names in clib.GEN_KERNELS): explicit
+        # state of the generator, written to info.json and checkpoints -- 'auto' follows the library's operand-precision
+        # setting (clib.set_operand_precision), 'mfma-fp32' / 'tile' keep fp32 operands whatever that setting is
+        self.kernel = clib.gen_kernel_code(gen_kernel)
         if ssn_type not in ssn_type_choices:
             raise ValueError('Unknown ssn_type: {}'.format(ssn_type))
         assert dist_in in dist_in_choices
@@ -197,10 +201,16 @@ class TuningCurveGenerator(object):
         if rest:
             raise ValueError('Unknown parameters: {}'.format(rest))
 
-    # kernel family of the forward / adjoint launches (`ssn_gen_params.kernel`): 0 = library default (the fp16-split MFMA
-    # kernels where they apply), 2 = fp32 MFMA kernels, 1 = VALU tile kernels; an attribute so that benchmarks and tests
-    # can time one against the other on the same generator
-    kernel = 0
+    @property
+    def gen_kernel(self):
+        return next(name for name, code in clib.GEN_KERNELS.items() if code == self.kernel)
+
+    def forward_variant(self, num_models=None, save=False):
+        """The forward kernel a call with `num_models` draws runs (`ssn_gen_forward_variant`; fp32 only, else 1)."""
+        if self.dtype != 'float32':
+            return 1
+        return genops.forward_variant(self.batchsize if num_models is None else num_models, self.num_tcdom,
+                                      self.num_neurons, self.gen_params(), save=save)
 
     def gen_params(self, rate_penalty_threshold=200.0):
         return genops.make_gen_params(io_type=self.io_type, k=self.k, n=self.n, tau_E=self.tau_E, tau_I=self.tau_I,
@@ -365,7 +375,7 @@ class TuningCurveGenerator(object):
                     tau_E=self.tau_E, tau_I=self.tau_I, dt=self.dt, io_type=self.io_type,
                     seqlen=self.seqlen, skip_steps=self.skip_steps, batchsize=self.batchsize,
                     include_rate_penalty=self.include_rate_penalty, include_time_avg=self.include_time_avg,
-                    unroll_scan=self.unroll_scan, ssn_type=self.ssn_type, ssn_impl='default',
+                    unroll_scan=self.unroll_scan, ssn_type=self.ssn_type, ssn_impl='default', gen_kernel=self.gen_kernel,
                     **({} if not self.heteroin else dict(V=np.asarray(self.V).tolist(), dist_in=self.dist_in)),
                     **({} if self.probes is None else dict(probes=self.probes.tolist())))
 

@@ -4,7 +4,7 @@ from logging import getLogger
 
 import numpy as np
 
-from .. import execution, ssnode, utils
+from .. import clib, execution, ssnode, utils
 from ..networks.dataset import generate_dataset
 from ..networks.fixed_time_sampler import new_JDS
 from ..networks.wgan import DEFAULT_PARAMS
@@ -64,6 +64,12 @@ def add_bptt_common_options(parser):
     parser.add_argument('--critic-iters', '--WGAN_n_critic', default=5, type=int)
     parser.add_argument('--ssn-type', default='default', choices=('default', 'heteroin', 'deg-heteroin'),
                         help='SSN variant (the reference sets it through --load-config)')
+    parser.add_argument('--gen-kernel', default='auto', choices=tuple(clib.GEN_KERNELS),
+                        help='Kernel family of the generator forward / adjoint (new; recorded in info.json).  auto (default): '
+                             'the library\'s choice -- for float32 with >= 4 bandwidths and enough models the fp16-split '
+                             'matrix-core kernels (W and the state enter the products with 23 significant bits, exact '
+                             'products, fp32 accumulation: within the fp32 kernels\' own distance from fp64); mfma-fp32 or '
+                             'tile: fp32 operands (the reference\'s floatX arithmetic); the others name one kernel')
     parser.add_argument('--z-device-seed', default=None, type=int,
                         help='Draw z on the device (Philox4x32-10, one stream sharded over the ranks) instead of the '
                              'host RandomState (new; fast mode, and the mode to use for multi-GPU runs)')

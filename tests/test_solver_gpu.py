@@ -191,6 +191,10 @@ def test_test_inf_message():
     (76, 8, 6, 'float32'), (52, 8, 6, 'float32'),
     # variant 7: the same in the alternating two-group form (state as three fp16 parts)
     (100, 8, 7, 'float32'), (50, 5, 7, 'float32'), (101, 9, 7, 'float32'), (76, 8, 7, 'float32'),
+    # variant 8: fp16-split kernel with two draws per workgroup, every wave both roles (csrc/ssn_duo.hip; B = 6 draws:
+    # even unit count, 9 / 11 stimuli: two groups per draw, 5: ragged group)
+    (100, 8, 8, 'float32'), (100, 4, 8, 'float32'), (50, 5, 8, 'float32'), (101, 9, 8, 'float32'), (16, 11, 8, 'float32'),
+    (76, 8, 8, 'float32'), (52, 8, 8, 'float32'),
     # fp64 resident shapes beyond 2N = 104: 4 rows per lane, 5-7 waves, one workgroup per CU (2N = 204 is the reference's
     # default N = 102: the truth-data path of every CLI run)
     (102, 1, 2, 'float64'), (102, 8, 2, 'float64'), (100, 3, 2, 'float64'), (76, 2, 2, 'float64'), (60, 1, 2, 'float64'),
@@ -202,7 +206,7 @@ def test_test_inf_message():
 def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
     """atol=0 -> exactly T Euler steps (code 1): end states vs the fp64 C oracle."""
     from tc_gan_amd.ssnode import fixed_points_batch
-    if variant in (6, 7) and io_type != 'asym_tanh':
+    if variant in (6, 7, 8) and io_type != 'asym_tanh':
         pytest.skip('the fp16-split solver needs the rate bound of asym_tanh (refused otherwise: test below)')
     B, T = 6, 300
     Ws, exts = _inputs(N, B, NB, seed=N * 31 + NB)
@@ -218,14 +222,14 @@ def test_fixed_step_batch_vs_oracle(oracle_lib, io_type, N, NB, variant, dtype):
 
 @pytest.mark.parametrize('dtype,variant', [('float64', 0), ('float64', 1), ('float64', 2), ('float32', 1),
                                            ('float32', 2), ('float32', 0), ('float32', 3), ('float32', 4), ('float32', 5),
-                                           ('float32', 6), ('float32', 7)])
+                                           ('float32', 6), ('float32', 7), ('float32', 8)])
 def test_converging_batch_codes_steps_states(oracle_lib, dtype, variant):
     """Default solver settings (atol 1e-5, dt 8e-4): per-pair convergence step and state."""
     from tc_gan_amd.ssnode import fixed_points_batch
     N, B, NB = 50, 5, 8
     Ws, exts = _inputs(N, B, NB, seed=7)
     for io_type in ('asym_power', 'asym_tanh'):
-        if variant in (6, 7) and io_type != 'asym_tanh':
+        if variant in (6, 7, 8) and io_type != 'asym_tanh':
             continue
         want, wcodes, wsteps = _oracle_batch(oracle_lib, Ws, exts, io_type, 100000, 1e-5,
                                              hard=np.inf if io_type != 'asym_tanh' else 1000.)
@@ -439,12 +443,15 @@ def test_split_solver_initial_states_beyond_the_rate_bound_and_refusals():
     N, B, NB = 100, 3, 8
     Ws, exts = _inputs(N, B, NB, seed=5)
     r0 = np.random.RandomState(1).rand(B, NB, 2 * N) * 9000.0          # hard bound 1000
-    a = fixed_points_batch(Ws, exts, P['k'], P['n'], r0=r0, max_iter=200, atol=0.0, dtype='float32', variant=6)
     b = fixed_points_batch(Ws, exts, P['k'], P['n'], r0=r0, max_iter=200, atol=0.0, dtype='float32', variant=2)
-    np.testing.assert_allclose(a.x, b.x, rtol=2e-5, atol=1e-4)
-    assert np.isfinite(a.x).all()
-    with pytest.raises(clib.SSNLibraryError):
-        fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=10, atol=0.0, io_type='asym_power', dtype='float32', variant=6)
+    for variant in (6, 8):                       # (8: B = 3 draws, the second workgroup holds one draw and an idle half)
+        a = fixed_points_batch(Ws, exts, P['k'], P['n'], r0=r0, max_iter=200, atol=0.0, dtype='float32', variant=variant,
+                               want_prev=True)
+        np.testing.assert_allclose(a.x, b.x, rtol=2e-5, atol=1e-4)
+        assert np.isfinite(a.x).all() and np.isfinite(a.x_prev).all()
+        with pytest.raises(clib.SSNLibraryError):
+            fixed_points_batch(Ws, exts, P['k'], P['n'], max_iter=10, atol=0.0, io_type='asym_power', dtype='float32',
+                               variant=variant)
 
 
 @pytest.mark.parametrize('variant', [2, 5, 6, 7, 8])

@@ -37,6 +37,15 @@ def main():
         ta = genops.gen_forward(W, ext, gp)['time_avg']
         if ref is None:
             ref = ta
+        if k == 8 and hasattr(genops.libssnode, 'ssn_debug_duo_stamps'):      # diagnostic build (-DSSN_DUO_STAMP=1)
+            import ctypes
+            buf = (ctypes.c_ulonglong * 16)()
+            torch.cuda.synchronize()
+            genops.libssnode.ssn_debug_duo_stamps(buf)
+            n = max(int(buf[8]), 1)
+            for d in (0, 1):
+                print('  draw %d wave 0: chain %.0f  barrier %.0f  serial %.0f  barrier %.0f cycles per step (s_memtime ticks); wave 3: chain %.0f serial %.0f barriers %.0f'
+                      % ((d,) + tuple(buf[4 * d + i] / n for i in range(4)) + tuple(buf[9 + 3 * d + i] / n for i in range(3))))
         print('kernel %d: forward%s %.3f ms   max |time_avg - first kernel| %.3e (max %.3e)' % (
             k, ' + stores' if save else '', ms, float((ta - ref).abs().max()), float(ref.abs().max())), flush=True)
 
