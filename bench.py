@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)"
+SPLIT_VARIANTS = (4, 5, 6, 7, 8)   # generator forward kernels on the fp16 matrix cores (`ssn_gen_forward_variant`)
 
 WORKLOADS = {
     # name: (N, B, NB, T, description)
@@ -123,7 +124,8 @@ def _traffic(key):
         return None
 
 
-def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iters_init=5, critic_iters=5, models=None):
+def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iters_init=5, critic_iters=5, models=None,
+                gen_kernel='auto'):
     """The GAN of BASELINE config 3/4 (or, `paper=True`, of scripts/fig4/gan/run.json) with its truth data set:
     returns (gan, (N, models_per_rank, NB, T, skip), bandwidths).  Shared by the bench and by the full-size parity test."""
     from tc_gan_amd.networks.cwgan import make_gan
@@ -135,6 +137,7 @@ def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iter
                include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
                seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=critic_iters_init, critic_iters=critic_iters,
                lipschitz_cost=10.0, z_device_seed=4321,      # one Philox stream, sharded over the ranks by make_gan
+               gen_kernel=gen_kernel,
                gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
@@ -166,18 +169,21 @@ def _forward_roofline(variant, achieved, traffic, kernel_ms, M, steps_in_loop):
     8 in the alternating form (2 x 4 columns per stimulus: 3 state parts + 1 unused), on tiles padded from M x M to
     16 ceil(M / 16) x 32 ceil(M / 32)."""
     groups = {2: 'two 4-stimulus groups per workgroup', 3: 'one 4-stimulus group per workgroup'}
-    if variant in (4, 5, 6, 7):
+    if variant in SPLIT_VARIANTS:
         peak = 16 * PEAK_FP32_VALU_TFLOPS
         pad = (16 * -(-M // 16)) * (32 * -(-M // 32)) / float(M * M)
         # executed fp16 flops per algorithmic flop: W parts x operand columns per stimulus
         form, per_flop, state = {4: ('all 8 stimuli in one chain per step', 2 * 2, '2 parts (22 bits)'),
                                  7: ('all 8 stimuli in one chain per step', 3 * 2, '3 parts (exact)'),
                                  5: (groups[3], 2 * 4, '3 parts (exact)'),
-                                 6: (groups[2] + ', alternating', 2 * 4, '3 parts (exact)')}[variant]
+                                 6: (groups[2] + ', alternating', 2 * 4, '3 parts (exact)'),
+                                 8: ('two draws per workgroup, every wave chain + serial part, all 8 stimuli in one chain per step',
+                                     2 * 2, '2 parts (23 bits, round to nearest)')}[variant]
         executed = achieved * (2 * M) / (2 * M + 8) * per_flop * pad
+        name = {4: 'wide', 7: 'wide', 8: 'duo'}.get(variant, 'split')
         return {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'traffic': traffic, 'kernel': 'gen_forward_%s_kernel (fp16-split MFMA, %s)' % ('wide' if variant in (4, 7) else 'split', form),
-                'mfma_dtype': 'f16 (W = 2 parts = 22 bits, state = %s, exact products, fp32 accumulate)' % state,
+                'traffic': traffic, 'kernel': 'gen_forward_%s_kernel (fp16-split MFMA, %s)' % (name, form),
+                'mfma_dtype': 'f16 (W = 2 parts = 23 bits by round to nearest, state = %s, exact products, fp32 accumulate)' % state,
                 'executed_mfma_tflops': executed, 'executed_frac': executed / peak,
                 'frac_of_fp32_peak': achieved / PEAK_FP32_VALU_TFLOPS,
                 'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8, 'ssn_steps_per_s_in_loop': steps_in_loop}
@@ -197,46 +203,57 @@ def run_c3(args, rank, world, local_rank, paper=False):
     value = N x iterations/s, i.e. 1024-model GAN iterations per second over the whole job."""
     import torch
     import torch.distributed as dist
-    gan, (N, models, NB, T, skip), bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision)
-    it = gan.learning()
+    def timed_loop(gen_kernel):
+        """warm-up + `steps` GAN iterations of a FRESH GAN (same seeds), barrier + synchronize on both sides, MAX over ranks."""
+        gan, shape, bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision, gen_kernel=gen_kernel)
+        gan.reducer.timed = world > 1
+        it = gan.learning()
 
-    def one_iter():
-        while True:
-            info = next(it)
-            if not info.is_discriminator:
-                return info
+        def one_iter():
+            while True:
+                info = next(it)
+                if not info.is_discriminator:
+                    return info
 
-    for _ in range(args.warmup):
-        one_iter()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        info = one_iter()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert np.isfinite(info.gen_loss)
-    # the same loop with the generator's W.r on the fp32 matrix instructions (W carried with all 24 bits) for a few
-    # iterations, so that the line holds both numbers (`fp32_mfma` below); the split kernels stay the measured default
-    fp32_ms = None
-    if not paper and args.steps >= 2:
-        gan.gen.kernel = 2
-        one_iter()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(args.warmup):
             one_iter()
+        gan.host_draw_seconds = 0.0
+        gan.reducer.collective_ms()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
-        fp32_ms = (time.perf_counter() - t1) / 2 * 1e3
-        gan.gen.kernel = 0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            info = one_iter()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        phases = None
+        if world > 1:
+            t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            # where a rank's time goes besides its kernels: device time inside the all-reduces (includes waiting for the
+            # slowest rank) and host time in the RNG draws, per GAN iteration, max / min over ranks
+            mine = torch.tensor([gan.reducer.collective_ms() / args.steps, gan.host_draw_seconds * 1e3 / args.steps],
+                                device='cuda', dtype=torch.float64)
+            hi, lo = mine.clone(), mine.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            phases = {'allreduce_ms': {'max': float(hi[0]), 'min': float(lo[0])},
+                      'host_draw_ms': {'max': float(hi[1]), 'min': float(lo[1])},
+                      'collectives_per_iteration': gan.critic_iters + 1}
+        assert np.isfinite(info.gen_loss)
+        return gan, shape, bandwidths, elapsed, info, phases
+
+    gan, (N, models, NB, T, skip), bandwidths, elapsed, info, phases = timed_loop('auto')
+    # the same loop -- same seeds, fresh GAN, same warm-up, steps and max-over-ranks -- with the generator's W.r on the fp32
+    # matrix instructions (W and state carried with all 24 bits), so that the line holds both numbers (`fp32_mfma` below)
+    fp32_ms = None
+    if not paper and args.steps >= 2 and gan.gen.forward_variant(models) in SPLIT_VARIANTS:
+        fp32_ms = timed_loop('mfma-fp32')[3] / args.steps * 1e3
     # dominant kernel: gen_forward_kernel, timed alone with HIP events on the launch stream
     bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
     kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
@@ -246,6 +263,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
     ext, z, W = gan.gen._device_inputs(bw, kw['stimulator_contrasts'], noise['model_zs'], noise.get('model_zs_in'))
     gp = gan.gen.gen_params(200.0)
     genops.gen_forward(W, ext, gp)
+    out_extra_kernel = gan.gen.gen_kernel
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(3):
@@ -266,7 +284,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
         'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '%d-model GAN iterations/s' % models,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (critic GEMMs bf16%s)' % ('; generator W.r on fp16 matrix cores as an exact-product split of 22-bit operands' if variant in (4, 5, 6, 7) else ''),
+        'dtype': 'f32 (critic GEMMs %s%s)' % (args.disc_precision, '; generator W.r on fp16 matrix cores as an exact-product split of 23-bit operands' if variant in SPLIT_VARIANTS else ''),
         'data': 'synthetic',
         'config': {'workload': ('C3 paper shape (scripts/fig4/gan/run.json): 2N=202, 128 models x 8 bandwidths per GPU, '
                                 'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
@@ -275,11 +293,14 @@ def run_c3(args, rank, world, local_rank, paper=False):
                                '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
                                'device-side z (Philox)', 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
         'roofline': _forward_roofline(variant, achieved, traffic, kernel_ms, M, 7 * units * iters_per_s * world),
-        'last_gen_loss': info.gen_loss,
+        'last_gen_loss': info.gen_loss, 'gen_kernel': out_extra_kernel, 'forward_variant': variant,
     }
-    if fp32_ms is not None and variant in (4, 5, 6, 7):
-        out['fp32_mfma'] = {'ms_per_step': fp32_ms, 'value': world * 1e3 / fp32_ms,
-                            'note': 'same loop, generator forward and adjoint on the fp32 MFMA kernels (2 iterations, this rank)'}
+    if fp32_ms is not None:
+        out['fp32_mfma'] = {'ms_per_step': fp32_ms, 'value': world * 1e3 / fp32_ms, 'steps': args.steps, 'warmup': args.warmup,
+                            'note': 'same loop on a fresh GAN with the same seeds, generator forward and adjoint on the fp32 MFMA '
+                                    'kernels (gen_kernel mfma-fp32: fp32 operands), same warm-up, steps and max-over-ranks timing'}
+    if phases is not None:
+        out['phases'] = phases
     out['world_size'] = world
     return out
 
@@ -400,12 +421,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c3', 'c3paper', 'c5'])
     ap.add_argument('--variant', type=int, default=-1, help='-1 auto, 0 streaming, 1 register-stationary DPP, 2 tile (library picks the shape), '
-                    '3 tile/split residency, 4 tile/all-register, 5 fp32 MFMA (NB >= 4), 6 fp16-split MFMA (NB >= 4), 7 the same in the alternating form')
+                    '3 tile/split residency, 4 tile/all-register, 5 fp32 MFMA (NB >= 4), 6 fp16-split MFMA (NB >= 4), 7 the same in the alternating form, '
+                    '8 fp16-split MFMA with two draws per workgroup')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
     ap.add_argument('--secondary-steps', type=int, default=5,
                     help='GAN iterations of the C3 run whose line rides along as `secondary` with the default (C2) '
                          'workload, so that one command covers both halves of BASELINE.json.metric (0 = off)')
+    ap.add_argument('--no-extras', dest='extras', action='store_false',
+                    help='default (C2) workload on one GPU: skip the short c2nb8 / c5 / c1-dropin / c3paper runs that ride along '
+                         'as `extras`')
     ap.add_argument('--disc-precision', default='bf16', choices=['bf16', 'fp32'],
                     help='c3: critic GEMM operand precision (BASELINE config 3 names bf16 MFMA)')
     ap.add_argument('--via', default='batched', choices=['batched', 'dropin'],
@@ -454,8 +479,31 @@ def main():
             out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                                                     'higher_is_better', 'scaling', 'dtype', 'data', 'config', 'roofline',
                                                     'last_gen_loss')}
-            if 'fp32_mfma' in sec:
-                out['secondary']['fp32_mfma'] = sec['fp32_mfma']
+            for key in ('fp32_mfma', 'phases', 'gen_kernel', 'forward_variant'):
+                if key in sec:
+                    out['secondary'][key] = sec[key]
+        if args.workload == 'c2' and args.extras and world == 1:
+            # The other workloads SURVEY.md section 8(d) names, short runs in the same job so that the driver's record holds
+            # them too: C2 with the 8 bandwidths every real caller uses, C5, C1 through the drop-in symbols, the paper's shape.
+            out['extras'] = {}
+            keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
+                    'gen_kernel', 'forward_variant')
+            for name, workload, steps, warmup, kw in (('c2nb8', 'c2nb8', 3, 1, {}), ('c5', 'c5', 5, 1, {}),
+                                                      ('c1_dropin', 'c1', 1, 0, dict(via='dropin', cpu_sample=128)),
+                                                      ('c3paper', 'c3paper', 20, 5, {})):
+                sub = argparse.Namespace(**dict(vars(args), workload=workload, steps=steps, warmup=warmup, variant=-1,
+                                                no_cpu_baseline=(name != 'c1_dropin'), **kw))
+                t_extra = time.perf_counter()
+                if workload == 'c3paper':
+                    res = run_c3(sub, rank, world, local_rank, paper=True)
+                elif workload == 'c5':
+                    res = run_c5(sub, rank, world, local_rank)
+                elif name == 'c1_dropin':
+                    res = run_c1_dropin(sub)
+                else:
+                    res = run_solver(sub, rank, world, local_rank)
+                out['extras'][name] = dict({k: res[k] for k in keep if k in res}, wall_s=time.perf_counter() - t_extra)
+                torch.cuda.empty_cache()
     # what actually ran: the process group's own size and backend (1 / none for a single process)
     out['world_size'] = dist.get_world_size() if world > 1 else 1
     out['dist_backend'] = dist.get_backend() if world > 1 else None
@@ -549,12 +597,9 @@ def run_solver(args, rank, world, local_rank):
             traffic = json.load(open(tpath)).get(args.workload)
         except Exception:
             traffic = None
-    if args.variant >= 0:
-        fast = args.variant
-    elif NB >= 4 and 104 < M <= 208 and B * ((NB + 7) // 8) >= 192:
-        fast = 6 if os.environ.get('SSN_FWD_SPLIT', '1') != '0' else 5   # the library's automatic choice for large fp32 NB >= 4 batches (asym_tanh)
-    else:
-        fast = libssnode.ssn_solver_fast_path(M, NB, 4)
+    # the variant that ran: the forced one, or what the library says it picks for this call shape and these parameters
+    fast = args.variant if args.variant >= 0 else libssnode.ssn_solve_batch_variant_for(B, NB, M, 4, ctypes.byref(p))
+    assert fast >= 0
     out = {
         'metric': 'SSN-steps/sec', 'value': value, 'unit': 'neuron*batch*Euler-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -562,22 +607,23 @@ def run_solver(args, rank, world, local_rank):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': desc + ', asym_tanh, atol=0, fp32, W rebuilt from resident z each step',
                    'neurons': M, 'batch_per_gpu': B, 'stimuli_per_draw': NB, 'euler_steps': T,
-                   'kernel': {7: 'solve_split_kernel (fp16-split MFMA, alternating groups)', 6: 'solve_wide_kernel (fp16-split MFMA)', 5: 'solve_mfma_kernel', 4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
+                   'kernel': {8: 'solve_duo_kernel (fp16-split MFMA, two draws per workgroup)', 7: 'solve_split_kernel (fp16-split MFMA, alternating groups)', 6: 'solve_wide_kernel (fp16-split MFMA)', 5: 'solve_mfma_kernel', 4: 'solve_tile_kernel (all-register)', 3: 'solve_tile_kernel (split)', 2: 'solve_tile_kernel', 1: 'solve_regw_kernel', 0: 'solve_stream_kernel'}[int(fast)],
                    'parallelism': 'draws sharded over %d GPU(s), no data-path collective' % world},
         # fp32 VALU peak = fp32 MFMA (v_mfma_f32_4x4x1) peak = 157.3 TFLOP/s (MI355X_MICROARCH.md)
-        'roofline': {'bound': 'mfma' if int(fast) in (5, 6, 7) else 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
+        'roofline': {'bound': 'mfma' if int(fast) in (5, 6, 7, 8) else 'valu_fp32', 'achieved': achieved, 'peak': PEAK_FP32_VALU_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': achieved / PEAK_FP32_VALU_TFLOPS, 'traffic': traffic,
                      'kernel_ms': kernel_ms, 'flops_per_unit': flops_per_unit,
                      'algorithmic_hbm_bytes': B * (4 * M * M + 12 * M * NB)},
     }
-    if int(fast) in (6, 7):  # fp16-split MFMA solver: priced like the split generator forward (see _forward_roofline)
+    if int(fast) in (6, 7, 8):  # fp16-split MFMA solver: priced like the split generator forward (see _forward_roofline)
         wide = int(fast) == 6 and os.environ.get('SSN_FWD_WIDE', '2') != '0'
-        rl = _forward_roofline(4 if wide else 6, achieved, traffic, kernel_ms, M, None)
+        rl = _forward_roofline(8 if int(fast) == 8 else (4 if wide else 6), achieved, traffic, kernel_ms, M, None)
         rl.pop('ssn_steps_per_s_in_loop')
-        rl['kernel'] = rl['kernel'].replace('gen_forward_wide_kernel', 'solve_wide_kernel').replace('gen_forward_split_kernel', 'solve_split_kernel')
+        rl['kernel'] = (rl['kernel'].replace('gen_forward_wide_kernel', 'solve_wide_kernel').replace('gen_forward_split_kernel', 'solve_split_kernel')
+                        .replace('gen_forward_duo_kernel', 'solve_duo_kernel'))
         rl['algorithmic_hbm_bytes'] = B * (4 * M * M + 12 * M * NB)
         out['roofline'] = rl
-        out['dtype'] = 'f32 (W.r on fp16 matrix cores as an exact-product split of 22-bit operands)'
+        out['dtype'] = 'f32 (W.r on fp16 matrix cores as an exact-product split of 23-bit operands)'
     out['world_size'] = world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = min(len(os.sched_getaffinity(0)), 16)           # the 1-GPU box's CPU share

@@ -105,9 +105,12 @@ class Critic(object):
             sizes = [int(np.prod(shape)) for _, shape in self.param_shapes()]
             self._seg_sizes = np.asarray(sizes, dtype='float64')
             self._seg_bounds = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(self.device)
+            self._seg_ws = torch.empty(int(libssnode.ssn_segment_sqnorms_ws_doubles(len(sizes))), device=self.device,
+                                       dtype=torch.float64)
         out = torch.empty(len(self._seg_sizes), device=self.device, dtype=torch.float32)
         clib.check(libssnode.ssn_segment_sqnorms_f32(self.params.data_ptr(), self._seg_bounds.data_ptr(), int(out.numel()),
-                                                     out.data_ptr(), _stream()), 'ssn_segment_sqnorms_f32')
+                                                     out.data_ptr(), self._seg_ws.data_ptr(), _stream()),
+                   'ssn_segment_sqnorms_f32')
         return out
 
     def cache_param_nnorms(self, sqnorms_host):

@@ -71,7 +71,9 @@ int solve_batch_impl(int variant, const T* W, const T* ext, int ext_per_draw, T*
     // split tile kernel (which runs one workgroup per (draw, stimulus) and so keeps small batches busier)
     if (variant < 0) {
         const bool big = (long)B * ((NB + 7) / 8) >= 192 && M > 104;
-        variant = (mfma_ok && big) ? ((split_ok && forward_split_default()) ? 6 : 5) : (tile_ok ? 2 : (regw_ok ? 1 : 0));
+        // fp16-split forms: two draws per workgroup (8) once that still gives every CU a workgroup, else one (6)
+        const int split_variant = (long)B * ((NB + 7) / 8) > 256 ? 8 : 6;
+        variant = (mfma_ok && big) ? ((split_ok && forward_split_default()) ? split_variant : 5) : (tile_ok ? 2 : (regw_ok ? 1 : 0));
     }
     if (dry_run) return variant;
     switch (variant) {
@@ -432,6 +434,11 @@ static int mfma_groups_for(int kernel, bool mfma_ok, int B, int NB) {
     return 0;
 }
 
+// automatic choice among the fp16-split forward kernels with two groups per unit: two draws per workgroup (ssn_duo.hip,
+// 3.4 ms at C3) when that still gives every CU a workgroup, else one draw per workgroup (wide form, 5.3 ms at C3 but
+// twice the workgroups)
+static bool duo_default(int groups, int B, int NB) { return groups == 2 && (long)B * ((NB + 7) / 8) > 256; }
+
 template <typename T>
 int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_row, T* traj, T* df, int B, int NB,
                      int M, const ssn_gen_params* g, void* stream) {
@@ -464,7 +471,8 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
             a.mfma_groups = groups;
             a.split_narrow = g->kernel == 6;
             const bool split = g->kernel >= 4 || (g->kernel == 0 && split_ok && forward_split_default());
-            if (g->kernel == 8) SSN_TRY(ssn::launch_gen_forward_duo(a, (hipStream_t)stream));
+            if (g->kernel == 8 || (g->kernel == 0 && split && duo_default(groups, B, NB)))
+                SSN_TRY(ssn::launch_gen_forward_duo(a, (hipStream_t)stream));
             else if (split) SSN_TRY(ssn::launch_gen_forward_split(a, (hipStream_t)stream));
             else SSN_TRY(ssn::launch_gen_forward_mfma(a, (hipStream_t)stream));
             return 0;
@@ -766,6 +774,7 @@ int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ss
     if (!groups) return 1;
     if (g->kernel == 8) return 8;
     const bool split = g->kernel >= 4 || (g->kernel == 0 && split_ok && forward_split_default());
+    if (g->kernel == 0 && split && duo_default(groups, B, NB)) return 8;
     if (split && groups == 2 && (g->kernel == 6 || ssn::gen_split_wide_parts() == 0)) return 6;
     if (split && groups == 2 && ssn::gen_split_wide_parts() == 3) return 7;
     return (split ? 4 : 2) + (groups == 1 ? 1 : 0);
@@ -916,9 +925,10 @@ int ssn_probe_scatter_f64(const double* g, const long* ids, const long* probes, 
     SSN_TRY(ssn::launch_probe_scatter<double>(g, ids, probes, g_ta, n, B, NB, M, (hipStream_t)stream));
     return 0;
 }
-int ssn_segment_sqnorms_f32(const float* x, const long* bounds, int n, float* out, void* stream) {
-    if (n < 0 || (n > 0 && (!x || !bounds || !out))) { g_last_error = "ssn_segment_sqnorms: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
-    SSN_TRY(ssn::launch_segment_sqnorms(x, bounds, n, out, (hipStream_t)stream));
+long ssn_segment_sqnorms_ws_doubles(int n) { return ssn::segment_sqnorms_ws_doubles(n); }
+int ssn_segment_sqnorms_f32(const float* x, const long* bounds, int n, float* out, double* ws, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !bounds || !out || !ws))) { g_last_error = "ssn_segment_sqnorms: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_segment_sqnorms(x, bounds, n, out, ws, (hipStream_t)stream));
     return 0;
 }
 int ssn_interpolate_f32(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, void* stream) {

@@ -169,7 +169,8 @@ template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, 
 template <typename T> hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long offset, T* out, unsigned long long n, hipStream_t st);
 template <typename T> hipError_t launch_philox_amp(unsigned long long seed, unsigned long long offset, const T* v, T* zin, T* amp, unsigned long long n, int M, int bernoulli, hipStream_t st);
 template <typename T> hipError_t launch_probe_scatter(const T* g, const long* ids, const long* probes, T* g_ta, int n, int B, int NB, int M, hipStream_t st);
-hipError_t launch_segment_sqnorms(const float* x, const long* bounds, int n, float* out, hipStream_t st);
+long segment_sqnorms_ws_doubles(int n);
+hipError_t launch_segment_sqnorms(const float* x, const long* bounds, int n, float* out, double* ws, hipStream_t st);
 hipError_t launch_interpolate(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, hipStream_t st);
 template <typename T> hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, hipStream_t st);
 template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st);

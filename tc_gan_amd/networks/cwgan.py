@@ -22,6 +22,8 @@ from logging import getLogger
 
 import os
 
+import time
+
 import numpy as np
 import torch
 
@@ -173,6 +175,19 @@ class GradientAllReducer(object):
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.on else 1
         self.rank = dist.get_rank() if self.on else 0
+        # per-phase timing for multi-GPU diagnosis (bench.py --gpus N): device time between two events around every
+        # collective, summed on demand; off by default (two event records per update)
+        self.timed = False
+        self._events = []
+
+    def collective_ms(self):
+        """Device milliseconds spent in the all-reduces since the last call (synchronises)."""
+        if not self._events:
+            return 0.0
+        torch.cuda.synchronize()
+        total = sum(a.elapsed_time(b) for a, b in self._events)
+        self._events = []
+        return total
 
     def mean_(self, *tensors):
         """In-place mean over ranks of several tensors through ONE collective (one persistent flat fp32 buffer per
@@ -187,7 +202,14 @@ class GradientAllReducer(object):
         for t in tensors:
             flat[off:off + t.numel()].copy_(t.reshape(-1))
             off += t.numel()
-        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+        if self.timed and flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
+            ev[1].record()
+            self._events.append(ev)
+        else:
+            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
         flat /= self.world
         off = 0
         for t in tensors:
@@ -298,9 +320,11 @@ class ConditionalBPTTWassersteinGAN(object):
     # critic update and reads loss / accuracy / penalties back with ONE device-to-host copy.
     def _draw_disc(self):
         """The host RNG draws of one critic step, in the reference's order (minibatch, eps, zs)."""
+        t0 = time.perf_counter()
         batch = self.next_minibatch()
         eps_full = self.rng.rand(batch.batchsize, 1)
         noise = self._draw_noise(batch)
+        self.host_draw_seconds = getattr(self, 'host_draw_seconds', 0.0) + (time.perf_counter() - t0)
         return batch, eps_full, noise
 
     def _prepare_disc(self):

@@ -75,13 +75,18 @@ class DeviceNoise(object):
         self.seed, self.rank, self.world = int(seed), int(rank), int(world)
         self.position = 0                      # elements of the global stream consumed so far
 
+    def take(self, n):
+        """Stream offset of THIS rank's n elements of the next global draw of world * n elements; advances the position
+        by the global count (pure bookkeeping: the same on every rank but for the rank's own offset)."""
+        offset = self.position + self.rank * n
+        self.position += self.world * n
+        return offset
+
     def uniform(self, local_shape, tdtype):
         out = torch.empty(tuple(local_shape), device='cuda', dtype=tdtype)
         n = out.numel()
         fn = clib.libssnode.ssn_philox_uniform_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_uniform_f64
-        clib.check(fn(self.seed, self.position + self.rank * n, out.data_ptr(), n,
-                      clib.stream_ptr()), 'ssn_philox_uniform')
-        self.position += self.world * n
+        clib.check(fn(self.seed, self.take(n), out.data_ptr(), n, clib.stream_ptr()), 'ssn_philox_uniform')
         return out
 
     def signs_and_amp(self, local_shape, tdtype, v, bernoulli):
@@ -92,10 +97,9 @@ class DeviceNoise(object):
         n = zin.numel()
         assert v.dtype == tdtype and v.numel() == local_shape[-1] and v.is_contiguous()
         fn = clib.libssnode.ssn_philox_amp_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_amp_f64
-        clib.check(fn(self.seed, self.position + self.rank * n, v.data_ptr(), zin.data_ptr(), amp.data_ptr(), n,
+        clib.check(fn(self.seed, self.take(n), v.data_ptr(), zin.data_ptr(), amp.data_ptr(), n,
                       int(local_shape[-1]), int(bool(bernoulli)),
                       clib.stream_ptr()), 'ssn_philox_amp')
-        self.position += self.world * n
         return zin, amp
 
     def get_state(self):

@@ -35,6 +35,22 @@ def test_default_workload_line():
     assert abs(d['value'] - 200 * 4096 * 2000 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     c = d['cpu_baseline']
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(c) and c['kind'] in ('reference', 'port') and c['value'] > 0
+    # the GAN half of the metric and the other named workloads ride along
+    sec = d['secondary']
+    assert sec['metric'] == 'GAN iters/sec' and sec['value'] > 0 and sec['gen_kernel'] == 'auto'
+    assert sec['forward_variant'] == 8 and 'duo' in sec['roofline']['kernel']         # what the library picked, by its own word
+    assert sec['fp32_mfma']['steps'] == sec['steps'] and sec['fp32_mfma']['warmup'] == sec['warmup']
+    ex = d['extras']
+    assert set(ex) == {'c2nb8', 'c5', 'c1_dropin', 'c3paper'}
+    for name, e in ex.items():
+        assert e['value'] > 0 and e['ms_per_step'] > 0 and 'workload' in e['config'], name
+        assert name == 'c1_dropin' or {'bound', 'achieved', 'peak', 'frac'} <= set(e['roofline']), name
+    assert 'solve_duo_kernel' in ex['c2nb8']['config']['kernel'] and ex['c1_dropin']['cpu_baseline']['value'] > 0
+
+
+def test_no_extras_flag():
+    d = _bench('--steps', '1', '--warmup', '0', '--no-extras', '--secondary-steps', '0', '--no-cpu-baseline')
+    assert 'extras' not in d and 'secondary' not in d and 'cpu_baseline' not in d
 
 
 def test_gan_loop_line():

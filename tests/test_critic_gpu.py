@@ -275,6 +275,14 @@ def test_step_helpers_segment_sqnorms_and_interpolate():
     want = [float((np.asarray(v, dtype='float64') ** 2).sum()) for v in crit.get_param_values()]
     np.testing.assert_allclose(got, want, rtol=1e-6)
     assert len(got) == len(crit.get_param_names())
+    # the full-size critic of BASELINE config 3 (0.53 M parameters, tensors from 1 to 262144 elements; bias and single-row
+    # tensors leave most chunks empty): same values, and the same bits on every call (fixed summation order, no atomics)
+    big = Critic(8, [512, 512, 512], seed=5)
+    g1 = big.param_sqnorms_device().cpu().numpy()
+    want = [float((np.asarray(v, dtype='float64') ** 2).sum()) for v in big.get_param_values()]
+    np.testing.assert_allclose(g1, want, rtol=1e-6)
+    for _ in range(3):
+        np.testing.assert_array_equal(big.param_sqnorms_device().cpu().numpy(), g1)
     rs = np.random.RandomState(0)
     eps, xd, xg = rs.rand(37, 1).astype('float32'), rs.randn(37, 8).astype('float32'), rs.randn(37, 8).astype('float32')
     xp = crit.interpolate(torch.as_tensor(eps).cuda(), torch.as_tensor(xd).cuda(), torch.as_tensor(xg).cuda()).cpu().numpy()
