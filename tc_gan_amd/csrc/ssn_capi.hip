@@ -162,7 +162,14 @@ struct ArenaLease {
         a = arena_pool().acquire(dev);
         return hipSuccess;
     }
-    ~ArenaLease() { if (a) arena_pool().release(a); }
+    // An error return between an asynchronous copy and its wait must not hand staging memory with DMA in flight to the
+    // next borrower: drain the arena's stream before it goes back to the pool (a no-op on the normal path, which has
+    // already waited for its download).
+    ~ArenaLease() {
+        if (!a) return;
+        if (a->stream) (void)hipStreamSynchronize(a->stream);
+        arena_pool().release(a);
+    }
 };
 inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
 
@@ -239,6 +246,7 @@ struct SolveReq {
     double *r0, *r1;
     ssn_solver_params p;
     int code = -1, steps = 0, rc = 0;
+    std::string error;                 // the batch leader's message when rc != 0 (thread-local on ITS thread)
     bool done = false;
     bool same_shape(const SolveReq& o) const {
         return device == o.device && N == o.N && p.io_type == o.p.io_type && p.max_iter == o.p.max_iter && p.k == o.p.k &&
@@ -345,11 +353,11 @@ public:
             int rc = solve_group(grp);
             const std::string err = g_last_error;      // the leader's thread-local message, for every member
             lk.lock();
-            for (SolveReq* r : grp) { r->rc = rc; r->done = true; }
-            (void)err;
+            for (SolveReq* r : grp) { r->rc = rc; if (rc) r->error = err; r->done = true; }
             leader_active_ = false;
             cv_.notify_all();
         }
+        if (q.rc) g_last_error = q.error;              // every member of a failed batch reports the batch's error
         return q.rc;
     }
 };

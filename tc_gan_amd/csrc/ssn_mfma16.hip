@@ -374,15 +374,22 @@ __device__ __forceinline__ void wide_store(const float (&x)[4], fv2 sc01, fv2 sc
     const fv2 s01 = (fv2){x[0], x[1]} * sc01, s23 = (fv2){x[2], x[3]} * sc23;
     auto top = [](fv2 v) { return __builtin_bit_cast(fv2, __builtin_bit_cast(uv2, v) & (uv2){0xffffe000u, 0xffffe000u}); };
     auto pk = [](fv2 v) { return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)); };
-    const fv2 h01 = top(s01), h23 = top(s23);
-    const fv2 d01 = s01 - h01, d23 = s23 - h23;
-    *(LdsU2)(size_t)bw = (uv2){pk(h01), pk(h23)};
     if constexpr (RP == 3) {
+        const fv2 h01 = top(s01), h23 = top(s23);
+        const fv2 d01 = s01 - h01, d23 = s23 - h23;
+        *(LdsU2)(size_t)bw = (uv2){pk(h01), pk(h23)};
         const fv2 m01 = top(d01), m23 = top(d23);
         *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(m01), pk(m23)};
         *(LdsU2)(size_t)(bw + second) = (uv2){pk(d01 - m01), pk(d23 - m23)};
     } else {
-        *(LdsU2)(size_t)(bw + 128u) = (uv2){pk(d01), pk(d23)};         // the remainder, rounded toward zero to 11 bits
+        // two parts: both by ROUND TO NEAREST (h = rn(s), m = rn(s - h): |s - h - m| <= 2^-23 |s|, no bias; round 2
+        // truncated both, 2^-21 and biased toward zero)
+        typedef _Float16 hv2_ __attribute__((ext_vector_type(2)));
+        const hv2_ hn01 = __builtin_convertvector(s01, hv2_), hn23 = __builtin_convertvector(s23, hv2_);
+        const fv2 r01 = s01 - __builtin_convertvector(hn01, fv2), r23 = s23 - __builtin_convertvector(hn23, fv2);
+        *(LdsU2)(size_t)bw = (uv2){__builtin_bit_cast(unsigned, hn01), __builtin_bit_cast(unsigned, hn23)};
+        *(LdsU2)(size_t)(bw + 128u) = (uv2){__builtin_bit_cast(unsigned, __builtin_convertvector(r01, hv2_)),
+                                            __builtin_bit_cast(unsigned, __builtin_convertvector(r23, hv2_))};
     }
 }
 
@@ -821,9 +828,14 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
             dfc[g][v] = pdf[g][v];
             pdf[g][v] = ndf[v];
         }
-        if (b_live) {
+        {
+            // The scale lags one step behind the data: an adjoint that grows by more than 2^8 within one step (unstable
+            // draws, the unbounded I/O functions) would SATURATE in v_cvt_pkrtz and come out finite but clamped.  Such a
+            // step is poisoned instead: NaN into the hand-over and into the delta stream, so that the gradient is NaN like
+            // the fp32 kernels' overflow and the drivers' NaN guards see it.
             const float rs = live[g] ? __builtin_bit_cast(float, (unsigned)(127 + bexp) << 23) : 0.f;
-            split3_store(delta, (fv2){rs, rs}, (fv2){rs, rs}, (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off);
+            if (!(dm * rs < 65504.f)) delta[0] = __builtin_nanf("");
+            if (b_live) split3_store(delta, (fv2){rs, rs}, (fv2){rs, rs}, (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off);
         }
         bused[g] = bexp;
         const unsigned wm = wave_max_bits(live[g] ? dm : 0.f);

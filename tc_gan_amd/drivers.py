@@ -130,122 +130,142 @@ class WGANDiscLossLimiter(object):
         return cls(driver.datastore)
 
 
-class BPTTWGANDriver(object):
-    """drivers.py:61-180 + 298-337 (GANDriver machinery specialised to the BPTT WGANs)."""
+class _GeneratorStepLoop(object):
+    """The part of a driver that does not depend on the learner: a counted loop over generator steps with the exit
+    reason recorded, and the per-step bookkeeping both learners need -- log the generator's parameters, flush the
+    tables, give up when the parameters have drifted beyond `quit_JDS_threshold`.
+
+    Subclasses provide `open_recorders()` and `record_step(gen_step, result)`; the reference's method names (`pre_loop`,
+    `post_update`, `iterate`) stay available because its run scripts and subclasses use them (drivers.py:97-180)."""
+
+    start_step = 0
+    quit_JDS_threshold = -1
+
+    def watch_generator(self, gen_step):
+        """Log (J, D, S[, V]) of this step and apply the distance guard.  NB: the reference exponentiates the recorded
+        (J, D, S) before comparing them with ssnode's default parameters -- a leftover from when they were stored as
+        logarithms (drivers.py:147-152); kept so that a run ends exactly where the reference's would."""
+        recorded = self.generator_recorder.record(gen_step)
+        self.datastore.flush_all()
+        maybe_quit(self.datastore, JDS_fake=[np.exp(block) for block in recorded],
+                   JDS_true=[ssnode.DEFAULT_PARAMS[name] for name in 'JDS'], quit_JDS_threshold=self.quit_JDS_threshold)
+
+    def iterate(self, update_func):
+        """`update_func(gen_step)` advances the learner by one generator step and returns what `post_update` records."""
+        self.pre_loop()
+        name = type(self).__name__
+        logger.info('%s: start iterations', name)
+        with recording_exit_reason(self.datastore):
+            for gen_step in range(self.start_step, self.iterations):
+                self.post_update(gen_step, update_func(gen_step))
+        logger.info('%s: maximum iterations reached', name)
+
+
+class BPTTWGANDriver(_GeneratorStepLoop):
+    """Driver of the BPTT Wasserstein GANs (drivers.py:61-180 + 298-337): consumes `gan.learning()`, one critic or
+    generator update per item, and records / guards after each."""
 
     def __init__(self, gan, datastore, iterations, quiet, disc_param_save_interval, disc_param_template,
                  disc_param_save_on_error, quit_JDS_threshold=-1, checkpoint_interval=-1, resume_from=None, **kwargs):
-        self.checkpoint_interval = checkpoint_interval      # new: write <datastore>/checkpoint.pkl every K generator steps
-        self.resume_from = resume_from                      # new: continue from such a file
-        self.start_step = 0
-        self.gan = gan
-        self.datastore = datastore
-        self.iterations = iterations
-        self.quiet = quiet
+        self.gan, self.datastore = gan, datastore
+        self.iterations, self.quiet = iterations, quiet
         self.disc_param_save_interval = disc_param_save_interval
         self.disc_param_template = disc_param_template
         self.disc_param_save_on_error = disc_param_save_on_error
         self.quit_JDS_threshold = quit_JDS_threshold
+        self.checkpoint_interval = checkpoint_interval      # new: write <datastore>/checkpoint.pkl every K generator steps
+        self.resume_from = resume_from                      # new: continue from such a file
         self.__dict__.update(kwargs)
 
+    def _disc_param_path(self, name):
+        return self.datastore.path('disc_param', name)
+
     def pre_loop(self):
-        self.learning_recorder = LearningRecorder.from_driver(self)
-        self.generator_recorder = FlexGenParamRecorder.from_driver(self)
-        self.discparamstats_recorder = DiscParamStatsRecorder.from_driver(self)
-        self.disclearning_recorder = DiscLearningRecorder.from_driver(self)
-        self.rejection_limiter = SSNRejectionLimiter.from_driver(self)
-        self.disc_loss_limiter = WGANDiscLossLimiter.from_driver(self)
+        for attr, recorder in (('learning_recorder', LearningRecorder), ('generator_recorder', FlexGenParamRecorder),
+                               ('discparamstats_recorder', DiscParamStatsRecorder),
+                               ('disclearning_recorder', DiscLearningRecorder),
+                               ('rejection_limiter', SSNRejectionLimiter), ('disc_loss_limiter', WGANDiscLossLimiter)):
+            setattr(self, attr, recorder.from_driver(self))
 
     def post_disc_update(self, gen_step, disc_step, Dloss, Daccuracy, SSsolve_time, gradient_time, model_info):
+        """After every critic update: its row, the parameter statistics, then the three guards (critic went non-finite,
+        finder rejects too much, loss blew up)."""
         self.disclearning_recorder.record(gen_step, disc_step, Dloss, Daccuracy, SSsolve_time, gradient_time,
                                           model_info.rejections, model_info.unused)
-        nnorms = self.discparamstats_recorder.record(gen_step, disc_step)
-        check_disc_param(self.datastore, self.gan.discriminator, nnorms)
+        check_disc_param(self.datastore, self.gan.discriminator, self.discparamstats_recorder.record(gen_step, disc_step))
         self.rejection_limiter(model_info.rejections)
         self.disc_loss_limiter(Dloss)
 
     def post_update(self, gen_step, update_result):
+        """After every generator update: its row, periodic critic snapshot / checkpoint, then `watch_generator`."""
         self.learning_recorder.record(gen_step, update_result)
-        jj, dd, ss = self.generator_recorder.record(gen_step)
         if is_at_interval(gen_step, self.disc_param_save_interval):
-            param_file.dump(self.gan.discriminator,
-                            self.datastore.path('disc_param', self.disc_param_template.format(gen_step)))
+            param_file.dump(self.gan.discriminator, self._disc_param_path(self.disc_param_template.format(gen_step)))
         if is_at_interval(gen_step, self.checkpoint_interval):
             self.gan.save_checkpoint(self.datastore.path('checkpoint.pkl'), gen_step)
-        self.datastore.flush_all()
-        # NB: the reference exponentiates (J, D, S) here (they used to be stored as logs) and compares with the
-        # original parameters; kept for identical exit behaviour (drivers.py:147-152).
-        maybe_quit(self.datastore, JDS_fake=list(map(np.exp, [jj, dd, ss])),
-                   JDS_true=list(map(ssnode.DEFAULT_PARAMS.get, 'JDS')),
-                   quit_JDS_threshold=self.quit_JDS_threshold)
+        self.watch_generator(gen_step)
+
+    def _guarded(self, update_func):
+        """`--disc-param-save-on-error`: the critic as it was before the step, and as the failing step left it."""
+        def step(gen_step):
+            param_file.dump(self.gan.discriminator, self._disc_param_path('pre_error.npz'))
+            try:
+                return update_func(gen_step)
+            except Exception:
+                param_file.dump(self.gan.discriminator, self._disc_param_path('post_error.npz'))
+                raise
+        return step
 
     def iterate(self, update_func):
-        if self.disc_param_save_on_error:
-            inner = update_func
-
-            def update_func(gen_step):
-                param_file.dump(self.gan.discriminator, self.datastore.path('disc_param', 'pre_error.npz'))
-                try:
-                    return inner(gen_step)
-                except Exception:
-                    param_file.dump(self.gan.discriminator, self.datastore.path('disc_param', 'post_error.npz'))
-                    raise
-        self.pre_loop()
-        logger.info('%s: start iterations', self.__class__.__name__)
-        with recording_exit_reason(self.datastore):
-            for gen_step in range(self.start_step, self.iterations):
-                self.post_update(gen_step, update_func(gen_step))
-        logger.info('%s: maximum iterations reached', self.__class__.__name__)
+        super(BPTTWGANDriver, self).iterate(self._guarded(update_func) if self.disc_param_save_on_error else update_func)
 
     def run(self, gan):
         if self.resume_from:
             self.start_step = gan.load_checkpoint(self.resume_from)
             logger.info('resumed from %s: continuing with generator step %d', self.resume_from, self.start_step)
-        learning_it = gan.learning(self.start_step)
-        state = {}
+        updates = gan.learning(self.start_step)
+        last_critic = [None]
 
-        def update_func(k):
-            while True:
-                info = next(learning_it)
+        def until_generator_update(gen_step):
+            for info in updates:
                 if info.is_discriminator:
-                    self.post_disc_update(info.gen_step, info.disc_step, info.disc_loss, info.accuracy,
-                                          info.gen_time, info.disc_time, ssnode.null_FixedPointsInfo)
-                    state['disc_info'] = info
-                else:
-                    assert info.gen_step == k
-                    disc_info = state['disc_info']
-                    data_mean = _host(disc_info.xd).mean(axis=0).tolist()
-                    gen_mean = _host(disc_info.xg).mean(axis=0).tolist()
-                    self.datastore.tables.saverow('TC_mean.csv', gen_mean + data_mean)
-                    return Namespace(info=info, disc_info=disc_info)
-        self.iterate(update_func)
+                    self.post_disc_update(info.gen_step, info.disc_step, info.disc_loss, info.accuracy, info.gen_time,
+                                          info.disc_time, ssnode.null_FixedPointsInfo)
+                    last_critic[0] = info
+                    continue
+                assert info.gen_step == gen_step
+                # TC_mean.csv: batch means of the generated, then of the data curves of the last critic step
+                critic = last_critic[0]
+                self.datastore.tables.saverow('TC_mean.csv', _host(critic.xg).mean(axis=0).tolist()
+                                              + _host(critic.xd).mean(axis=0).tolist())
+                return Namespace(info=info, disc_info=critic)
+            raise RuntimeError('gan.learning() ended before generator step {}'.format(gen_step))
+        self.iterate(until_generator_update)
 
 
 class BPTTcWGANDriver(BPTTWGANDriver):
-    """drivers.py:340-351."""
+    """The conditional GAN adds tuning-curve statistics every `tc_stats_record_interval` steps (drivers.py:340-351)."""
+
+    def pre_loop(self):
+        super(BPTTcWGANDriver, self).pre_loop()
+        self.tuning_curve_recorder = ConditionalTuningCurveStatsRecorder.from_driver(self)
 
     def post_update(self, gen_step, update_result):
         if is_at_interval(gen_step, self.tc_stats_record_interval):
             self.tuning_curve_recorder.record(gen_step, update_result.disc_info)
         super(BPTTcWGANDriver, self).post_update(gen_step, update_result)
 
-    def pre_loop(self):
-        super(BPTTcWGANDriver, self).pre_loop()
-        self.tuning_curve_recorder = ConditionalTuningCurveStatsRecorder.from_driver(self)
 
-
-class MomentMatchingDriver(object):
-    """drivers.py:354-421."""
+class MomentMatchingDriver(_GeneratorStepLoop):
+    """Driver of `BPTTMomentMatcher` (drivers.py:354-421): one generator update per item of `learner.learning()`."""
 
     def __init__(self, mmatcher, datastore, iterations, quiet, gen_moments_record_interval, quit_JDS_threshold=-1):
-        self.mmatcher = mmatcher
-        self.datastore = datastore
-        self.iterations = iterations
-        self.quiet = quiet
+        self.mmatcher, self.datastore = mmatcher, datastore
+        self.iterations, self.quiet = iterations, quiet
         self.gen_moments_record_interval = gen_moments_record_interval
         self.quit_JDS_threshold = quit_JDS_threshold
 
-    gan = property(lambda self: self.mmatcher)        # for FlexGenParamRecorder
+    gan = property(lambda self: self.mmatcher)        # FlexGenParamRecorder.from_driver looks for `.gan`
 
     def pre_loop(self):
         self.learning_recorder = MMLearningRecorder.from_driver(self)
@@ -256,25 +276,13 @@ class MomentMatchingDriver(object):
         self.learning_recorder.record(gen_step, update_result)
         if is_at_interval(gen_step, self.gen_moments_record_interval):
             self.gen_moments_recorder.record(gen_step, update_result)
-        jj, dd, ss = self.generator_recorder.record(gen_step)
-        self.datastore.flush_all()
-        maybe_quit(self.datastore, JDS_fake=list(map(np.exp, [jj, dd, ss])),
-                   JDS_true=list(map(ssnode.DEFAULT_PARAMS.get, 'JDS')),
-                   quit_JDS_threshold=self.quit_JDS_threshold)
-
-    def iterate(self, update_func):
-        self.pre_loop()
-        logger.info('%s: start iterations', self.__class__.__name__)
-        with recording_exit_reason(self.datastore):
-            for gen_step in range(self.iterations):
-                self.post_update(gen_step, update_func(gen_step))
-        logger.info('%s: maximum iterations reached', self.__class__.__name__)
+        self.watch_generator(gen_step)
 
     def run(self, learner):
-        learning_it = learner.learning()
+        updates = learner.learning()
 
-        def update_func(k):
-            info = next(learning_it)
-            assert info.step == k
+        def one_update(gen_step):
+            info = next(updates)
+            assert info.step == gen_step
             return info
-        self.iterate(update_func)
+        self.iterate(one_update)

@@ -29,6 +29,7 @@ import torch
 
 from .. import clib
 from ..critic import Critic, Updater
+from ..execution import KnownError
 from ..gradient_expressions.utils import sample_sites_from_stim_space
 from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product, to_device, to_device_packed
 from .ssn import TuningCurveGenerator
@@ -508,6 +509,9 @@ class ConditionalBPTTWassersteinGAN(object):
                  rng=dict(kind=kind, keys=keys, pos=pos, has_gauss=has_gauss, cached=cached))
         if self.gen._zgen is not None:
             d['zgen'] = self.gen._zgen.get_state()
+        # explicit state that changes what a continuation computes: the kernel family (operand precision) and the job size
+        d['gen_kernel'] = self.gen.gen_kernel
+        d['world'] = self.reducer.world
         return d
 
     def load_state_dict(self, d):
@@ -521,13 +525,26 @@ class ConditionalBPTTWassersteinGAN(object):
         self.rng.set_state((str(r['kind']), np.asarray(r['keys'], dtype='uint32'), int(r['pos']), int(r['has_gauss']),
                             float(r['cached'])))
         if self.gen._zgen is not None and 'zgen' in d:
-            self.gen._zgen.set_state(d['zgen'])
+            z = d['zgen']
+            if not (isinstance(z, dict) and 'seed' in z and 'position' in z):
+                # format 1 of round 1 kept a torch.Generator state (uint8 array) here; the stream is a different one now
+                raise KnownError('this checkpoint holds the device-noise state of an earlier format (a torch.Generator state '
+                                 'array, not a Philox seed/position pair); it cannot be continued with --z-device-seed',
+                                 exit_code=5)
+            self.gen._zgen.set_state(z)
+        for key, mine in (('gen_kernel', self.gen.gen_kernel), ('world', self.reducer.world)):
+            if key in d and d[key] != mine:
+                logger.warning('checkpoint was written with %s = %r, this run has %r: the continuation will not reproduce the '
+                               'uninterrupted run bit for bit%s', key, d[key], mine,
+                               ' (each rank draws other rows of the noise stream)' if key == 'world' else '')
+
+    CHECKPOINT_VERSION = 2          # 2: Philox (seed, position) device-noise state, gen_kernel and world recorded
 
     def save_checkpoint(self, path, gen_step):
         import pickle
         tmp = path + '.tmp'
         with open(tmp, 'wb') as f:
-            pickle.dump(dict(version=1, gen_step=int(gen_step), state=self.state_dict()), f, protocol=4)
+            pickle.dump(dict(version=self.CHECKPOINT_VERSION, gen_step=int(gen_step), state=self.state_dict()), f, protocol=4)
         os.replace(tmp, path)
 
     def load_checkpoint(self, path):
@@ -535,6 +552,10 @@ class ConditionalBPTTWassersteinGAN(object):
         import pickle
         with open(path, 'rb') as f:
             ck = pickle.load(f)
+        if not isinstance(ck, dict) or ck.get('version') not in (1, self.CHECKPOINT_VERSION) or 'state' not in ck:
+            raise KnownError('{} is not a checkpoint this version can read (format version {!r}; known: 1, {})'
+                             .format(path, ck.get('version') if isinstance(ck, dict) else None, self.CHECKPOINT_VERSION),
+                             exit_code=5)
         self.load_state_dict(ck['state'])
         return ck['gen_step'] + 1
 
@@ -568,6 +589,10 @@ def make_gan(config):
         kwargs.pop(key, None)
     reducer = GradientAllReducer()
     local_models = num_models // reducer.world
+    # (the command line's --gen-kernel arrives as gen['kernel']: run scripts group their gen_* options; configs written
+    # by hand may also say gen_kernel at the top level)
+    gen_kernel = gen_cfg.pop('kernel', None) or take('gen_kernel', 'auto')
+    kwargs.pop('gen_kernel', None)
     gen = TuningCurveGenerator(
         num_sites=num_sites, num_tcdom=len(bandwidths), smoothness=take('smoothness'),
         J=take('J0'), D=take('D0'), S=take('S0'), k=take('k'), n=take('n'),
@@ -579,7 +604,7 @@ def make_gan(config):
         unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'),
         z_device_seed=take('z_device_seed', None), shard=(reducer.rank, reducer.world),
-        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=take('gen_kernel', 'auto'))
+        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=gen_kernel)
     rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
     disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
     seed = take('seed', 0)

@@ -8,7 +8,7 @@ from logging import getLogger
 
 import numpy as np
 
-from .. import execution, utils
+from .. import clib, execution, utils
 from ..drivers import MomentMatchingDriver
 from ..networks.moment_matching import DEFAULT_PARAMS, MOMENT_WEIGHT_TYPES, make_moment_matcher
 from .bptt_wgan import do_learning, generate_dataset_and_save
@@ -67,6 +67,8 @@ def make_parser():
     parser.add_argument('--dynamics-cost', type=float, default=1)
     parser.add_argument('--ssn-type', default='default', choices=('default', 'heteroin', 'deg-heteroin'),
                         help='SSN variant (the reference sets it through --load-config)')
+    parser.add_argument('--gen-kernel', default='auto', choices=tuple(clib.GEN_KERNELS),
+                        help='Kernel family of the generator forward / adjoint (new; see tc_gan.run.bptt_cwgan --help)')
     parser.add_argument('--z-device-seed', default=None, type=int,
                         help='Draw z on the device (Philox) instead of the host RandomState (new; fast mode)')
     parser.add_argument('--n_bandwidths', default=4, type=int, choices=(1, 4, 5, 8))

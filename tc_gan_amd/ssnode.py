@@ -186,11 +186,40 @@ def make_io_fun(k, n,
 # single solve through the reference's C entry points
 # --------------------------------------------------------------------------
 def solve_dynamics(*args, **kwds):
-    """ssnode.py:152-156."""
-    sol = fixed_point(*args, **kwds)
-    if not sol.success:
-        print(sol.message)
-    return sol.x
+    """ssnode.py:152-156: the state only; a failed solve is reported on stdout, not raised."""
+    outcome = fixed_point(*args, **kwds)
+    if outcome.error != 0:
+        print(outcome.message)
+    return outcome.x
+
+
+_IO_TYPES = ('asym_linear', 'asym_tanh', 'asym_power')
+_UNBOUNDED_IO = ('asym_power', 'asym_linear')      # their only rate bound is the caller's rate_stop_at (ssnode.py:241-242)
+
+
+def _legacy_entry(io_type, solver):
+    """The drop-in C symbol of one (I/O function, solver) pair, looked up by name like the reference does
+    (ssnode.py:244-245: 'solve_dynamics_{io_type}_{solver}')."""
+    if io_type not in _IO_TYPES:
+        raise ValueError("Unknown I/O type: {}".format(io_type))
+    if solver not in ('euler'):
+        raise ValueError("Unknown solver: {}".format(solver))
+    return getattr(libssnode, 'solve_dynamics_' + io_type + '_' + solver)
+
+
+def _single_solve_buffers(W, ext, r0):
+    """fp64, C-contiguous views of one solve's inputs plus the two state buffers the C routine ping-pongs between.
+    W and ext are passed through when they already qualify; the initial state is ALWAYS a private copy, because the
+    routine writes its result into it and that buffer becomes `FixedPointResult.x` (gotcha 6)."""
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    if W.ndim != 2 or W.shape[0] != W.shape[1] or W.shape[0] % 2:
+        raise AssertionError('W must be a (2N, 2N) matrix, got shape {}'.format(W.shape))
+    M = W.shape[0]
+    ext = np.ascontiguousarray(ext, dtype=np.float64)
+    state = np.zeros(M) if r0 is None else np.array(r0, dtype=np.float64, order='C')
+    if ext.shape != (M,) or state.shape != (M,):
+        raise AssertionError('ext and r0 must have shape ({},), got {} and {}'.format(M, ext.shape, state.shape))
+    return M // 2, W, ext, state, np.empty(M)
 
 
 def fixed_point(
@@ -201,62 +230,28 @@ def fixed_point(
         rate_stop_at=np.inf,
         io_type='asym_tanh', check=False):
     """
-    Solve ODE for the SSN until it converges to a fixed point (ssnode.py:159-273).
+    One fixed-point solve through the reference's own C entry point (ssnode.py:159-273): same parameters, same
+    `FixedPointResult` (``x``, ``error``, ``message``, ``success``).  The symbol executes the fp64 HIP kernel.
 
-    Same parameters and return object (`FixedPointResult` with ``x``,
-    ``error``, ``message``, ``success``) as the reference.  The C symbol
-    ``solve_dynamics_{io_type}_{solver}`` is looked up dynamically exactly as in
-    ssnode.py:244-245; it executes the fp64 HIP kernel.
+    error: 0 converged; 1 `max_iter` reached -- or "converged" onto a non-finite state, which the reference also books as
+    a failure; 2 a rate reached `rate_stop_at` (power-law / linear I/O only).  ``check=True`` raises `FixedPointError`.
     """
-    if io_type not in ('asym_linear', 'asym_tanh', 'asym_power'):
-        raise ValueError("Unknown I/O type: {}".format(io_type))
-    if solver not in ('euler'):
-        raise ValueError("Unknown solver: {}".format(solver))
-
-    W = np.asarray(W, dtype='double')
-    N = W.shape[0] // 2
-    ext = np.asarray(ext, dtype='double')
-    if r0 is None:
-        r0 = np.zeros(2 * N, dtype='double')
-    else:
-        r0 = np.array(r0, dtype='double')  # copied, as it will be modified
-    r1 = np.empty_like(r0)
-    tau_E, tau_I = tau
-
-    assert 2 * N == W.shape[0] == W.shape[1]
-    assert W.ndim == 2
-    assert (2 * N,) == r0.shape == ext.shape
-    W = np.ascontiguousarray(W)
-    ext = np.ascontiguousarray(ext)
-
-    if io_type in ('asym_power', 'asym_linear'):
-        rate_hard_bound = rate_stop_at
-
+    entry = _legacy_entry(io_type, solver)
+    N, W, ext, state, scratch = _single_solve_buffers(W, ext, r0)
+    stop_bound = rate_stop_at if io_type in _UNBOUNDED_IO else rate_hard_bound
     clib.require_gpu()
-    error = getattr(libssnode,
-                    'solve_dynamics_{}_{}'.format(io_type, solver))(
-        N,
-        W.ctypes.data_as(double_ptr),
-        ext.ctypes.data_as(double_ptr),
-        float(k), float(n),
-        r0.ctypes.data_as(double_ptr),
-        r1.ctypes.data_as(double_ptr),
-        tau_E, tau_I,
-        dt, int(max_iter), atol,
-        rate_soft_bound, rate_hard_bound,
-    )
-    if error > 900:
-        raise clib.SSNLibraryError('solve_dynamics_{}_{}: status {} ({})'.format(
-            io_type, solver, error, clib.last_error()))
-    sol = FixedPointResult(r0, error)
-    if error == 0 and not np.isfinite(r0).all():
-        sol.error = 1
-        sol.message = "Converged to non-finite value"
-    else:
-        sol.message = _message_for(error)
-    if check and not sol.success:
-        raise sol.to_exception()
-    return sol
+    code = entry(N, W.ctypes.data_as(double_ptr), ext.ctypes.data_as(double_ptr), float(k), float(n),
+                 state.ctypes.data_as(double_ptr), scratch.ctypes.data_as(double_ptr),
+                 float(tau[0]), float(tau[1]), dt, int(max_iter), atol, rate_soft_bound, stop_bound)
+    if code > 900:                      # the library's own failures (no device, launch error) are not solver outcomes
+        raise clib.SSNLibraryError('solve_dynamics_{}_{}: status {} ({})'.format(io_type, solver, code, clib.last_error()))
+    outcome = FixedPointResult(state, code)
+    outcome.message = _message_for(code)
+    if code == 0 and not np.all(np.isfinite(state)):
+        outcome.error, outcome.message = 1, "Converged to non-finite value"
+    if check and outcome.error != 0:
+        raise outcome.to_exception()
+    return outcome
 
 
 # --------------------------------------------------------------------------
@@ -450,6 +445,22 @@ find_fixed_points_serial = find_fixed_points_batched
 find_fixed_points_parallel = find_fixed_points_batched
 
 
+def _weight_draws(noise_source, N, J, D, S):
+    """Endless (z, W) pairs: one ``rand(1, 2N, 2N)`` call per candidate draw from the given RandomState, in draw order
+    (the stream contract of ssnode.py:580-586), W from `weight_gen.generate_weight` (the reference goes through a
+    compiled Theano expression here, `numeric_w`; equal to 2.6e-11)."""
+    from .weight_gen import generate_weight
+    M = 2 * N
+    while True:
+        z = noise_source.rand(1, M, M)[0]
+        yield z, generate_weight(N, J, D, S, z)
+
+
+def _stimulus_rows(N, bandwidths, smoothness, contrast, offset=(0,)):
+    from . import stimuli
+    return stimuli.input(bandwidths, np.linspace(-0.5, 0.5, N), smoothness, contrast, offset)
+
+
 def make_solver_params(
         N=DEFAULT_PARAMS['N'],
         J=DEFAULT_PARAMS['J'],
@@ -463,27 +474,12 @@ def make_solver_params(
         k=DEFAULT_PARAMS['k'],
         n=DEFAULT_PARAMS['n'],
         ):
-    """ssnode.py:524-558."""
-    from . import stimuli
-    from .weight_gen import generate_weight
-
-    if isinstance(seed, int):
-        rs = np.random.RandomState(seed)
-    else:
-        rs = seed
-
-    Z = rs.rand(1, 2 * N, 2 * N)
-    W = generate_weight(N, J, D, S, Z[0])
-    X = np.linspace(-0.5, 0.5, N)
-    ext, = stimuli.input([bandwidth], X, smoothness, contrast)
-
-    return dict(
-        W=W,
-        ext=ext,
-        r0=np.zeros(W.shape[0]),
-        k=k, n=n,
-        io_type=io_type,
-    )
+    """Keyword arguments of one `fixed_point` call on a seeded random network (ssnode.py:524-558); `seed` may be an int
+    or a RandomState to draw from."""
+    source = seed if hasattr(seed, 'rand') else np.random.RandomState(seed)
+    _, W = next(_weight_draws(source, N, J, D, S))
+    return dict(W=W, ext=_stimulus_rows(N, [bandwidth], smoothness, contrast)[0], r0=np.zeros(2 * N), k=k, n=n,
+                io_type=io_type)
 
 
 def sample_fixed_points(
@@ -500,34 +496,21 @@ def sample_fixed_points(
         k=DEFAULT_PARAMS['k'],
         n=DEFAULT_PARAMS['n'],
         **solver_kwargs):
-    """ssnode.py:561-590.  ``z = rs.rand(1, 2N, 2N)`` per candidate draw, in draw
-    order, from ``RandomState(seed)``; W built on the device from z."""
-    from . import stimuli
-    from .weight_gen import generate_weight
-
-    X = np.linspace(-0.5, 0.5, N)
-    exts = stimuli.input(bandwidths, X, smoothness, contrast, offset)
-    rs = np.random.RandomState(seed)
-
-    def Z_W_gen():
-        while True:
-            z = rs.rand(1, 2 * N, 2 * N)
-            yield z[0], generate_weight(N, J, D, S, z[0])
-
-    solver_kwargs.setdefault('r0', np.zeros(2 * N))
-    solver_kwargs.update(k=k, n=n, io_type=io_type)
-    return find_fixed_points(NZ, Z_W_gen(), exts, **solver_kwargs)
+    """`NZ` accepted weight draws and their fixed points for every stimulus of the (bandwidth x contrast x offset) grid
+    (ssnode.py:561-590): returns what `find_fixed_points` returns.  Extra keywords go to the solver."""
+    solver_options = dict(dict(r0=np.zeros(2 * N)), **solver_kwargs)
+    solver_options.update(k=k, n=n, io_type=io_type)
+    return find_fixed_points(NZ, _weight_draws(np.random.RandomState(seed), N, J, D, S),
+                             _stimulus_rows(N, bandwidths, smoothness, contrast, offset), **solver_options)
 
 
 def sample_tuning_curves(sample_sites=[0], track_offset_identity=False,
                          include_inhibitory_neurons=False,
                          **kwargs):
-    """ssnode.py:593-602."""
+    """Tuning curves of the probed neurons of `sample_fixed_points(**kwargs)` (ssnode.py:593-602): returns
+    ``(tunings, sample)`` with `tunings` of shape (stimuli [x sites], draws) and `sample` the finder's triple."""
     from .gradient_expressions.utils import subsample_neurons
-    _, rates, _ = sample = sample_fixed_points(**kwargs)
-    rates = np.array(rates)
-    tunings = subsample_neurons(
-        rates, sample_sites,
-        include_inhibitory_neurons=include_inhibitory_neurons,
-        track_offset_identity=track_offset_identity).T
-    return tunings, sample
+    sample = sample_fixed_points(**kwargs)
+    probed = subsample_neurons(np.array(sample[1]), sample_sites, include_inhibitory_neurons=include_inhibitory_neurons,
+                               track_offset_identity=track_offset_identity)
+    return probed.T, sample

@@ -224,6 +224,21 @@ def test_checkpoint_resume_continues_the_same_run(tmp_path):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-8)
     np.testing.assert_allclose(second.disc.get_flat(), full.disc.get_flat(), rtol=1e-4, atol=1e-6)
     assert second.disc_updater.step == full.disc_updater.step == 3 + 3 * 2
+    # format guards: the file says which format it is and what it was written with; a device-noise state of the round-1
+    # format (a torch.Generator state array) and an unknown version are refused with a KnownError, not an IndexError
+    import pickle
+    from tc_gan_amd.execution import KnownError
+    ck = pickle.load(open(path, 'rb'))
+    assert ck['version'] == 2 and ck['state']['gen_kernel'] == 'auto' and ck['state']['world'] == 1
+    noisy, _ = make_gan(dict(cfg, z_device_seed=3))
+    noisy.set_dataset(_fake_data(noisy, 9, np.random.RandomState(4)))
+    old = dict(ck, state=dict(ck['state'], zgen=np.zeros(16, dtype='uint8')))
+    pickle.dump(old, open(str(tmp_path / 'old.pkl'), 'wb'))
+    with pytest.raises(KnownError, match='earlier format'):
+        noisy.load_checkpoint(str(tmp_path / 'old.pkl'))
+    pickle.dump(dict(ck, version=99), open(str(tmp_path / 'v99.pkl'), 'wb'))
+    with pytest.raises(KnownError, match='format version'):
+        noisy.load_checkpoint(str(tmp_path / 'v99.pkl'))
 
 
 @pytest.mark.parametrize('truth_size,probes_per_model,norm_probes,inhibitory', [
