@@ -84,7 +84,9 @@ struct IoSelect {
         }
         if (__builtin_amdgcn_ballot_w64(vmax > v0_low) != 0) {
             // all NV saturating values unconditionally (pinned: left alone the compiler puts each one under its own
-            // `v > v0` branch, NV dependent exp / rcp chains one after the other), then selects
+            // `v > v0` branch, NV dependent exp / rcp chains one after the other), then selects.  The empty asm keeps this
+            // block behind its wave-uniform branch: for small NV the compiler would otherwise run it every time.
+            asm volatile("");
             float th[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {

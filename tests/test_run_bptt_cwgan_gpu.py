@@ -153,8 +153,8 @@ def test_single_g_step_with_load_config(args, config, tmp_path, monkeypatch):
     assert gen.dtype.names == ('gen_step',) + vnames + ('J_EE', 'J_EI', 'J_IE', 'J_II', 'D_EE', 'D_EI', 'D_IE', 'D_II',
                                                        'S_EE', 'S_EI', 'S_IE', 'S_II')
     assert len(gen) == 1 and all(np.isfinite(gen[n]).all() for n in gen.dtype.names)
-    if 'V' in config:        # the start value of V is the configured one (recorded before the first update)
-        np.testing.assert_allclose([gen[n][0] for n in vnames], np.atleast_1d(config['V']), rtol=1e-6)
+    if 'V' in config:        # the configured start value, one adam-wgan step (lr 0.01: +-0.01 per entry) later
+        np.testing.assert_allclose([gen[n][0] for n in vnames], np.atleast_1d(config['V']), rtol=0, atol=0.0101)
     if 'gen_V_max' in config:                                   # V_I is pinned to [0, 0]
         assert gen['V_I'][0] == 0.0
 
