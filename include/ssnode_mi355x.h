@@ -117,8 +117,9 @@ int ssn_solve_batch_f64(const double *W, const double *ext, int ext_per_draw,
  * (shape chosen by the library), 3 = tile kernel with split VGPR/LDS residency,
  * 4 = tile kernel with the whole tile in VGPRs, 5 = fp32 MFMA kernel (NB >= 4), 6 = fp16-split MFMA kernel
  * (NB >= 4, asym_tanh, dt <= tau: W and the state carried as two fp16 parts each, exact products, all 8 stimuli in one
- * chain per step), 7 = the same in the alternating two-group form (state as three parts, exact);
- * error if the size has no instantiation; negative = automatic (MFMA kernel for
+ * chain per step), 7 = the same in the alternating two-group form (state as three parts, exact), 8 = fp16-split kernel
+ * with two draws per workgroup (csrc/ssn_duo.hip; what the automatic choice takes for more than 256 (draw, 8 stimuli)
+ * units); error if the size has no instantiation; negative = automatic (MFMA kernel for
  * large fp32 batches with NB >= 4, otherwise tile > DPP > streaming). */
 int ssn_solve_batch_f32_variant(int variant, const float *W, const float *ext, int ext_per_draw,
                                 float *r, float *r_prev, int *codes, int *steps,
@@ -194,8 +195,12 @@ typedef struct ssn_gen_params {
                                   * groups in the alternating form, which carries the state as three parts (exact);
                                   * backward: the adjoint sweep in the alternating form
                                   * (W^T as two fp16 parts, delta as three with a scale that follows max |delta| step
-                                  * by step; any I/O function).  The default picks 4 / 5 where they apply unless
-                                  * SSN_FWD_SPLIT=0 is set in the environment. */
+                                  * by step; any I/O function); 8 = fp16-split forward with TWO DRAWS per workgroup
+                                  * (csrc/ssn_duo.hip: the chain of one draw behind the serial part of the other, W and
+                                  * state as two fp16 parts each by round to nearest = 23 bits; adjoint as 4).  0 picks
+                                  * 8 / 4 / 5 where they apply (8 when there are more than 256 (draw, 8 stimuli) units)
+                                  * unless ssn_set_operand_precision(0) -- or SSN_FWD_SPLIT=0 as the initial value --
+                                  * keeps the automatic choice on fp32 operands. */
     double k, n;
     double tau_E, tau_I, dt;     /* eps = dt / tau per neuron */
     double rate_soft_bound, rate_hard_bound;
@@ -205,8 +210,9 @@ typedef struct ssn_gen_params {
 /* 1 if the register-stationary generator kernels cover this size (2N <= 208 fp32, <= 104 fp64). */
 int ssn_gen_supported(int M, int dtype_bytes);
 /* Which fp32 forward kernel ssn_gen_forward_f32 runs for this call shape and p->kernel (the numbering of p->kernel:
- * 1 VALU tile / streaming kernels, 2 / 3 fp32 MFMA, 4 / 5 / 6 fp16-split MFMA: 4 two groups in the wide form, 5 one
- * group, 6 two groups in the alternating form; 7: wide form with an exact state, SSN_FWD_WIDE=3); save != 0: with trajectory stores;
+ * 1 VALU tile / streaming kernels, 2 / 3 fp32 MFMA, 4 / 5 / 6 / 8 fp16-split MFMA: 4 two groups in the wide form, 5 one
+ * group, 6 two groups in the alternating form, 8 two draws per workgroup; 7: wide form with an exact state, SSN_FWD_WIDE=3);
+ * save != 0: with trajectory stores;
  * -1: the call would be refused.  For benchmarks and tests that must name the kernel they measured. */
 int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ssn_gen_params *p);
 
@@ -214,8 +220,9 @@ int ssn_gen_forward_variant(int B, int NB, int M, int seqlen, int save, const ss
  * Forward: r_{t+1} = (1-eps) r_t + eps f(W r_t + ext), r_0 = 0, T = seqlen steps.
  *   W        device [B][M][M];  ext device [B][NB][M]
  *   time_avg device [B][NB][M]  mean over output indices >= skip_steps
- *   dyn_row  device [B][NB][M]  per-neuron SUM over the window of (x_{t+1}-x_t)^2
- *   rate_row device [B][NB][M]  per-neuron SUM over the window of relu(x_t - threshold)
+ *   dyn_row  device [B][NB][M]  SUM over the window of (x_{t+1}-x_t)^2, per neuron -- or, from the two-draw kernel (8),
+ *            per group of neurons booked on one of them (zeros elsewhere): only sum(dyn_row) is defined
+ *   rate_row device [B][NB][M]  the same for relu(x_t - threshold)
  *            (dynamics_penalty = sum(dyn_row)/(B*(T-skip-1)*NB*M), rate_penalty =
  *             sum(rate_row)/(B*(T-skip)*NB*M): the means of ssn.py:626,632)
  *   traj, df device [B][NB][T][M] or both NULL: trajectory and f'(u_t) kept for the backward

@@ -261,10 +261,21 @@ class Updater(object):
         self._state = snap[2]
 
     def __call__(self, params, grads, clip=None):
-        """In-place update of the flat device tensor `params` from `grads`."""
+        """In-place update of the flat device tensor `params` from `grads`.  `clip` = (lo, hi): scalars, or arrays of the
+        parameter's shape for bounds per element (the reference clips with numpy broadcasting, wgan.py:244-251 -- its
+        heteroin test pins V_I with V_min = [0, 0], V_max = [1, 0])."""
         if self._state is None or self._state[0].shape != params.shape:
             self._state = (torch.zeros_like(params), torch.zeros_like(params))
         self.step += 1
+        elementwise = None
+        if clip is not None and (np.ndim(clip[0]) > 0 or np.ndim(clip[1]) > 0):
+            lo = np.broadcast_to(np.asarray(clip[0], dtype='float32').ravel(), (params.numel(),))
+            hi = np.broadcast_to(np.asarray(clip[1], dtype='float32').ravel(), (params.numel(),))
+            key = (lo.tobytes(), hi.tobytes())
+            if getattr(self, '_clip_cache', (None,))[0] != key:
+                self._clip_cache = (key, torch.as_tensor(np.array(lo)).to(params.device), torch.as_tensor(np.array(hi)).to(params.device))
+            elementwise = self._clip_cache[1:]
+            clip = (float(lo.min()), float(hi.max()))
         o = clib.OptParams(kind=self.kind, step=self.step, clip=int(clip is not None), reserved=0,
                            learning_rate=self.learning_rate, beta1=self.cfg['beta1'], beta2=self.cfg['beta2'],
                            epsilon=self.cfg['epsilon'], rho=self.cfg['rho'],
@@ -274,3 +285,5 @@ class Updater(object):
         clib.check(libssnode.ssn_optimizer_step(params.data_ptr(), grads.data_ptr(), self._state[0].data_ptr(),
                                                 self._state[1].data_ptr(), params.numel(), ctypes.byref(o), _stream()),
                    'ssn_optimizer_step')
+        if elementwise is not None:
+            torch.minimum(torch.maximum(params, elementwise[0], out=params), elementwise[1], out=params)

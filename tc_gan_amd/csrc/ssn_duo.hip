@@ -464,7 +464,7 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     const LdsI flags = (LdsI)(dlds + S::SYNC);                                  // [3][8] of this draw
     // previous state of this lane's values (r_prev output): kept in LDS, 32 B per lane, rewritten with every applied step
     using LdsF4s = __attribute__((address_space(3))) mf4*;
-    const LdsF4s rp_slot = (LdsF4s)(plds + (size_t)(WV * 64 + lane) * 32);
+    const LdsF4s rp_slot = (LdsF4s)(plds + (size_t)WV * 2048 + (size_t)lane * 16);     // second half 1 KB further: conflict-free 16-byte stores
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
     using Ops = DuoOperands<MK, WV, S::nl(true)>;
@@ -493,7 +493,7 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     __hip_atomic_fetch_max(wmax + 1, __builtin_bit_cast(unsigned, r0max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     auto store_prev = [&]() {
         rp_slot[0] = (mf4){rc[0], rc[1], NE > 2 ? rc[2 % NE] : 0.f, NE > 2 ? rc[3 % NE] : 0.f};
-        if constexpr (NE > 4) rp_slot[1] = (mf4){rc[4 % NE], rc[5 % NE], NE > 6 ? rc[6 % NE] : 0.f, NE > 6 ? rc[7 % NE] : 0.f};
+        if constexpr (NE > 4) rp_slot[64] = (mf4){rc[4 % NE], rc[5 % NE], NE > 6 ? rc[6 % NE] : 0.f, NE > 6 ? rc[7 % NE] : 0.f};
     };
     store_prev();                                        // (zero steps: previous = initial state)
     __syncthreads();                                                          // (A) max |W|, max |r0| of both draws
@@ -609,7 +609,7 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
             const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
             if (row >= M) continue;
             a.r[unit * M + row] = rc[i];
-            if (a.r_prev) a.r_prev[unit * M + row] = ((const __attribute__((address_space(3))) float*)rp_slot)[i];
+            if (a.r_prev) a.r_prev[unit * M + row] = ((const __attribute__((address_space(3))) float*)rp_slot)[(i / 4) * 256 + (i % 4)];
         }
     }
     if (WV == 0 && valid && lane < 8 && s0 + lane < a.NB) {

@@ -560,6 +560,15 @@ class ConditionalBPTTWassersteinGAN(object):
         return ck['gen_step'] + 1
 
 
+def _v_bounds(v_min, v_max, ssn_type):
+    """Clip bounds of the input-variability parameter V (wgan.py:244-251, 263-283): one (V_E, V_I) pair each for
+    'heteroin' -- per element, like numpy's broadcasting clip in the reference -- a scalar each for 'deg-heteroin'."""
+    if ssn_type == 'heteroin':
+        return (np.broadcast_to(np.asarray(v_min, dtype='float64'), (2,)).copy(),
+                np.broadcast_to(np.asarray(v_max, dtype='float64'), (2,)).copy())
+    return float(np.min(v_min)), float(np.max(v_max))
+
+
 def make_gan(config):
     """make_gan(config: dict) -> (GAN, dict): build the GAN and return the unconsumed part of `config`
     (cwgan.py:555-614).  ``config['gen']`` / ``config['disc']`` hold the trainer options with the reference's
@@ -623,7 +632,7 @@ def make_gan(config):
     dynamics_cost = gen_cfg.pop('dynamics_cost', 1.0)
     rate_cost = gen_cfg.pop('rate_cost')
     bounds = {name: (gen_cfg.pop(name + '_min', 1e-3), gen_cfg.pop(name + '_max', 10.0)) for name in 'JDS'}
-    bounds['V'] = (float(np.min(gen_cfg.pop('V_min', 0))), float(np.max(gen_cfg.pop('V_max', 1))))   # wgan.py:263-283
+    bounds['V'] = _v_bounds(gen_cfg.pop('V_min', 0), gen_cfg.pop('V_max', 1), ssn_type)   # wgan.py:263-283
     gen_upd_cfg = {k: gen_cfg.pop(k) for k in list(gen_cfg) if k in ('learning_rate', 'update_name', 'update_config',
                                                                      'reg_l2_penalty', 'reg_l2_decay',
                                                                      'reg_l1_penalty', 'reg_l1_decay')}

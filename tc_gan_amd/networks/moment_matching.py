@@ -16,7 +16,7 @@ from .. import clib
 from ..clib import libssnode
 from ..critic import Updater
 from ..utils import Namespace, StopWatch
-from .cwgan import GradientAllReducer
+from .cwgan import _v_bounds, GradientAllReducer
 from .ssn import TuningCurveGenerator
 from .wgan import DEFAULT_PARAMS as _WGAN_DEFAULTS, grid_stimulator_inputs, probes_from_stim_space
 
@@ -198,7 +198,7 @@ def make_moment_matcher(config):
         shard=(reducer.rank, reducer.world),
         ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=take('gen_kernel', 'auto'))
     bounds = {name: (take(name + '_min', 1e-3), take(name + '_max', 10.0)) for name in 'JDS'}
-    bounds['V'] = (float(np.min(take('V_min', 0))), float(np.max(take('V_max', 1))))
+    bounds['V'] = _v_bounds(take('V_min', 0), take('V_max', 1), ssn_type)
     upd_cfg = {k: take(k) for k in ('learning_rate', 'update_name', 'update_config', 'reg_l2_penalty', 'reg_l2_decay',
                                     'reg_l1_penalty', 'reg_l1_decay') if k in kwargs}
     mm = BPTTMomentMatcher(
