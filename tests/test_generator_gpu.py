@@ -426,3 +426,34 @@ def test_split_kernels_random_shapes_against_the_fp32_mfma_kernels():
                 assert np.isfinite(got).all(), tag
                 scale = np.abs(want).max() if want.size else 0.0
                 np.testing.assert_allclose(got, want, rtol=2e-5, atol=3e-6 * scale + 1e-30, err_msg=tag)
+
+
+def test_two_draw_kernel_free_running_form_gives_the_same_bits():
+    """`SSN_DUO_FREE=1` runs the two-draw forward without a workgroup barrier in the time loop (per-draw LDS counters, double
+    buffered B images, flagged partial sums; kept for A/B timing).  Same arithmetic in the same order: its outputs must be
+    bit-identical to the lock-step form's, odd unit count included.  (The switch is read once per process: subprocess.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tc_gan_amd import genops\n"
+        "g = torch.Generator(device='cuda'); g.manual_seed(3)\n"
+        "W = (torch.rand((5, 200, 200), device='cuda', generator=g) - 0.6) * 0.02\n"
+        "ext = torch.rand((5, 11, 200), device='cuda', generator=g) * 40\n"
+        "gp = genops.make_gen_params(seqlen=300, skip_steps=250, kernel=8)\n"
+        "out = genops.gen_forward(W, ext, gp, save=True)\n"
+        "np.savez(sys.argv[1], ta=out['time_avg'].cpu().numpy(), traj=out['traj'].cpu().numpy(), df=out['df'].cpu().numpy(),\n"
+        "         pen=np.array([float(out['dynamics_penalty']), float(out['rate_penalty'])]))\n" % root)
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for form in ('0', '1'):
+            path = os.path.join(tmp, 'form%s.npz' % form)
+            env = dict(os.environ, SSN_DUO_FREE=form)
+            subprocess.run([sys.executable, '-c', code, path], check=True, env=env, timeout=300)
+            res[form] = dict(np.load(path))
+    assert np.isfinite(res['0']['ta']).all() and res['0']['ta'].max() > 1.0
+    for key in ('ta', 'traj', 'df', 'pen'):
+        np.testing.assert_array_equal(res['1'][key], res['0'][key])
