@@ -515,7 +515,9 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
             const bool split_ok = ssn::gen_split_backward_supported(M, NB);
             a.split_narrow = g->kernel == 6;
             const bool split = split_ok && (g->kernel >= 4 || (g->kernel == 0 && forward_split_default()));
-            if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
+            if (split_ok && (g->kernel == 8 || (g->kernel == 0 && forward_split_default() && duo_default(groups, B, NB))))
+                SSN_TRY(ssn::launch_gen_backward_duo(a, (hipStream_t)stream));
+            else if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
             else SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
             return 0;
         }

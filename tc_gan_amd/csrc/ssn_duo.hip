@@ -79,6 +79,8 @@ struct Duo16 {
     // plain forward 3.38 ms with NL = 0 against 3.67 with 4 (the extra reads sit on the chain's critical path, and it did not
     // spill); forward with stores 6.1 -> 5.6 ms, solver 40.2 -> 34.3 ms with NL = 4.
     static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? 4 : 0; }
+    // adjoint sweep: 10 state values per row and stimulus -- by the number of row tiles a wave finishes (6 or 8 values per lane)
+    static constexpr int nl_bwd(int ntf, bool gext) { return MK > 152 ? (ntf >= 4 ? 18 : 13) + (gext ? 2 : 0) : (MK > 104 ? 4 : 0); }
     static constexpr int LDS = 2 * DRAW + 16;
     static_assert(start(1) >= NKT, "a row tile is shared by at most two waves");
 };
@@ -103,8 +105,37 @@ __device__ __forceinline__ void duo_fetch(const __amdgpu_buffer_rsrc_t& rsrc, in
     for (int e = 0; e < 8; ++e) w[e] = (row < M && k0 + e < M) ? v[e] : 0.f;
 }
 
+// the same elements of W^T (adjoint sweep): A[row][k] = W[k][row]; 64-byte runs over the 16 lanes of a row tile
+__device__ __forceinline__ void duo_fetch_t(const __amdgpu_buffer_rsrc_t& rsrc, int M, int row, int k0, float (&w)[8]) {
+    const int rowc = row < M ? row : M - 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e < M ? k0 + e : M - 1;
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (k * M + rowc) * 4, 0, 0));
+        w[e] = (row < M && k0 + e < M) ? v : 0.f;
+    }
+}
+
 __device__ __forceinline__ float dpp_ror8(float x) {                  // lane li of a 16-lane row <- lane (li + 8) % 16
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
+}
+
+// max over the wave of a non-negative float (bit patterns order like the values), the same value in every lane's SGPR copy
+__device__ __forceinline__ unsigned duo_wave_max_bits(float x) {
+    unsigned v = __builtin_bit_cast(unsigned, x);
+#define SSN_DUO_DPP_MAX(CTRL, ROWMASK)                                                                                   \
+    {                                                                                                                     \
+        const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, false);                   \
+        v = o > v ? o : v;                                                                                                \
+    }
+    SSN_DUO_DPP_MAX(0xB1, 0xf)     // quad_perm [1,0,3,2]
+    SSN_DUO_DPP_MAX(0x4E, 0xf)     // quad_perm [2,3,0,1]
+    SSN_DUO_DPP_MAX(0x141, 0xf)    // row_half_mirror
+    SSN_DUO_DPP_MAX(0x140, 0xf)    // row_mirror: every lane = row max
+    SSN_DUO_DPP_MAX(0x142, 0xa)    // row_bcast15 -> rows 1, 3
+    SSN_DUO_DPP_MAX(0x143, 0xc)    // row_bcast31 -> rows 2, 3
+#undef SSN_DUO_DPP_MAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // x 2^rshift = h + m by round to nearest, two values per call; returns the packed fp16 pairs
@@ -119,7 +150,7 @@ __device__ __forceinline__ void duo_split2(float x0, float x1, float rs, unsigne
 }
 
 // A wave's share of W (two fp16 parts of W 2^a) and its MFMA chain.
-template <int MK, int WV, int NL>
+template <int MK, int WV, int NL, bool TR = false>
 struct DuoOperands {
     using S = Duo16<MK>;
     using WS = DuoWave<MK, WV>;
@@ -133,7 +164,8 @@ struct DuoOperands {
         float mx = 0.f;
         for (int u = U0; u < U1; ++u) {
             float w[8];
-            duo_fetch(rsrc, M, 16 * (u / S::NKT) + li, 32 * (u % S::NKT) + 8 * lg, w);
+            if (TR) duo_fetch_t(rsrc, M, 16 * (u / S::NKT) + li, 32 * (u % S::NKT) + 8 * lg, w);
+            else duo_fetch(rsrc, M, 16 * (u / S::NKT) + li, 32 * (u % S::NKT) + 8 * lg, w);
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
         }
@@ -145,7 +177,8 @@ struct DuoOperands {
 #pragma unroll
         for (int ui = 0; ui < NU; ++ui) {
             float w[8];
-            duo_fetch(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, w);
+            if (TR) duo_fetch_t(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, w);
+            else duo_fetch(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, w);
             hv8 m;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -649,6 +682,288 @@ __global__ void __launch_bounds__(512, 2) solve_duo_kernel(SolveArgs<float> a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The BPTT adjoint sweep in the two-draw form (lock-step phases; semantics of gen_backward_split_kernel, ssn_mfma16.hip,
+// and of gen_backward_kernel, ssn_gen.hip: time runs backwards, the wave that finishes row j keeps a_t[j], forms
+// delta_t = eps f'(u_t) a_t, hands it to the chain W^T delta_t and writes it -- shifted by one step, in place over f' --
+// to HBM).  Per draw: phase A = serial part of step tau (needs W^T delta_{tau+1} from the accumulators of the previous
+// chain), phase B = chain of step tau; the two draws of a workgroup run the two phases in opposition.
+// delta goes to the chain as TWO fp16 parts by round to nearest (|d - h - m| <= 2^-23 |d|) under a power-of-two scale that
+// follows the data with one step of lag: the scale of step tau puts max |delta_{tau+1}| of the draw at 2^7 (the four
+// waves' maxima meet in one of three rotating LDS words per draw); a step whose delta outgrows the fp16 range under that
+// scale is poisoned with NaN (see gen_backward_split_kernel).  All 8 stimuli of a draw share the scale.
+// The sweep's state (carry, f' with one prefetch, three trajectory rows with one prefetch inside the penalty window,
+// the sum of delta for dL/d ext: 9 values per row and stimulus) lives in registers next to W^T, which is why the low parts
+// of the last 13 units of every wave stay in LDS here, 18 in the wave that finishes four row tiles (Duo16::nl_bwd; with 14
+// everywhere that wave still spilled two operands into its chain: 4000 cycles per chain instead of 1400).
+// ---------------------------------------------------------------------------------------------------------------
+template <int MK, int WV, bool GEXT>
+__device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, int d, int b, int s0, bool valid, int lane,
+                                                  char* dlds, char* wwlds, unsigned* wmax) {
+    using S = Duo16<MK>;
+    using WS = DuoWave<MK, WV>;
+    constexpr int NT = WS::NT, NTF = WS::NTF, RT0 = WS::RT0;
+    constexpr int NE = 2 * NTF;
+    const int M = a.M, N = a.M / 2, T_ = a.seqlen;
+    const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
+    using Ops = DuoOperands<MK, WV, S::nl_bwd(WS::NTF, GEXT), true>;
+    atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)));
+    using LdsH8 = const __attribute__((address_space(3))) hv8*;
+    using LdsF4 = __attribute__((address_space(3))) mf4*;
+    using LdsU = __attribute__((address_space(3))) unsigned*;
+    using LdsUC = volatile const __attribute__((address_space(3))) unsigned*;
+    const unsigned bimg = (unsigned)(size_t)(LdsH8)dlds;
+    // (lock-step only: ONE B image per draw -- the second one of the common layout is LDS this kernel needs for W^T)
+    constexpr int SYNCB = S::BB + (S::WM - 1) * S::XS;
+    const unsigned xs = bimg + (unsigned)S::BB + (unsigned)(lane * 16);
+    const unsigned b_rd = bimg + (unsigned)(lg * S::BROW + li * 16);
+    const unsigned b_wr = bimg + (unsigned)((lg >> 1) * S::BROW + st * 16 + (lg & 1) * 8 + hi * 4);
+    const unsigned slots = bimg + (unsigned)SYNCB;                              // three rotating words: max |delta| bit patterns
+    auto slot = [&](int tau) { return slots + 4u * (unsigned)((tau + 3) % 3); };
+    // ---- the values this lane finishes
+    const int s = s0 + st;
+    const bool live = valid && s < a.NB;
+    const float inv = 1.f / (float)(T_ - a.skip);
+    const size_t blk_elems = (size_t)a.NB * T_ * M;
+    const __amdgpu_buffer_rsrc_t rs_traj =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.traj) + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_dlt =
+        __builtin_amdgcn_make_buffer_rsrc(a.delta + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
+    const int toff = live ? (int)(((size_t)s * T_ * M + 4 * lg + 2 * hi) * 4) : -1;     // (stimulus, index 0, row 4 lg + 2 hi)
+    // byte offset of the row pair of finished tile tf at stream index t (-1: nothing there)
+    auto at = [&](int tf, int t) { return (toff < 0 || 16 * (RT0 + tf) + 4 * lg + 2 * hi >= M) ? -1 : toff + (t * M + 16 * (RT0 + tf)) * 4; };
+    auto load2 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float& x0, float& x1) {
+        const fv2 q = __builtin_bit_cast(fv2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+        x0 = q.x; x1 = q.y;
+    };
+    auto store2 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float x0, float x1) {
+        const fv2 q = {x0, x1};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), q), rs, off, 0, 0);
+    };
+    // f'(u) of three consecutive steps in a rotating set of registers: the step with phase PH = (T - tau) % 3 uses
+    // df3[(PH + 1) % 3] and loads, two steps ahead, into df3[PH] -- no register copies between steps, so the wait for a
+    // load sits two steps (four phases) behind its issue instead of at the end of the serial part that issued it
+    float eps[NE], gta[NE], carry[NE], dsum[NE], xn[NE], xc[NE], xm[NE], pxm[NE], df3[3][NE];
+    bool rowok[NE];
+    auto direct = [&](int i, int tau) {            // dL/dx_tau inside the penalty window (time average, rate and dynamics terms)
+        float gg = gta[i] + ((xc[i] > a.theta) ? a.c_rate : 0.f);
+        if (tau <= T_ - 1) gg -= 2.f * a.c_dyn * (xn[i] - xc[i]);
+        if (tau >= a.skip + 2) gg += 2.f * a.c_dyn * (xc[i] - xm[i]);
+        return gg;
+    };
+    float m0 = 0.f;
+#pragma unroll
+    for (int tf = 0; tf < NTF; ++tf) {
+        const int row = 16 * (RT0 + tf) + 4 * lg + 2 * hi;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * tf + e;
+            rowok[i] = row + e < M;
+            eps[i] = row + e < N ? a.eps_E : a.eps_I;
+            gta[i] = (live && row + e < M) ? a.g_time_avg[((size_t)b * a.NB + s) * M + row + e] * inv : 0.f;
+            carry[i] = dsum[i] = xn[i] = 0.f;
+        }
+        load2(rs_traj, at(tf, T_ - 1), xc[2 * tf], xc[2 * tf + 1]);                       // x_T
+        if (T_ >= 2) load2(rs_traj, at(tf, T_ - 2), xm[2 * tf], xm[2 * tf + 1]); else xm[2 * tf] = xm[2 * tf + 1] = 0.f;
+        load2(rs_dlt, at(tf, T_ - 1), df3[1][2 * tf], df3[1][2 * tf + 1]);                 // f'(u_T): phase 0 uses df3[1]
+        store2(rs_dlt, at(tf, T_ - 1), 0.f, 0.f);                                          // slot T - 1 of the shifted delta stays zero
+        if (T_ >= 3) load2(rs_traj, at(tf, T_ - 3), pxm[2 * tf], pxm[2 * tf + 1]); else pxm[2 * tf] = pxm[2 * tf + 1] = 0.f;
+        if (T_ >= 2) load2(rs_dlt, at(tf, T_ - 2), df3[2][2 * tf], df3[2][2 * tf + 1]);    // f'(u_{T-1}): phase 1 uses df3[2]
+        else df3[2][2 * tf] = df3[2][2 * tf + 1] = 0.f;
+        df3[0][2 * tf] = df3[0][2 * tf + 1] = 0.f;
+        // the first step's scale: max |delta_T| (carry = 0), or of eps |a_T| 2^-20 if f' vanishes everywhere
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * tf + e;
+            if (!rowok[i] || !live) continue;
+            const float a_T = (T_ >= a.skip + 1) ? direct(i, T_) : 0.f;
+            m0 = fmaxf(m0, fmaxf(__builtin_fabsf(eps[i] * df3[1][i] * a_T), __builtin_fabsf(eps[i] * a_T) * 9.5367431640625e-07f));
+        }
+    }
+    {
+        const unsigned wm0 = duo_wave_max_bits(m0);
+        if (lane == 0) __hip_atomic_fetch_max((__attribute__((address_space(3))) unsigned*)(dlds + SYNCB) + (T_ + 1 + 3) % 3, wm0,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();                                                          // (A) max |W| and the first delta scale
+    const int wexp = duo_w_exp(*wmax);
+    Ops ops;
+    ops.load(rsrc, M, li, lg, duo_pow2(wexp), wwlds, lane);
+
+    mf4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+    int bused = 0;                                  // the scale exponent the draw's delta in LDS was written with
+    unsigned lastref = 0u;
+    auto chain = [&]() {
+        ops.chain(b_rd, acc);
+        if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
+    };
+    auto serial = [&](auto WIN, auto PH, int tau) {
+        constexpr bool win_on = decltype(WIN)::value;
+        constexpr int ph = decltype(PH)::value;
+        float (&dfc)[NE] = df3[(ph + 1) % 3];
+        float (&ndf)[NE] = df3[ph];
+        // loads for two steps ahead (f' into the rotating set; the trajectory row of the window is copied into place at the end)
+        float nxm[NE];
+#pragma unroll
+        for (int tf = 0; tf < NTF; ++tf) {
+            nxm[2 * tf] = nxm[2 * tf + 1] = 0.f;
+            if constexpr (win_on)         // (an offset of -1 is out of range for the buffer: the load returns zeros, no branch)
+                load2(rs_traj, (tau >= 4 && tau >= a.skip + 3) ? at(tf, tau - 4) : -1, nxm[2 * tf], nxm[2 * tf + 1]);
+        }
+        // scale of this step's delta from the previous step's maximum (kept when that was exactly zero)
+        const unsigned mprev = (unsigned)__builtin_amdgcn_readfirstlane((int)*(LdsUC)(size_t)slot(tau + 1));
+        if (WV == 0 && lane == 0) *(LdsU)(size_t)slot(tau + 2) = 0u;             // next step's word (last read two phases ago)
+        const unsigned ref = mprev ? mprev : lastref;
+        lastref = ref;
+        int bexp = 7 - ((int)((ref >> 23) & 0xffu) - 127);
+        bexp = ref == 0u ? 0 : (bexp > 100 ? 100 : (bexp < -100 ? -100 : bexp));
+        if (tau < T_) {                             // W^T delta_{tau+1} 2^(a + bused) from the accumulators of the last chain
+            const float usc = duo_pow2(-wexp - bused);
+#pragma unroll
+            for (int tf = 0; tf < NTF; ++tf) {
+                mf4 sm = acc[tf];
+                if constexpr (WS::HEAD_SHARED) {
+                    if (tf == 0) {
+                        const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                        sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
+                    }
+                }
+                const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
+                const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
+                carry[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, carry[2 * tf]);
+                carry[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, carry[2 * tf + 1]);
+            }
+        }
+        float delta[NE], dm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            float gg = 0.f;
+            if constexpr (win_on) gg = direct(i, tau);
+            const float a_t = gg + carry[i];
+            delta[i] = (rowok[i] && live) ? eps[i] * dfc[i] * a_t : 0.f;
+            dm = fmaxf(dm, __builtin_fabsf(delta[i]));
+            carry[i] = fmaf(-eps[i], a_t, a_t);                                   // (1 - eps) a_t
+            if (GEXT) dsum[i] += delta[i];
+            if constexpr (win_on) { xn[i] = xc[i]; xc[i] = xm[i]; xm[i] = pxm[i]; pxm[i] = nxm[i]; }
+        }
+        // (after the last use of this phase's f': its registers are free for nothing else; the load two steps ahead goes
+        // into the set the step before last used)
+#pragma unroll
+        for (int tf = 0; tf < NTF; ++tf) {
+            load2(rs_dlt, (tau >= 3 && !(SSN_DUO_ABLATE & 32)) ? at(tf, tau - 3) : -1, ndf[2 * tf], ndf[2 * tf + 1]);
+        }
+        const float rs = live ? duo_pow2(bexp) : 0.f;
+        if (!(dm * rs < 65504.f)) delta[0] = __builtin_nanf("");                   // outgrew the lagged scale: poison, do not clamp
+#pragma unroll
+        for (int tf = 0; tf < NTF; ++tf) {
+            const int rt = RT0 + tf;
+            unsigned h, m;
+            duo_split2(delta[2 * tf], delta[2 * tf + 1], rs, h, m);
+            const unsigned wr = b_wr + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW);
+            *(LdsU)(size_t)wr = h;
+            *(LdsU)(size_t)(wr + 128u) = m;
+            store2(rs_dlt, (tau >= 2 && !(SSN_DUO_ABLATE & 16)) ? at(tf, tau - 2) : -1, delta[2 * tf], delta[2 * tf + 1]);    // shifted: pairs with x_{tau-1}
+        }
+        bused = bexp;
+        // one LDS atomic per wave (64 lanes on one address serialise: 16.6 -> 9.x ms): wave maximum first, six DPP steps
+        const unsigned wm = duo_wave_max_bits(live ? dm : 0.f);
+        if (lane == 0) __hip_atomic_fetch_max((__attribute__((address_space(3))) unsigned*)(dlds + SYNCB) + (tau + 3) % 3, wm,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    constexpr std::integral_constant<bool, false> W0{};
+    constexpr std::integral_constant<bool, true> W1{};
+    __syncthreads();                                                          // (B)
+    if (d) __syncthreads();                            // draw 1 runs one phase behind draw 0
+    auto step = [&](auto WIN, auto PH, int tau) {
+        serial(WIN, PH, tau);
+        __syncthreads();
+        chain();
+        __syncthreads();
+    };
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    constexpr std::integral_constant<int, 2> P2{};
+    int tau = T_, ph = 0;
+    for (; tau >= a.skip + 1 && tau >= 1; --tau) {     // window steps first (time runs backwards)
+        if (ph == 0) step(W1, P0, tau); else if (ph == 1) step(W1, P1, tau); else step(W1, P2, tau);
+        ph = ph == 2 ? 0 : ph + 1;
+    }
+#if SSN_DUO_STAMP
+    {
+        unsigned long long ts = 0, tb1 = 0, tc = 0, tb2 = 0; int n = 0;
+        for (; tau >= 1; --tau, ++n) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            if (ph == 0) serial(W0, P0, tau); else if (ph == 1) serial(W0, P1, tau); else serial(W0, P2, tau);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            chain();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            ts += t1 - t0; tb1 += t2 - t1; tc += t3 - t2; tb2 += t4 - t3;
+            ph = ph == 2 ? 0 : ph + 1;
+        }
+        if (blockIdx.x == 0 && (WV == 0 || WV == 3) && d == 0 && lane == 0) {
+            unsigned long long* o = duo_stamps + (WV == 0 ? 0 : 4);
+            o[0] = tc; o[1] = tb2; o[2] = ts; o[3] = tb1; duo_stamps[8] = (unsigned long long)n;
+        }
+    }
+#else
+    for (; tau >= 1; --tau) {
+        if (ph == 0) step(W0, P0, tau); else if (ph == 1) step(W0, P1, tau); else step(W0, P2, tau);
+        ph = ph == 2 ? 0 : ph + 1;
+    }
+#endif
+    if (!d) __syncthreads();
+    if (GEXT && live) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
+            if (row < M) a.g_ext[((size_t)b * a.NB + s) * M + row] = dsum[i];
+        }
+    }
+}
+
+template <int MK, bool GEXT>
+__global__ void __launch_bounds__(512, 2) gen_backward_duo_kernel(GenBwdArgs<float> a) {
+    using S = Duo16<MK>;
+    // LDS-resident part of W^T per wave of a draw (by the row tiles the wave finishes), and its prefix sums
+    constexpr int WL0 = S::nl_bwd(DuoWave<MK, 0>::NTF, GEXT) * 1024, WL1 = S::nl_bwd(DuoWave<MK, 1>::NTF, GEXT) * 1024,
+                  WL2 = S::nl_bwd(DuoWave<MK, 2>::NTF, GEXT) * 1024, WL3 = S::nl_bwd(DuoWave<MK, 3>::NTF, GEXT) * 1024;
+    constexpr int WLD = WL0 + WL1 + WL2 + WL3;                        // per draw
+    constexpr int DRAWB = S::BB + (S::WM - 1) * S::XS + 32;          // per draw: one B image, partial-sum slots, scale words
+    constexpr int LDSB = 2 * DRAWB + 16;
+    __shared__ __align__(16) char lds[LDSB + 2 * WLD + 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int d = wave >> 2;
+    const int ngroups = (a.NB + 7) / 8;
+    const long nunits = (long)a.B * ngroups;
+    long unit = 2L * blockIdx.x + d;
+    const bool valid = unit < nunits;
+    if (!valid) unit = nunits - 1;
+    const int b = (int)(unit / ngroups), s0 = (int)(unit % ngroups) * 8;
+    for (int c = threadIdx.x; c < LDSB / 4; c += blockDim.x) reinterpret_cast<unsigned*>(lds)[c] = 0u;
+    __syncthreads();
+    char* const dlds = lds + d * DRAWB;
+    const int wq = wave & 3;
+    char* const wwlds = lds + LDSB + d * WLD + (wq > 0 ? WL0 : 0) + (wq > 1 ? WL1 : 0) + (wq > 2 ? WL2 : 0);
+    unsigned* const wmax = reinterpret_cast<unsigned*>(lds + 2 * DRAWB) + d;
+    switch (wave & 3) {
+        case 0: duo_backward_wave<MK, 0, GEXT>(a, d, b, s0, valid, lane, dlds, wwlds, wmax); break;
+        case 1: duo_backward_wave<MK, 1, GEXT>(a, d, b, s0, valid, lane, dlds, wwlds, wmax); break;
+        case 2: duo_backward_wave<MK, 2, GEXT>(a, d, b, s0, valid, lane, dlds, wwlds, wmax); break;
+        default: duo_backward_wave<MK, 3, GEXT>(a, d, b, s0, valid, lane, dlds, wwlds, wmax); break;
+    }
+}
+
 // SSN_DUO_FREE=1: the free-running form (per-draw LDS counters, no workgroup barrier in the time loop) instead of the
 // lock-step one (one workgroup barrier per phase).  Same results bit for bit; measured 3.50 against 3.38 ms at C3, so the
 // lock-step form is the default and this one stays for A/B timing.
@@ -700,6 +1015,24 @@ hipError_t launch_solve_duo(const SolveArgs<float>& a, hipStream_t st) {
         case 104: return launch_duo_solve_mk<104>(a, st);
         case 152: return launch_duo_solve_mk<152>(a, st);
         case 208: return launch_duo_solve_mk<208>(a, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MK>
+static hipError_t launch_duo_bwd_mk(const GenBwdArgs<float>& a, hipStream_t st) {
+    const long nunits = (long)a.B * ((a.NB + 7) / 8);
+    const dim3 grid((unsigned)((nunits + 1) / 2));
+    if (a.g_ext) hipLaunchKernelGGL((gen_backward_duo_kernel<MK, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gen_backward_duo_kernel<MK, false>), grid, dim3(512), 0, st, a);
+    return hipGetLastError();
+}
+// applicability: gen_split_backward_supported (any I/O function: the scale follows the data)
+hipError_t launch_gen_backward_duo(const GenBwdArgs<float>& a, hipStream_t st) {
+    switch (duo_pick_mk(a.M)) {
+        case 104: return launch_duo_bwd_mk<104>(a, st);
+        case 152: return launch_duo_bwd_mk<152>(a, st);
+        case 208: return launch_duo_bwd_mk<208>(a, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -83,6 +83,7 @@ hipError_t launch_gen_backward_split(const GenBwdArgs<float>& a, hipStream_t st)
 // ssn_duo.hip: two draws per workgroup, every wave both roles (wide operand layout, state as two fp16 parts by round to nearest)
 hipError_t launch_gen_forward_duo(const GenFwdArgs<float>& a, hipStream_t st);
 hipError_t launch_solve_duo(const SolveArgs<float>& a, hipStream_t st);
+hipError_t launch_gen_backward_duo(const GenBwdArgs<float>& a, hipStream_t st);
 hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st);
 hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st);
 

@@ -45,7 +45,15 @@
                                 // read seven times (wrong results, timing only)
 #endif
 
+#ifndef SSN_SPLIT_STAMP
+#define SSN_SPLIT_STAMP 0       // diagnostic build: cycle stamps of the adjoint's serial wave (ssn_debug_split_stamps)
+#endif
+
 namespace ssn {
+
+#if SSN_SPLIT_STAMP
+__device__ unsigned long long split_stamps[8];
+#endif
 
 typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
 typedef unsigned uv2 __attribute__((ext_vector_type(2)));
@@ -854,12 +862,33 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
         if (gpw == 2) serial(G1, W1, tau);            // phase 2 (T - tau) + 1
         __syncthreads();
     }
+#if SSN_SPLIT_STAMP
+    {   // diagnostic build: s_memtime per segment of the non-window steps, serial wave 0 of workgroup 0
+        unsigned long long ts = 0, tb = 0; int n = 0;
+        for (; tau >= 1; --tau) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            serial(G0, W0, tau);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            if (gpw == 2) serial(G1, W0, tau);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+            ts += (t1 - t0) + (t3 - t2); tb += (t2 - t1) + (t4 - t3); ++n;
+        }
+        if (blockIdx.x == 0 && sw == 0 && lane == 0) { split_stamps[0] = ts; split_stamps[1] = tb; split_stamps[2] = (unsigned long long)n; }
+    }
+#else
     for (; tau >= 1; --tau) {
         serial(G0, W0, tau);
         __syncthreads();
         if (gpw == 2) serial(G1, W0, tau);
         __syncthreads();
     }
+#endif
     if (a.g_ext) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -1466,3 +1495,9 @@ hipError_t launch_gen_backward_split(const GenBwdArgs<float>& a, hipStream_t st)
 }
 
 }  // namespace ssn
+
+#if SSN_SPLIT_STAMP
+extern "C" int ssn_debug_split_stamps(unsigned long long* out8) {
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(ssn::split_stamps), 8 * sizeof(unsigned long long));
+}
+#endif

@@ -79,7 +79,10 @@ def test_forward_reductions_vs_oracle(io_type, N, B, NB, dtype, kernel):
     (201, 1, 1, 'float32', 0),
     # trajectory-saving forward and adjoint sweep on the fp16-split MFMA kernels
     (100, 1, 8, 'float32', 4), (76, 2, 5, 'float32', 5), (101, 1, 8, 'float32', 4), (50, 2, 9, 'float32', 4),
-    (33, 1, 4, 'float32', 5), (104, 1, 6, 'float32', 4), (100, 1, 8, 'float32', 6)])
+    (33, 1, 4, 'float32', 5), (104, 1, 6, 'float32', 4), (100, 1, 8, 'float32', 6),
+    # trajectory-saving forward and adjoint sweep in the two-draw form (8; adjoint: any I/O function)
+    (100, 1, 8, 'float32', 8), (100, 3, 8, 'float32', 8), (76, 2, 5, 'float32', 8), (101, 1, 8, 'float32', 8),
+    (50, 2, 9, 'float32', 8), (33, 1, 4, 'float32', 8), (104, 2, 6, 'float32', 8)])
 def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype, kernel):
     """dL/dJ, dL/dD, dL/dS for L = sum(G * time_avg) + c_d * dyn_pen + c_r * rate_pen."""
     from tc_gan_amd import genops, stimuli, weight_gen
@@ -299,7 +302,7 @@ def test_split_adjoint_matches_fp32_adjoint_step_by_step(N, B, NB, T, skip, taus
     gp2 = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=1.0, kernel=2, **gen)
     out = genops.gen_forward(W, ext, gp2, save=True)
     res = {}
-    for kernel in (2, 4, 5, 6):
+    for kernel in (2, 4, 5, 6, 8):
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=1.0, kernel=kernel, **gen)
         d, gx = genops.gen_backward(W, out['traj'], out['df'].clone(), G, 1e-3, 1e-3, gp, want_g_ext=True)
         res[kernel] = (d.cpu().numpy().astype('float64'), gx.cpu().numpy().astype('float64'))
@@ -320,6 +323,11 @@ def test_split_adjoint_matches_fp32_adjoint_step_by_step(N, B, NB, T, skip, taus
     np.testing.assert_array_equal(res[4][0], res[6][0])
     err6 = np.abs(res[6][0] - d2).max(axis=(0, 1, 3))[live] / per_step[live]
     assert err6.max() < 5e-6
+    # the two-draw form: delta as two fp16 parts by round to nearest, one scale per draw (all 8 stimuli)
+    err8 = np.abs(res[8][0] - d2).max(axis=(0, 1, 3))[live] / per_step[live]
+    print('adjoint, two-draw form: max over steps of |duo - fp32| / max|delta_t| = %.2e' % err8.max())
+    assert np.isfinite(res[8][0]).all() and err8.max() < 5e-6
+    np.testing.assert_allclose(res[8][1], res[2][1], rtol=1e-5, atol=1e-6 * np.abs(res[2][1]).max())
 
 
 @pytest.mark.parametrize('soft,hard,contrast', [(200., 1000., 2000.), (2000., 20000., 5e4), (0.2, 0.5, 20.), (200., 1000., 20.)])
@@ -363,7 +371,7 @@ def test_split_kernels_propagate_nan_and_terminate():
     W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
     W[1, 7, 9] = float('nan')
     ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
-    for kernel in (4, 8):                                      # (8: the two draws share a workgroup)
+    for kernel in (4, 8):                                      # (8: the two draws share a workgroup, forward and adjoint)
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=kernel, **GEN)
         out = genops.gen_forward(W, ext, gp, save=True)
         ta = out['time_avg'].cpu().numpy()

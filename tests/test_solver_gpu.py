@@ -454,6 +454,36 @@ def test_split_solver_initial_states_beyond_the_rate_bound_and_refusals():
                                variant=variant)
 
 
+def test_two_draw_solver_with_per_draw_stimuli_large_batch_and_mixed_stop_steps(oracle_lib):
+    """Variant 8 on what the automatic dispatch gives it: > 256 (draw, 8 stimuli) units, stimuli per draw, start states
+    that differ per draw, default tolerances -- so the two draws of a workgroup stop at different steps and one half idles
+    until the other is done.  Codes and steps per pair as the tile kernel's; states within fp32 tolerance."""
+    from tc_gan_amd.clib import SolverParams, libssnode
+    from tc_gan_amd.ssnode import fixed_points_batch
+    import ctypes
+    N, B, NB = 50, 301, 8                     # odd unit count as well
+    Ws, exts = _inputs(N, B, NB, seed=21)
+    rs = np.random.RandomState(3)
+    extb = np.stack([exts * (0.2 + 1.6 * rs.rand()) for _ in range(B)])
+    r0 = rs.rand(B, NB, 2 * N) * np.where(np.arange(B) % 3 == 0, 30.0, 0.0)[:, None, None]
+    # (atol 1e-4: well above the fp32 rounding noise of |r1 - r0| at these rates -- up to 8e-6 at r = 100 -- so that
+    # whether a pair converges does not depend on a kernel's summation order)
+    kw = dict(r0=r0, max_iter=20000, atol=1e-4, dtype='float32', want_prev=True)
+    a = fixed_points_batch(Ws, extb, P['k'], P['n'], variant=8, **kw)
+    b = fixed_points_batch(Ws, extb, P['k'], P['n'], variant=2, **kw)
+    np.testing.assert_array_equal(a.codes, b.codes)
+    assert (a.codes == 0).all() and a.steps.min() < 0.7 * a.steps.max()      # really different stop steps
+    assert np.abs(a.steps - b.steps).max() <= 0.2 * b.steps.max()
+    np.testing.assert_allclose(a.x, b.x, rtol=RTOL32, atol=1e-3)
+    assert np.abs(a.x - a.x_prev).max() < 1e-3
+    # and it is what the library picks by itself for this shape
+    p = SolverParams(io_type=2, max_iter=100, k=P['k'], n=P['n'], tau_E=P['tau'][0], tau_I=P['tau'][1], dt=8e-4, atol=1e-5,
+                     rate_soft_bound=200., rate_hard_bound=1000.)
+    assert libssnode.ssn_solve_batch_variant_for(B, NB, 2 * 100, 4, ctypes.byref(p)) == 8
+    assert libssnode.ssn_solve_batch_variant_for(200, NB, 2 * 100, 4, ctypes.byref(p)) == 6
+    assert libssnode.ssn_solve_batch_variant_for(B, 1, 2 * 100, 4, ctypes.byref(p)) == 2
+
+
 @pytest.mark.parametrize('variant', [2, 5, 6, 7, 8])
 def test_fp32_solver_kernels_reach_the_fp64_fixed_points(variant):
     """The reference pins its fixed-time network against `sample_fixed_points(atol=1e-10)` at 1e-4 after 10000 steps

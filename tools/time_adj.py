@@ -1,0 +1,24 @@
+import os, sys, torch
+sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/tc_gan_amd') else os.getcwd())
+from tc_gan_amd import genops
+B, NB, M, T, skip = 1024, 8, 200, 1200, 1000
+g = torch.Generator(device='cuda'); g.manual_seed(1)
+W = (torch.rand((B, M, M), device='cuda', generator=g) - 0.6) * 0.02
+ext = torch.rand((B, NB, M), device='cuda', generator=g) * 20
+gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=8)
+out = genops.gen_forward(W, ext, gp, save=True)
+gta = torch.rand((B, NB, M), device='cuda', generator=g)
+traj, df = out['traj'], out['df']
+def bwd(): return genops.gen_backward(W, traj, df, gta, 1.0, 0.01, gp)
+bwd(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): bwd()
+e1.record(); torch.cuda.synchronize()
+print('adjoint (duo, in place, repeated) %.2f ms' % (e0.elapsed_time(e1) / 3))
+if hasattr(genops.libssnode, 'ssn_debug_duo_stamps'):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 16)()
+    genops.libssnode.ssn_debug_duo_stamps(buf)
+    n = max(int(buf[8]), 1)
+    for name, o in (('wave 0', 0), ('wave 3', 4)):
+        print('  draw 0 %s: chain %.0f  barrier %.0f  serial %.0f  barrier %.0f cycles per step' % ((name,) + tuple(buf[o + i] / n for i in range(4))))

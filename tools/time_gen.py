@@ -44,6 +44,13 @@ def main():
         return genops.gen_backward(W, traj, df, gta, 1.0, 0.01, gp)
     t_copy = timed(lambda: df.copy_(keep))
     print('adjoint sweep    %.2f ms' % (timed(bwd) - t_copy))
+    if hasattr(genops.libssnode, 'ssn_debug_split_stamps'):          # diagnostic build (-DSSN_SPLIT_STAMP=1)
+        import ctypes
+        buf = (ctypes.c_ulonglong * 8)()
+        torch.cuda.synchronize()
+        genops.libssnode.ssn_debug_split_stamps(buf)
+        n = max(int(buf[2]), 1)
+        print('  adjoint serial wave 0: serial parts %.0f + barrier waits %.0f cycles per step (two phases)' % (buf[0] / n, buf[1] / n))
     delta = bwd()
     print('dL/dW bmm        %.2f ms' % timed(lambda: genops.weight_grad(delta, traj)))
 
