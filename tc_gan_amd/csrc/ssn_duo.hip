@@ -80,7 +80,9 @@ struct Duo16 {
     // spill); forward with stores 6.1 -> 5.6 ms, solver 40.2 -> 34.3 ms with NL = 4.
     static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? 4 : 0; }
     // adjoint sweep: 10 state values per row and stimulus -- by the number of row tiles a wave finishes (6 or 8 values per lane)
-    static constexpr int nl_bwd(int ntf, bool gext) { return MK > 152 ? (ntf >= 4 ? 18 : 13) + (gext ? 2 : 0) : (MK > 104 ? 4 : 0); }
+    // (window steps / the steps after the window: the window keeps four trajectory rows per value in registers)
+    static constexpr int nl_bwd_win(int ntf) { return MK > 152 ? (ntf >= 4 ? 20 : 16) : (MK > 104 ? 4 : 0); }
+    static constexpr int nl_bwd(int ntf, bool gext) { return MK > 152 ? (ntf >= 4 ? 12 : 8) + (gext ? 4 : 0) : (MK > 104 ? 4 : 0); }
     static constexpr int LDS = 2 * DRAW + 16;
     static_assert(start(1) >= NKT, "a row tile is shared by at most two waves");
 };
@@ -190,6 +192,21 @@ struct DuoOperands {
             if (ui < NR) Am[ui < NR ? ui : 0] = m;
             else *(LdsH8)(size_t)(wl + (unsigned)((ui - NR) * 1024)) = m;
         }
+    }
+    // Take over the operands of `o`, which keeps MORE units in LDS (NL2 >= NL), and pull the difference into registers
+    // (adjoint sweep: the penalty-window steps need the registers for trajectory rows, the steps after them do not).
+    template <int NL2>
+    __device__ __forceinline__ void promote_from(const DuoOperands<MK, WV, NL2, TR>& o) {
+        static_assert(NL2 >= NL, "promotion only moves units from LDS into registers");
+        constexpr int NR2 = NU - NL2;
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui) Ah[ui] = o.Ah[ui];
+#pragma unroll
+        for (int ui = 0; ui < NR; ++ui) {
+            if (ui < NR2) Am[ui] = o.Am[ui < NR2 ? ui : 0];
+            else Am[ui] = *(LdsH8)(size_t)(o.wl + (unsigned)((ui - NR2) * 1024));
+        }
+        wl = o.wl + (unsigned)((NR - NR2) * 1024);
     }
     // acc[t] = (W_h + W_m)[row tile RT0 + t, my k range] . B, B read from the image at LDS byte address rd (per lane)
     __device__ __forceinline__ void chain(unsigned rd, mf4 (&acc)[NT]) const {
@@ -694,8 +711,9 @@ __global__ void __launch_bounds__(512, 2) solve_duo_kernel(SolveArgs<float> a) {
 // scale is poisoned with NaN (see gen_backward_split_kernel).  All 8 stimuli of a draw share the scale.
 // The sweep's state (carry, f' with one prefetch, three trajectory rows with one prefetch inside the penalty window,
 // the sum of delta for dL/d ext: 9 values per row and stimulus) lives in registers next to W^T, which is why the low parts
-// of the last 13 units of every wave stay in LDS here, 18 in the wave that finishes four row tiles (Duo16::nl_bwd; with 14
-// everywhere that wave still spilled two operands into its chain: 4000 cycles per chain instead of 1400).
+// of the last 16 / 20 units of a wave (three / four row tiles finished) stay in LDS through the penalty window and 8 / 12
+// after it, when the trajectory rows are gone and the difference is pulled into registers (Duo16::nl_bwd_win, nl_bwd;
+// an operand spilled to scratch instead costs its chain 4000 cycles instead of 1400).
 // ---------------------------------------------------------------------------------------------------------------
 template <int MK, int WV, bool GEXT>
 __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, int d, int b, int s0, bool valid, int lane,
@@ -708,7 +726,8 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
-    using Ops = DuoOperands<MK, WV, S::nl_bwd(WS::NTF, GEXT), true>;
+    using Ops = DuoOperands<MK, WV, S::nl_bwd_win(WS::NTF), true>;             // window steps
+    using OpsN = DuoOperands<MK, WV, S::nl_bwd(WS::NTF, GEXT), true>;            // the steps after the window
     atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)));
     using LdsH8 = const __attribute__((address_space(3))) hv8*;
     using LdsF4 = __attribute__((address_space(3))) mf4*;
@@ -731,16 +750,26 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.traj) + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_dlt =
         __builtin_amdgcn_make_buffer_rsrc(a.delta + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
-    const int toff = live ? (int)(((size_t)s * T_ * M + 4 * lg + 2 * hi) * 4) : -1;     // (stimulus, index 0, row 4 lg + 2 hi)
-    // byte offset of the row pair of finished tile tf at stream index t (-1: nothing there)
-    auto at = [&](int tf, int t) { return (toff < 0 || 16 * (RT0 + tf) + 4 * lg + 2 * hi >= M) ? -1 : toff + (t * M + 16 * (RT0 + tf)) * 4; };
-    auto load2 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float& x0, float& x1) {
-        const fv2 q = __builtin_bit_cast(fv2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+    // Addresses of the two streams: byte offset = lane part (stimulus, row 4 lg + 2 hi within a tile: ONE register per
+    // finished tile, -1 = this lane has nothing there: out of range for the buffer, loads return zeros and stores are
+    // dropped) + uniform part (stream index, row tile) in the instruction's scalar offset.  The hardware's range check sees
+    // the lane part only, so a step that has no such index (tau - 3 < 0 ...) goes to a descriptor of zero records instead.
+    const int toff = live ? (int)(((size_t)s * T_ * M + 4 * lg + 2 * hi) * 4) : -1;
+    int voff[NTF];
+#pragma unroll
+    for (int tf = 0; tf < NTF; ++tf) voff[tf] = (toff < 0 || 16 * (RT0 + tf) + 4 * lg + 2 * hi >= M) ? -1 : toff;
+    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.traj), 0, 0, 0x00020000);
+    struct At { int tf, t; };
+    auto at = [&](int tf, int t) { return At{tf, t}; };
+    auto soff = [&](const At& p) { return (p.t * M + 16 * (RT0 + p.tf)) * 4; };
+    auto load2 = [&](const __amdgpu_buffer_rsrc_t& rs, bool on, const At& p, float& x0, float& x1) {
+        const fv2 q = __builtin_bit_cast(fv2, __builtin_amdgcn_raw_buffer_load_b64(on ? rs : rs_none, voff[p.tf], on ? soff(p) : 0, 0));
         x0 = q.x; x1 = q.y;
     };
-    auto store2 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float x0, float x1) {
+    auto store2 = [&](const __amdgpu_buffer_rsrc_t& rs, bool on, const At& p, float x0, float x1) {
         const fv2 q = {x0, x1};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), q), rs, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), q), on ? rs : rs_none,
+                                              voff[p.tf], on ? soff(p) : 0, 0);
     };
     // f'(u) of three consecutive steps in a rotating set of registers: the step with phase PH = (T - tau) % 3 uses
     // df3[(PH + 1) % 3] and loads, two steps ahead, into df3[PH] -- no register copies between steps, so the wait for a
@@ -765,13 +794,12 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
             gta[i] = (live && row + e < M) ? a.g_time_avg[((size_t)b * a.NB + s) * M + row + e] * inv : 0.f;
             carry[i] = dsum[i] = xn[i] = 0.f;
         }
-        load2(rs_traj, at(tf, T_ - 1), xc[2 * tf], xc[2 * tf + 1]);                       // x_T
-        if (T_ >= 2) load2(rs_traj, at(tf, T_ - 2), xm[2 * tf], xm[2 * tf + 1]); else xm[2 * tf] = xm[2 * tf + 1] = 0.f;
-        load2(rs_dlt, at(tf, T_ - 1), df3[1][2 * tf], df3[1][2 * tf + 1]);                 // f'(u_T): phase 0 uses df3[1]
-        store2(rs_dlt, at(tf, T_ - 1), 0.f, 0.f);                                          // slot T - 1 of the shifted delta stays zero
-        if (T_ >= 3) load2(rs_traj, at(tf, T_ - 3), pxm[2 * tf], pxm[2 * tf + 1]); else pxm[2 * tf] = pxm[2 * tf + 1] = 0.f;
-        if (T_ >= 2) load2(rs_dlt, at(tf, T_ - 2), df3[2][2 * tf], df3[2][2 * tf + 1]);    // f'(u_{T-1}): phase 1 uses df3[2]
-        else df3[2][2 * tf] = df3[2][2 * tf + 1] = 0.f;
+        load2(rs_traj, true, at(tf, T_ - 1), xc[2 * tf], xc[2 * tf + 1]);                   // x_T
+        load2(rs_traj, T_ >= 2, at(tf, T_ - 2), xm[2 * tf], xm[2 * tf + 1]);
+        load2(rs_dlt, true, at(tf, T_ - 1), df3[1][2 * tf], df3[1][2 * tf + 1]);             // f'(u_T): phase 0 uses df3[1]
+        store2(rs_dlt, true, at(tf, T_ - 1), 0.f, 0.f);                                      // slot T - 1 of the shifted delta stays zero
+        load2(rs_traj, T_ >= 3, at(tf, T_ - 3), pxm[2 * tf], pxm[2 * tf + 1]);
+        load2(rs_dlt, T_ >= 2, at(tf, T_ - 2), df3[2][2 * tf], df3[2][2 * tf + 1]);          // f'(u_{T-1}): phase 1 uses df3[2]
         df3[0][2 * tf] = df3[0][2 * tf + 1] = 0.f;
         // the first step's scale: max |delta_T| (carry = 0), or of eps |a_T| 2^-20 if f' vanishes everywhere
 #pragma unroll
@@ -797,8 +825,8 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
     int bused = 0;                                  // the scale exponent the draw's delta in LDS was written with
     unsigned lastref = 0u;
-    auto chain = [&]() {
-        ops.chain(b_rd, acc);
+    auto chain = [&](const auto& o) {
+        o.chain(b_rd, acc);
         if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
     };
     auto serial = [&](auto WIN, auto PH, int tau) {
@@ -811,8 +839,8 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
 #pragma unroll
         for (int tf = 0; tf < NTF; ++tf) {
             nxm[2 * tf] = nxm[2 * tf + 1] = 0.f;
-            if constexpr (win_on)         // (an offset of -1 is out of range for the buffer: the load returns zeros, no branch)
-                load2(rs_traj, (tau >= 4 && tau >= a.skip + 3) ? at(tf, tau - 4) : -1, nxm[2 * tf], nxm[2 * tf + 1]);
+            if constexpr (win_on)         // (no such index: zero-record descriptor, the load returns zeros, no branch)
+                load2(rs_traj, tau >= 4 && tau >= a.skip + 3, at(tf, tau - 4), nxm[2 * tf], nxm[2 * tf + 1]);
         }
         // scale of this step's delta from the previous step's maximum (kept when that was exactly zero)
         const unsigned mprev = (unsigned)__builtin_amdgcn_readfirstlane((int)*(LdsUC)(size_t)slot(tau + 1));
@@ -854,7 +882,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         // into the set the step before last used)
 #pragma unroll
         for (int tf = 0; tf < NTF; ++tf) {
-            load2(rs_dlt, (tau >= 3 && !(SSN_DUO_ABLATE & 32)) ? at(tf, tau - 3) : -1, ndf[2 * tf], ndf[2 * tf + 1]);
+            load2(rs_dlt, tau >= 3, at(tf, tau - 3), ndf[2 * tf], ndf[2 * tf + 1]);
         }
         const float rs = live ? duo_pow2(bexp) : 0.f;
         if (!(dm * rs < 65504.f)) delta[0] = __builtin_nanf("");                   // outgrew the lagged scale: poison, do not clamp
@@ -866,7 +894,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
             const unsigned wr = b_wr + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW);
             *(LdsU)(size_t)wr = h;
             *(LdsU)(size_t)(wr + 128u) = m;
-            store2(rs_dlt, (tau >= 2 && !(SSN_DUO_ABLATE & 16)) ? at(tf, tau - 2) : -1, delta[2 * tf], delta[2 * tf + 1]);    // shifted: pairs with x_{tau-1}
+            store2(rs_dlt, tau >= 2, at(tf, tau - 2), delta[2 * tf], delta[2 * tf + 1]);         // shifted: pairs with x_{tau-1}
         }
         bused = bexp;
         // one LDS atomic per wave (64 lanes on one address serialise: 16.6 -> 9.x ms): wave maximum first, six DPP steps
@@ -878,10 +906,10 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     constexpr std::integral_constant<bool, true> W1{};
     __syncthreads();                                                          // (B)
     if (d) __syncthreads();                            // draw 1 runs one phase behind draw 0
-    auto step = [&](auto WIN, auto PH, int tau) {
+    auto step = [&](auto WIN, auto PH, int tau, const auto& o) {
         serial(WIN, PH, tau);
         __syncthreads();
-        chain();
+        chain(o);
         __syncthreads();
     };
     constexpr std::integral_constant<int, 0> P0{};
@@ -889,9 +917,11 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     constexpr std::integral_constant<int, 2> P2{};
     int tau = T_, ph = 0;
     for (; tau >= a.skip + 1 && tau >= 1; --tau) {     // window steps first (time runs backwards)
-        if (ph == 0) step(W1, P0, tau); else if (ph == 1) step(W1, P1, tau); else step(W1, P2, tau);
+        if (ph == 0) step(W1, P0, tau, ops); else if (ph == 1) step(W1, P1, tau, ops); else step(W1, P2, tau, ops);
         ph = ph == 2 ? 0 : ph + 1;
     }
+    OpsN opsn;                                         // the window is over: its registers go to W^T (fewer LDS reads per chain)
+    opsn.promote_from(ops);
 #if SSN_DUO_STAMP
     {
         unsigned long long ts = 0, tb1 = 0, tc = 0, tb2 = 0; int n = 0;
@@ -902,7 +932,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
             const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            chain();
+            chain(opsn);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
             __syncthreads();
@@ -917,7 +947,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     }
 #else
     for (; tau >= 1; --tau) {
-        if (ph == 0) step(W0, P0, tau); else if (ph == 1) step(W0, P1, tau); else step(W0, P2, tau);
+        if (ph == 0) step(W0, P0, tau, opsn); else if (ph == 1) step(W0, P1, tau, opsn); else step(W0, P2, tau, opsn);
         ph = ph == 2 ? 0 : ph + 1;
     }
 #endif
@@ -935,8 +965,8 @@ template <int MK, bool GEXT>
 __global__ void __launch_bounds__(512, 2) gen_backward_duo_kernel(GenBwdArgs<float> a) {
     using S = Duo16<MK>;
     // LDS-resident part of W^T per wave of a draw (by the row tiles the wave finishes), and its prefix sums
-    constexpr int WL0 = S::nl_bwd(DuoWave<MK, 0>::NTF, GEXT) * 1024, WL1 = S::nl_bwd(DuoWave<MK, 1>::NTF, GEXT) * 1024,
-                  WL2 = S::nl_bwd(DuoWave<MK, 2>::NTF, GEXT) * 1024, WL3 = S::nl_bwd(DuoWave<MK, 3>::NTF, GEXT) * 1024;
+    constexpr int WL0 = S::nl_bwd_win(DuoWave<MK, 0>::NTF) * 1024, WL1 = S::nl_bwd_win(DuoWave<MK, 1>::NTF) * 1024,
+                  WL2 = S::nl_bwd_win(DuoWave<MK, 2>::NTF) * 1024, WL3 = S::nl_bwd_win(DuoWave<MK, 3>::NTF) * 1024;
     constexpr int WLD = WL0 + WL1 + WL2 + WL3;                        // per draw
     constexpr int DRAWB = S::BB + (S::WM - 1) * S::XS + 32;          // per draw: one B image, partial-sum slots, scale words
     constexpr int LDSB = 2 * DRAWB + 16;
