@@ -197,7 +197,8 @@ typedef struct ssn_gen_params {
                                   * (W^T as two fp16 parts, delta as three with a scale that follows max |delta| step
                                   * by step; any I/O function); 8 = fp16-split forward with TWO DRAWS per workgroup
                                   * (csrc/ssn_duo.hip: the chain of one draw behind the serial part of the other, W and
-                                  * state as two fp16 parts each by round to nearest = 23 bits; adjoint as 4).  0 picks
+                                  * state as two fp16 parts each by round to nearest = 23 bits; backward: the adjoint sweep in
+                                  * the same two-draw form, W^T and delta as two parts each, any I/O function).  0 picks
                                   * 8 / 4 / 5 where they apply (8 when there are more than 256 (draw, 8 stimuli) units)
                                   * unless ssn_set_operand_precision(0) -- or SSN_FWD_SPLIT=0 as the initial value --
                                   * keeps the automatic choice on fp32 operands. */

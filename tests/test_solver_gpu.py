@@ -474,7 +474,10 @@ def test_two_draw_solver_with_per_draw_stimuli_large_batch_and_mixed_stop_steps(
     np.testing.assert_array_equal(a.codes, b.codes)
     assert (a.codes == 0).all() and a.steps.min() < 0.7 * a.steps.max()      # really different stop steps
     assert np.abs(a.steps - b.steps).max() <= 0.2 * b.steps.max()
-    np.testing.assert_allclose(a.x, b.x, rtol=RTOL32, atol=1e-3)
+    # two kernels may see |r1 - r0| < atol first hold at different steps (fp32 summation order); every step between the
+    # two stop steps moves an element by less than about atol, so that is the tolerance the stop rule itself leaves
+    slack = 1e-3 + 1e-4 * (np.abs(a.steps - b.steps)[..., None] + 2)
+    assert (np.abs(a.x - b.x) <= RTOL32 * np.abs(b.x) + slack).all()
     assert np.abs(a.x - a.x_prev).max() < 1e-3
     # and it is what the library picks by itself for this shape
     p = SolverParams(io_type=2, max_iter=100, k=P['k'], n=P['n'], tau_E=P['tau'][0], tau_I=P['tau'][1], dt=8e-4, atol=1e-5,
