@@ -259,32 +259,61 @@ __device__ __forceinline__ void duo_wait_ge(unsigned addr, int target, bool& dea
 
 // f(u), f'(u) for the NE values of a lane; eight values go through in two halves (fewer values in flight at once: the
 // wave that finishes four row tiles is the one short of registers)
+// The barrier between two phases.  MFMAs touch registers only, so the scheduler is free to sink the tail of a chain below
+// an s_barrier and interleave it with the serial part -- where it waits for a matrix pipe the partner wave's chain is
+// filling, with the wave's own vector stream stuck in order behind it (seen in the assembly: up to 21 of 46 MFMAs moved).
+// Nothing crosses this one.
+__device__ __forceinline__ void duo_phase_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <bool WANT_DF, int NE>
 __device__ __forceinline__ void duo_eval(const IoSelect& io, const float (&uu)[NE], float (&ff)[NE], float (&dfn)[NE]) {
-    if constexpr (NE == 8) {
+    if constexpr (NE > 6) {                  // 7 or 8 values: 4 first, then the rest (fewer registers pinned at once)
         float u4[4], f4[4], d4[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int i = 0; i < 4; ++i) { u4[i] = uu[i]; d4[i] = 0.f; }
+        io.template evaln<WANT_DF, 4>(u4, f4, d4);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { u4[i] = uu[4 * h + i]; d4[i] = 0.f; }
-            io.template evaln<WANT_DF, 4>(u4, f4, d4);
+        for (int i = 0; i < 4; ++i) { ff[i] = f4[i]; dfn[i] = d4[i]; }
+        constexpr int NR = NE - 4;
+        float ur[NR], fr[NR], dr[NR];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { ff[4 * h + i] = f4[i]; dfn[4 * h + i] = d4[i]; }
-        }
+        for (int i = 0; i < NR; ++i) { ur[i] = uu[4 + i]; dr[i] = 0.f; }
+        io.template evaln<WANT_DF, NR>(ur, fr, dr);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { ff[4 + i] = fr[i]; dfn[4 + i] = dr[i]; }
     } else {
         io.template evaln<WANT_DF, NE>(uu, ff, dfn);
     }
 }
 
-template <int MK, int WV, bool SAVE, bool FREE>
+// Half-real tail tile (2N = 194 ... 200 at MK = 208: the 13th row tile holds at most 8 real rows, all in lane groups 0, 1).
+// The wave that finishes it would carry 8 values per lane, 2 of them padding in EVERY lane, and its serial part is the
+// length of a phase.  In the `HT` forms it finishes that tile one value per lane instead: after the DPP join lanes 0-31
+// hold the real row pairs (a, b); v_permlane32_swap hands b of lane l to lane 32 + l, so lane (lg, hi, st) finishes row
+// 4 (lg & 1) + 2 hi + (lg >> 1) of the tile -- 7 values per lane instead of 8 (6 / 6 / 6 / 7 over the four waves = 1600 / 256).
+__device__ __forceinline__ float duo_tail_take(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, r[0]);                 // lanes 0-31: a, lanes 32-63: b of lane - 32
+}
+constexpr bool duo_half_tail(int MK, int M) { return MK == 208 && M > 192 && M <= 200; }
+
+template <int MK, int WV, bool SAVE, bool FREE, bool HT>
 __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int rshift, int d, int b, int s0, bool valid,
                                                  int lane, char* dlds, char* wlds, unsigned* wmax) {
     using S = Duo16<MK>;
     using WS = DuoWave<MK, WV>;
     constexpr int NT = WS::NT, NTF = WS::NTF, RT0 = WS::RT0;
-    constexpr int NE = 2 * NTF;
+    constexpr bool HTW = HT && WV == S::WM - 1 && NTF > 1;       // this wave finishes the half-real tail tile one value per lane
+    constexpr int NP = HTW ? NTF - 1 : NTF;                      // row tiles finished as row pairs
+    constexpr int NE = 2 * NP + (HTW ? 1 : 0);
     const int M = a.M, N = a.M / 2, T_ = a.seqlen;
     const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
+    const int row_tail = 16 * (RT0 + NTF - 1) + 4 * (lg & 1) + 2 * hi + (lg >> 1);
+    auto row_of = [&](int i) { return (HTW && i == NE - 1) ? row_tail : 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1); };
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
     // ---- W: pass 1 = max |W| of the draw, pass 2 = the two fp16 parts of W 2^a
@@ -303,7 +332,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     float dps = 0.f, rps = 0.f;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
+        const int row = row_of(i);
         rc[i] = ta[i] = 0.f;
         ex[i] = (s < a.NB && row < M) ? a.ext[((size_t)b * a.NB + s) * M + row] : 0.f;
         eps[i] = row < N ? a.eps_E : a.eps_I;
@@ -316,14 +345,18 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
         rs_df = __builtin_amdgcn_make_buffer_rsrc(a.df + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
         toff = live ? (int)(((size_t)s * T_ * M + 4 * lg + 2 * hi) * 4) : -1;
     }
+    const int toff_tail = (SAVE && live && row_tail < M) ? (int)(((size_t)s * T_ * M + row_tail) * 4) : -1;
     using LdsH8 = const __attribute__((address_space(3))) hv8*;
     using LdsF4 = __attribute__((address_space(3))) mf4*;
     using LdsU = __attribute__((address_space(3))) unsigned*;
+    using LdsH = __attribute__((address_space(3))) unsigned short*;
     const unsigned bimg = (unsigned)(size_t)(LdsH8)dlds;
     const unsigned xs = bimg + (unsigned)(2 * S::BB) + (unsigned)(lane * 16);             // + slot * XS
     const unsigned b_rd = bimg + (unsigned)(lg * S::BROW + li * 16);                      // + kt * 4 * BROW
     // new state of rows 16 rt + 4 lg + 2 hi + {0, 1}: k tile rt / 2, k octet 2 (rt & 1) + lg / 2, element 4 (lg & 1) + 2 hi
     const unsigned b_wr = bimg + (unsigned)((lg >> 1) * S::BROW + st * 16 + (lg & 1) * 8 + hi * 4);
+    // the tail value (row 16 rt + 4 (lg & 1) + 2 hi + (lg >> 1)): k octet 2 (rt & 1), element 4 (lg & 1) + 2 hi + (lg >> 1)
+    const unsigned b_wr_tail = bimg + (unsigned)(st * 16 + (lg & 1) * 8 + hi * 4 + (lg >> 1) * 2);
 
     const unsigned sync = bimg + (unsigned)S::SYNC;
     bool dead = false;
@@ -353,8 +386,12 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             // lane s (hi = 0) keeps rows 0, 1 and offers rows 2, 3 of its part; lane 8 + s keeps 2, 3 and offers 0, 1
             const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
             const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
-            uu[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
-            uu[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
+            if (HTW && tf == NTF - 1) {
+                uu[NE - 1] = fmaf(duo_tail_take(k0 + dpp_ror8(o0), k1 + dpp_ror8(o1)), usc, ex[NE - 1]);
+            } else {
+                uu[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
+                uu[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NE; ++i) dfn[i] = 0.f;
@@ -377,8 +414,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             rc[i] = r1;
         }
 #pragma unroll
-        for (int tf = 0; tf < NTF; ++tf) {
-            constexpr int dummy = 0; (void)dummy;
+        for (int tf = 0; tf < NP; ++tf) {
             const int rt = RT0 + tf;
             if constexpr (SAVE) {
                 const int off = (toff < 0 || 16 * rt + 4 * lg + 2 * hi >= M) ? -1 : toff + (it * M + 16 * rt) * 4;
@@ -391,6 +427,19 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             const unsigned wr = b_wr + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW) + (FREE ? (unsigned)(((it + 1) & 1) * S::BB) : 0u);
             *(LdsU)(size_t)wr = h;
             *(LdsU)(size_t)(wr + 128u) = m;
+        }
+        if constexpr (HTW) {
+            constexpr int rt = RT0 + NTF - 1;
+            if constexpr (SAVE) {
+                const int off = toff_tail < 0 ? -1 : toff_tail + it * M * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rc[NE - 1]), rs_traj, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[NE - 1]), rs_df, off, 0, 0);
+            }
+            unsigned h, m;
+            duo_split2(rc[NE - 1], 0.f, rs, h, m);
+            const unsigned wr = b_wr_tail + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW) + (FREE ? (unsigned)(((it + 1) & 1) * S::BB) : 0u);
+            *(LdsH)(size_t)wr = (unsigned short)h;
+            *(LdsH)(size_t)(wr + 128u) = (unsigned short)m;
         }
         if (FREE) duo_signal_add(sync, lane);
     };
@@ -430,16 +479,16 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 #else
         for (int it = 0; it < nskip; ++it) {
             chain(it);
-            __syncthreads();
+            duo_phase_barrier();
             serial(W0, it);
-            __syncthreads();
+            duo_phase_barrier();
         }
 #endif
         for (int it = nskip; it < T_; ++it) {
             chain(it);
-            __syncthreads();
+            duo_phase_barrier();
             serial(W1, it);
-            __syncthreads();
+            duo_phase_barrier();
         }
         if (!d) __syncthreads();
     }
@@ -448,7 +497,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     const float inv = dead ? __builtin_nanf("") : 1.f / (float)(T_ - a.skip);
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
+        const int row = row_of(i);
         if (row >= M) continue;
         const size_t o = ((size_t)b * a.NB + s) * M + row;
         a.time_avg[o] = ta[i] * inv;
@@ -459,7 +508,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 }
 
 // grid: ceil(units / 2) workgroups, unit = (draw, group of 8 stimuli); 512 threads
-template <int MK, bool SAVE, bool FREE>
+template <int MK, bool SAVE, bool FREE, bool HT>
 __global__ void __launch_bounds__(512, 2) gen_forward_duo_kernel(GenFwdArgs<float> a, int rshift) {
     using S = Duo16<MK>;
     constexpr int WL = S::nl(SAVE) * 1024;          // LDS-resident part of W, per wave
@@ -479,10 +528,10 @@ __global__ void __launch_bounds__(512, 2) gen_forward_duo_kernel(GenFwdArgs<floa
     char* const wlds = lds + S::LDS + wave * WL;
     unsigned* const wmax = reinterpret_cast<unsigned*>(lds + 2 * S::DRAW) + d;
     switch (wave & 3) {
-        case 0: duo_forward_wave<MK, 0, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
-        case 1: duo_forward_wave<MK, 1, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
-        case 2: duo_forward_wave<MK, 2, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
-        default: duo_forward_wave<MK, 3, SAVE, FREE>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        case 0: duo_forward_wave<MK, 0, SAVE, FREE, HT>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        case 1: duo_forward_wave<MK, 1, SAVE, FREE, HT>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        case 2: duo_forward_wave<MK, 2, SAVE, FREE, HT>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
+        default: duo_forward_wave<MK, 3, SAVE, FREE, HT>(a, rshift, d, b, s0, valid, lane, dlds, wlds, wmax); break;
     }
 }
 
@@ -908,9 +957,9 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     if (d) __syncthreads();                            // draw 1 runs one phase behind draw 0
     auto step = [&](auto WIN, auto PH, int tau, const auto& o) {
         serial(WIN, PH, tau);
-        __syncthreads();
+        duo_phase_barrier();
         chain(o);
-        __syncthreads();
+        duo_phase_barrier();
     };
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
@@ -1001,24 +1050,36 @@ static bool duo_free_running() {
     static const bool on = [] { const char* e = getenv("SSN_DUO_FREE"); return e && e[0] == '1'; }();
     return on;
 }
+// SSN_DUO_HT=0: the half-real tail tile as row pairs like every other tile (A/B runs; results are bit-identical)
+static bool duo_half_tail_on() {
+    static const bool on = [] { const char* e = getenv("SSN_DUO_HT"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static int duo_pick_mk(int M) {
     const int ladder[] = {104, 152, 208};
     for (int mk : ladder) if (M <= mk) return mk;
     return 0;
 }
 
-template <int MK>
-static hipError_t launch_duo_fwd_mk(const GenFwdArgs<float>& a, int rshift, hipStream_t st) {
+template <int MK, bool HT>
+static hipError_t launch_duo_fwd_ht(const GenFwdArgs<float>& a, int rshift, hipStream_t st) {
     const long nunits = (long)a.B * ((a.NB + 7) / 8);
     const dim3 grid((unsigned)((nunits + 1) / 2));
     if (duo_free_running()) {
-        if (a.traj) hipLaunchKernelGGL((gen_forward_duo_kernel<MK, true, true>), grid, dim3(512), 0, st, a, rshift);
-        else hipLaunchKernelGGL((gen_forward_duo_kernel<MK, false, true>), grid, dim3(512), 0, st, a, rshift);
+        if (a.traj) hipLaunchKernelGGL((gen_forward_duo_kernel<MK, true, true, HT>), grid, dim3(512), 0, st, a, rshift);
+        else hipLaunchKernelGGL((gen_forward_duo_kernel<MK, false, true, HT>), grid, dim3(512), 0, st, a, rshift);
     } else {
-        if (a.traj) hipLaunchKernelGGL((gen_forward_duo_kernel<MK, true, false>), grid, dim3(512), 0, st, a, rshift);
-        else hipLaunchKernelGGL((gen_forward_duo_kernel<MK, false, false>), grid, dim3(512), 0, st, a, rshift);
+        if (a.traj) hipLaunchKernelGGL((gen_forward_duo_kernel<MK, true, false, HT>), grid, dim3(512), 0, st, a, rshift);
+        else hipLaunchKernelGGL((gen_forward_duo_kernel<MK, false, false, HT>), grid, dim3(512), 0, st, a, rshift);
     }
     return hipGetLastError();
+}
+template <int MK>
+static hipError_t launch_duo_fwd_mk(const GenFwdArgs<float>& a, int rshift, hipStream_t st) {
+    if constexpr (MK == 208) {
+        if (duo_half_tail(MK, a.M) && duo_half_tail_on()) return launch_duo_fwd_ht<MK, true>(a, rshift, st);
+    }
+    return launch_duo_fwd_ht<MK, false>(a, rshift, st);
 }
 // rshift from gen_split_rshift (ssn_mfma16.hip): the same applicability rules as the other fp16-split forms
 hipError_t launch_gen_forward_duo(const GenFwdArgs<float>& a, hipStream_t st) {
