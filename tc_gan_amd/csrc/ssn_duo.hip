@@ -33,6 +33,9 @@
 #include "ssn_host.h"
 #include "ssn_mfma_io.h"
 
+#ifndef SSN_DUO_EARLY
+#define SSN_DUO_EARLY 1         // row tiles a wave finishes right behind its own chain (forward kernels; 0 = none)
+#endif
 #ifndef SSN_DUO_ABLATE
 #define SSN_DUO_ABLATE 0        // diagnostic builds (timing only, wrong results): 1 = no nonlinearity, 2 = one FMA per MFMA,
                                 // 4 / 8 = serial part / chain at s_setprio 1
@@ -370,58 +373,83 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             if (FREE) duo_signal_set(sync + 4u * (1 + WV), (unsigned)(it + 1), lane);
         }
     };
-    auto serial = [&](auto WIN, int it) {
+    // The serial part of a step, in two pieces.  `compute(T0, T1, TAIL)` finishes the row tiles [T0, T1) (and the tail value):
+    // join of the two parts of every sum, f(u), Euler step, window sums, trajectory stores -- registers and global memory
+    // only.  `publish` splits the new state and writes it to the B image.  The wave that has just ended its chain would idle
+    // until the partner wave of its SIMD is through a serial part that runs at about half speed beside the MFMA stream, so
+    // it computes its last EARLY row tiles right behind its own chain, in the same phase (their sums are complete, nothing
+    // they need lives in LDS); what stays for its serial phase is the rest and the publication of all tiles.
+    auto compute = [&](auto WIN, int it, auto T0_, auto T1_, auto TAIL_) {
         constexpr bool win_on = decltype(WIN)::value;
-        float uu[NE], ff[NE], dfn[NE];
+        constexpr int T0 = decltype(T0_)::value, T1 = decltype(T1_)::value;
+        constexpr bool TAIL = decltype(TAIL_)::value;
+        constexpr int NV = 2 * (T1 - T0) + (TAIL ? 1 : 0);
+        if constexpr (NV > 0) {
+            auto gi = [&](int jv) { return (TAIL && jv == NV - 1) ? NE - 1 : 2 * T0 + jv; };       // local value -> lane value
+            float uu[NV], ff[NV], dfn[NV];
 #pragma unroll
-        for (int tf = 0; tf < NTF; ++tf) {
-            mf4 sm = acc[tf];
-            if constexpr (WS::HEAD_SHARED) {
-                if (tf == 0) {
-                    if (FREE) duo_wait_ge(sync + 4u * WV, it + 1, dead);          // wave WV - 1 has stored its partial sum of step it
-                    const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
-                    sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
+            for (int tf = T0; tf < T1 + (TAIL ? 1 : 0); ++tf) {
+                const bool is_tail = TAIL && tf == T1;
+                mf4 sm = acc[is_tail ? NTF - 1 : tf];
+                if constexpr (WS::HEAD_SHARED) {
+                    if (tf == 0 && !is_tail) {
+                        if (FREE) duo_wait_ge(sync + 4u * WV, it + 1, dead);          // wave WV - 1 has stored its partial sum of step it
+                        const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                        sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
+                    }
+                }
+                // lane s (hi = 0) keeps rows 0, 1 and offers rows 2, 3 of its part; lane 8 + s keeps 2, 3 and offers 0, 1
+                const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
+                const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
+                if (is_tail) {
+                    uu[NV - 1] = fmaf(duo_tail_take(k0 + dpp_ror8(o0), k1 + dpp_ror8(o1)), usc, ex[NE - 1]);
+                } else {
+                    uu[2 * (tf - T0)] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
+                    uu[2 * (tf - T0) + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
                 }
             }
-            // lane s (hi = 0) keeps rows 0, 1 and offers rows 2, 3 of its part; lane 8 + s keeps 2, 3 and offers 0, 1
-            const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
-            const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
-            if (HTW && tf == NTF - 1) {
-                uu[NE - 1] = fmaf(duo_tail_take(k0 + dpp_ror8(o0), k1 + dpp_ror8(o1)), usc, ex[NE - 1]);
+#pragma unroll
+            for (int jv = 0; jv < NV; ++jv) dfn[jv] = 0.f;
+            if (SSN_DUO_ABLATE & 1) {                    // (no nonlinearity: the rest of the serial part stays)
+#pragma unroll
+                for (int jv = 0; jv < NV; ++jv) ff[jv] = uu[jv];
             } else {
-                uu[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
-                uu[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
+                duo_eval<SAVE, NV>(io, uu, ff, dfn);
+            }
+            const float win2 = (it > a.skip) ? 1.f : 0.f;
+#pragma unroll
+            for (int jv = 0; jv < NV; ++jv) {
+                const int i = gi(jv);
+                const float r1 = fmaf(eps[i], ff[jv] - rc[i], rc[i]);                 // (1 - eps) r + eps f(u)
+                const float dd = r1 - rc[i];
+                if constexpr (win_on) {
+                    ta[i] += r1;
+                    rps += fmaxf(r1 - a.theta, 0.f);
+                    dps = fmaf(win2 * dd, dd, dps);
+                }
+                rc[i] = r1;
+            }
+            if constexpr (SAVE) {
+#pragma unroll
+                for (int tf = T0; tf < T1; ++tf) {
+                    const int rt = RT0 + tf;
+                    const int off = (toff < 0 || 16 * rt + 4 * lg + 2 * hi >= M) ? -1 : toff + (it * M + 16 * rt) * 4;
+                    const fv2 rv = {rc[2 * tf], rc[2 * tf + 1]}, dv = {dfn[2 * (tf - T0)], dfn[2 * (tf - T0) + 1]};
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), rv), rs_traj, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), dv), rs_df, off, 0, 0);
+                }
+                if constexpr (TAIL) {
+                    const int off = toff_tail < 0 ? -1 : toff_tail + it * M * 4;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rc[NE - 1]), rs_traj, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[NV - 1]), rs_df, off, 0, 0);
+                }
             }
         }
-#pragma unroll
-        for (int i = 0; i < NE; ++i) dfn[i] = 0.f;
-        if (SSN_DUO_ABLATE & 1) {                    // (no nonlinearity: the rest of the serial part stays)
-#pragma unroll
-            for (int i = 0; i < NE; ++i) ff[i] = uu[i];
-        } else {
-            duo_eval<SAVE, NE>(io, uu, ff, dfn);
-        }
-        const float win2 = (it > a.skip) ? 1.f : 0.f;
-#pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const float r1 = fmaf(eps[i], ff[i] - rc[i], rc[i]);                 // (1 - eps) r + eps f(u)
-            const float dd = r1 - rc[i];
-            if constexpr (win_on) {
-                ta[i] += r1;
-                rps += fmaxf(r1 - a.theta, 0.f);
-                dps = fmaf(win2 * dd, dd, dps);
-            }
-            rc[i] = r1;
-        }
+    };
+    auto publish = [&](int it) {
 #pragma unroll
         for (int tf = 0; tf < NP; ++tf) {
             const int rt = RT0 + tf;
-            if constexpr (SAVE) {
-                const int off = (toff < 0 || 16 * rt + 4 * lg + 2 * hi >= M) ? -1 : toff + (it * M + 16 * rt) * 4;
-                const fv2 rv = {rc[2 * tf], rc[2 * tf + 1]}, dv = {dfn[2 * tf], dfn[2 * tf + 1]};
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), rv), rs_traj, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), dv), rs_df, off, 0, 0);
-            }
             unsigned h, m;
             duo_split2(rc[2 * tf], rc[2 * tf + 1], rs, h, m);
             const unsigned wr = b_wr + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW) + (FREE ? (unsigned)(((it + 1) & 1) * S::BB) : 0u);
@@ -430,11 +458,6 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
         }
         if constexpr (HTW) {
             constexpr int rt = RT0 + NTF - 1;
-            if constexpr (SAVE) {
-                const int off = toff_tail < 0 ? -1 : toff_tail + it * M * 4;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rc[NE - 1]), rs_traj, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[NE - 1]), rs_df, off, 0, 0);
-            }
             unsigned h, m;
             duo_split2(rc[NE - 1], 0.f, rs, h, m);
             const unsigned wr = b_wr_tail + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW) + (FREE ? (unsigned)(((it + 1) & 1) * S::BB) : 0u);
@@ -442,6 +465,18 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             *(LdsH)(size_t)(wr + 128u) = (unsigned short)m;
         }
         if (FREE) duo_signal_add(sync, lane);
+    };
+    // row tiles finished behind the own chain: the last ones (never the first, which may wait for a neighbour's partial sum)
+    constexpr int EARLY = FREE ? 0 : (SSN_DUO_EARLY < NP - 1 ? SSN_DUO_EARLY : NP - 1);
+    constexpr std::integral_constant<int, 0> TB{};
+    constexpr std::integral_constant<int, NP - EARLY> TM{};
+    constexpr std::integral_constant<int, NP> TE{};
+    constexpr std::integral_constant<bool, HTW> HAS_TAIL{};
+    constexpr std::integral_constant<bool, false> NO_TAIL{};
+    auto early = [&](auto WIN, int it) { compute(WIN, it, TM, TE, NO_TAIL); };
+    auto serial = [&](auto WIN, int it) {
+        compute(WIN, it, TB, TM, HAS_TAIL);
+        publish(it);
     };
     constexpr std::integral_constant<bool, false> W0{};
     constexpr std::integral_constant<bool, true> W1{};
@@ -458,6 +493,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
         for (int it = 0; it < nskip; ++it) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             chain(it);
+            early(W0, it);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const unsigned long long t1 = __builtin_amdgcn_s_memtime();
             __syncthreads();
@@ -479,6 +515,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 #else
         for (int it = 0; it < nskip; ++it) {
             chain(it);
+            early(W0, it);
             duo_phase_barrier();
             serial(W0, it);
             duo_phase_barrier();
@@ -486,6 +523,7 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 #endif
         for (int it = nskip; it < T_; ++it) {
             chain(it);
+            early(W1, it);
             duo_phase_barrier();
             serial(W1, it);
             duo_phase_barrier();
