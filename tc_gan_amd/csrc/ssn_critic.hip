@@ -24,6 +24,7 @@
 // not MFMA bound; the tile is chosen for simplicity and full generality in the strides.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <type_traits>
 #include "ssn_host.h"
 
 namespace ssn {
@@ -51,6 +52,24 @@ struct GemmArgs {
     int kchunk;                        // K range per blockIdx.z (split-K; PLAIN with beta == 1 only)
     float* partial;                    // split-K: slice z writes its tile sums to partial[z][m*N + n] (no atomics)
 };
+
+// ---- epilogue of one 32 x 32 wave tile: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -----------
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc, int mw, int nw, int lane) {
+    const int n = nw + (lane & 31);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int m = mw + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (m < g.M && n < g.N) {
+            float v = acc[reg];
+            float* c = g.C + m * g.ldc + n;
+            if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : 0.f; }
+            else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : 0.f; }
+            else if (gridDim.z > 1) { g.partial[((long)blockIdx.z * g.M + m) * g.N + n] = v; continue; }   // split-K partial
+            else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
+            *c = v;
+        }
+    }
+}
 
 template <bool BF16>
 __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
@@ -126,21 +145,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -----------
-    const int n = n0 + wc * 32 + (lane & 31);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (m < g.M && n < g.N) {
-            float v = acc[reg];
-            float* c = g.C + m * g.ldc + n;
-            if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : 0.f; }
-            else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : 0.f; }
-            else if (gridDim.z > 1) { g.partial[((long)blockIdx.z * g.M + m) * g.N + n] = v; continue; }   // split-K partial
-            else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
-            *c = v;
-        }
-    }
+    gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane);
 }
 
 // ---- deterministic split-K ---------------------------------------------------------------------------------------
@@ -172,6 +177,117 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(SplitKReduceArgs a) 
         }
         C[i] = c;
     }
+}
+
+
+// ---------------------------------------------------------------------------------
+// The bf16 GEMM for the shapes the critic spends its time in (batch x 512 x 512 and the like: K >= 64, the contiguous
+// extents multiples of 4).  Same tile (64 x 64 per workgroup, 2 x 2 waves of one 32 x 32 MFMA tile), same k order of the
+// accumulation -- what changes is how the operands arrive: the general kernel above issues one K tile of scalar loads per
+// iteration and waits for it, and at 16 iterations of about a microsecond of load latency each a 0.5 GFLOP GEMM took
+// 18 us.  Here every thread fetches 16-byte vectors along the contiguous index, THREE K tiles of 64 ahead (24 loads in
+// flight per thread), LDS is double buffered and an iteration has one barrier.
+//   AKC / BKC: k is the contiguous index of op(A) / op(B) (otherwise m / n is).
+// ---------------------------------------------------------------------------------
+typedef float gf4 __attribute__((ext_vector_type(4)));
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
+    constexpr int BM = 64, BN = 64, BK = 64, LDK = BK + 8, NST = 3;
+    __shared__ __align__(16) unsigned short As[2][BM][LDK];
+    __shared__ __align__(16) unsigned short Bs[2][BN][LDK];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    const int q = tid & 15, p = tid >> 4;             // vector index along the contiguous extent, line within a group of 16
+    gf4 ra[NST][4], rb[NST][4];
+    const gf4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](auto ST, int k0) {
+        constexpr int st = decltype(ST)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (AKC) {                      // line = row m, vector = 4 consecutive k
+                const int m = m0 + p + 16 * i, k = k0 + 4 * q;
+                ra[st][i] = (m < g.M && k < kend) ? *reinterpret_cast<const gf4*>(g.A + (long)m * g.sam + k) : zero4;
+            } else {                                  // line = k, vector = 4 consecutive rows m
+                const int k = k0 + p + 16 * i, m = m0 + 4 * q;
+                ra[st][i] = (m < g.M && k < kend) ? *reinterpret_cast<const gf4*>(g.A + (long)k * g.sak + m) : zero4;
+            }
+            if constexpr (BKC) {
+                const int n = n0 + p + 16 * i, k = k0 + 4 * q;
+                rb[st][i] = (n < g.N && k < kend) ? *reinterpret_cast<const gf4*>(g.B + (long)n * g.sbn + k) : zero4;
+            } else {
+                const int k = k0 + p + 16 * i, n = n0 + 4 * q;
+                rb[st][i] = (n < g.N && k < kend) ? *reinterpret_cast<const gf4*>(g.B + (long)k * g.sbk + n) : zero4;
+            }
+        }
+    };
+    auto stash = [&](auto ST, int buf) {
+        constexpr int st = decltype(ST)::value;
+        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const gf4 a = ra[st][i], b = rb[st][i];
+            if constexpr (AKC) {
+                *reinterpret_cast<us4*>(&As[buf][p + 16 * i][4 * q]) = (us4){to_bf16(a.x), to_bf16(a.y), to_bf16(a.z), to_bf16(a.w)};
+            } else {
+                const int k = p + 16 * i;
+                As[buf][4 * q][k] = to_bf16(a.x); As[buf][4 * q + 1][k] = to_bf16(a.y);
+                As[buf][4 * q + 2][k] = to_bf16(a.z); As[buf][4 * q + 3][k] = to_bf16(a.w);
+            }
+            if constexpr (BKC) {
+                *reinterpret_cast<us4*>(&Bs[buf][p + 16 * i][4 * q]) = (us4){to_bf16(b.x), to_bf16(b.y), to_bf16(b.z), to_bf16(b.w)};
+            } else {
+                const int k = p + 16 * i;
+                Bs[buf][4 * q][k] = to_bf16(b.x); Bs[buf][4 * q + 1][k] = to_bf16(b.y);
+                Bs[buf][4 * q + 2][k] = to_bf16(b.z); Bs[buf][4 * q + 3][k] = to_bf16(b.w);
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // iteration t: registers of stage t % 3 -> LDS buffer t & 1, barrier, refill the stage with tile t + 3, MFMAs.  One
+    // barrier is enough: a wave stores into buffer (t + 1) & 1 only behind barrier t, which every wave reaches after its
+    // MFMA reads of iteration t - 1 from that buffer.
+    auto step = [&](auto ST, int t) {
+        const int buf = t & 1;
+        stash(ST, buf);
+        __syncthreads();
+        if (t + NST < nt) load(ST, kbeg + (t + NST) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(&As[buf][wr * 32 + (lane & 31)][kk + 8 * (lane >> 5)]);
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&Bs[buf][wc * 32 + (lane & 31)][kk + 8 * (lane >> 5)]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        }
+    };
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    constexpr std::integral_constant<int, 2> S2{};
+    if (nt > 0) load(S0, kbeg);
+    if (nt > 1) load(S1, kbeg + BK);
+    if (nt > 2) load(S2, kbeg + 2 * BK);
+    for (int t = 0; t < nt; t += NST) {
+        step(S0, t);
+        if (t + 1 < nt) step(S1, t + 1);
+        if (t + 2 < nt) step(S2, t + 2);
+    }
+    gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane);
+}
+// the vector loads of gemm_bf16_pipe_kernel: 16-byte aligned bases, contiguous extents and leading strides in fours
+static bool gemm_pipe_ok(const GemmArgs& g) {
+    if (g.K < 64) return false;
+    auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
+    if (!al(g.A) || !al(g.B)) return false;
+    const bool akc = g.sak == 1, bkc = g.sbk == 1;
+    if (!akc && g.sam != 1) return false;
+    if (!bkc && g.sbn != 1) return false;
+    if (akc ? (g.K % 4 || g.sam % 4) : (g.M % 4 || g.sak % 4)) return false;
+    if (bkc ? (g.K % 4 || g.sbn % 4) : (g.N % 4 || g.sbk % 4)) return false;
+    return true;
 }
 
 static int choose_splits(int M, int N, int K) {
@@ -224,7 +340,8 @@ static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
         // slabs of earlier split ones are added at the flush -- a fixed order either way.
         if (same >= 4 || tl_plan.used + (size_t)splits * g.M * g.N > tl_plan.cap) splits = 1;
     }
-    const int bk = bf16 ? 32 : 16;
+    const bool pipe = bf16 && gemm_pipe_ok(g);
+    const int bk = pipe ? 64 : (bf16 ? 32 : 16);
     g.kchunk = ((g.K + splits - 1) / splits + bk - 1) / bk * bk;
     splits = (g.K + g.kchunk - 1) / g.kchunk;
     g.partial = nullptr;
@@ -234,7 +351,13 @@ static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
         tl_plan.used += (size_t)splits * g.M * g.N;
     }
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
-    if (bf16) hipLaunchKernelGGL((gemm_mfma_kernel<true>), grid, dim3(256), 0, st, g);
+    if (pipe) {
+        const bool akc = g.sak == 1, bkc = g.sbk == 1;
+        if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else if (akc)   hipLaunchKernelGGL((gemm_bf16_pipe_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else if (bkc)   hipLaunchKernelGGL((gemm_bf16_pipe_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else            hipLaunchKernelGGL((gemm_bf16_pipe_kernel<false, false>), grid, dim3(256), 0, st, g);
+    } else if (bf16) hipLaunchKernelGGL((gemm_mfma_kernel<true>), grid, dim3(256), 0, st, g);
     else      hipLaunchKernelGGL((gemm_mfma_kernel<false>), grid, dim3(256), 0, st, g);
     return hipGetLastError();
 }
