@@ -84,7 +84,8 @@ struct Duo16 {
     static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? 4 : 0; }
     // adjoint sweep: 10 state values per row and stimulus -- by the number of row tiles a wave finishes (6 or 8 values per lane)
     // (window steps / the steps after the window: the window keeps four trajectory rows per value in registers)
-    static constexpr int nl_bwd_win(int ntf) { return MK > 152 ? (ntf >= 4 ? 20 : 16) : (MK > 104 ? 4 : 0); }
+    // (wave 0 of the window loop is the one short of registers: it takes three units from its two three-tile neighbours)
+    static constexpr int nl_bwd_win(int wv, int ntf) { return MK > 152 ? (ntf >= 4 ? 20 : (wv == 0 ? 19 : 15)) : (MK > 104 ? 4 : 0); }
     static constexpr int nl_bwd(int ntf, bool gext) { return MK > 152 ? (ntf >= 4 ? 12 : 8) + (gext ? 4 : 0) : (MK > 104 ? 4 : 0); }
     static constexpr int LDS = 2 * DRAW + 16;
     static_assert(start(1) >= NKT, "a row tile is shared by at most two waves");
@@ -813,7 +814,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
-    using Ops = DuoOperands<MK, WV, S::nl_bwd_win(WS::NTF), true>;             // window steps
+    using Ops = DuoOperands<MK, WV, S::nl_bwd_win(WV, WS::NTF), true>;             // window steps
     using OpsN = DuoOperands<MK, WV, S::nl_bwd(WS::NTF, GEXT), true>;            // the steps after the window
     atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)));
     using LdsH8 = const __attribute__((address_space(3))) hv8*;
@@ -869,6 +870,12 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         if (tau >= a.skip + 2) gg += 2.f * a.c_dyn * (xc[i] - xm[i]);
         return gg;
     };
+    __syncthreads();                                                          // (A) max |W|
+    const int wexp = duo_w_exp(*wmax);
+    Ops ops;
+    ops.load(rsrc, M, li, lg, duo_pow2(wexp), wwlds, lane);
+    // (the per-value state is set up AFTER the W prologue, the one place where every register is taken: set up before it,
+    // two of the window's constants were spilled there and reloaded from scratch -- with s_waitcnt vmcnt(0) -- in every step)
     float m0 = 0.f;
 #pragma unroll
     for (int tf = 0; tf < NTF; ++tf) {
@@ -902,10 +909,6 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         if (lane == 0) __hip_atomic_fetch_max((__attribute__((address_space(3))) unsigned*)(dlds + SYNCB) + (T_ + 1 + 3) % 3, wm0,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __syncthreads();                                                          // (A) max |W| and the first delta scale
-    const int wexp = duo_w_exp(*wmax);
-    Ops ops;
-    ops.load(rsrc, M, li, lg, duo_pow2(wexp), wwlds, lane);
 
     mf4 acc[NT];
 #pragma unroll
@@ -1002,11 +1005,25 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
     constexpr std::integral_constant<int, 2> P2{};
+    // The f' registers rotate through three sets, one per step (the load of step tau - 3 goes into the set step tau - 1
+    // used).  The rotation must be STATIC in the code that runs 1200 times: written as one loop over a phase variable the
+    // compiler folds the three variants back into one body that rotates the sets with v_mov -- and a copy of a register
+    // with a load in flight needs s_waitcnt vmcnt(0), i.e. every step waited for its own stores to be acknowledged
+    // (seen in the assembly; 2100 cycles per serial part instead of 1300).  So: three steps per iteration, spelled
+    // out; the generic form only for the at most two steps that bring the phase back to 0 at each end.
     int tau = T_, ph = 0;
-    for (; tau >= a.skip + 1 && tau >= 1; --tau) {     // window steps first (time runs backwards)
-        if (ph == 0) step(W1, P0, tau, ops); else if (ph == 1) step(W1, P1, tau, ops); else step(W1, P2, tau, ops);
+    auto step_any = [&](auto WIN, const auto& o) {
+        if (ph == 0) step(WIN, P0, tau, o); else if (ph == 1) step(WIN, P1, tau, o); else step(WIN, P2, tau, o);
         ph = ph == 2 ? 0 : ph + 1;
+        --tau;
+    };
+    const int tw = a.skip + 1 > 1 ? a.skip + 1 : 1;     // window steps first (time runs backwards): tau = T ... tw
+    for (; tau - 2 >= tw; tau -= 3) {
+        step(W1, P0, tau, ops);
+        step(W1, P1, tau - 1, ops);
+        step(W1, P2, tau - 2, ops);
     }
+    while (tau >= tw) step_any(W1, ops);
     OpsN opsn;                                         // the window is over: its registers go to W^T (fewer LDS reads per chain)
     opsn.promote_from(ops);
 #if SSN_DUO_STAMP
@@ -1033,10 +1050,13 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         }
     }
 #else
-    for (; tau >= 1; --tau) {
-        if (ph == 0) step(W0, P0, tau, opsn); else if (ph == 1) step(W0, P1, tau, opsn); else step(W0, P2, tau, opsn);
-        ph = ph == 2 ? 0 : ph + 1;
+    while (tau >= 1 && ph != 0) step_any(W0, opsn);
+    for (; tau >= 3; tau -= 3) {
+        step(W0, P0, tau, opsn);
+        step(W0, P1, tau - 1, opsn);
+        step(W0, P2, tau - 2, opsn);
     }
+    while (tau >= 1) step_any(W0, opsn);
 #endif
     if (!d) __syncthreads();
     if (GEXT && live) {
@@ -1052,8 +1072,8 @@ template <int MK, bool GEXT>
 __global__ void __launch_bounds__(512, 2) gen_backward_duo_kernel(GenBwdArgs<float> a) {
     using S = Duo16<MK>;
     // LDS-resident part of W^T per wave of a draw (by the row tiles the wave finishes), and its prefix sums
-    constexpr int WL0 = S::nl_bwd_win(DuoWave<MK, 0>::NTF) * 1024, WL1 = S::nl_bwd_win(DuoWave<MK, 1>::NTF) * 1024,
-                  WL2 = S::nl_bwd_win(DuoWave<MK, 2>::NTF) * 1024, WL3 = S::nl_bwd_win(DuoWave<MK, 3>::NTF) * 1024;
+    constexpr int WL0 = S::nl_bwd_win(0, DuoWave<MK, 0>::NTF) * 1024, WL1 = S::nl_bwd_win(1, DuoWave<MK, 1>::NTF) * 1024,
+                  WL2 = S::nl_bwd_win(2, DuoWave<MK, 2>::NTF) * 1024, WL3 = S::nl_bwd_win(3, DuoWave<MK, 3>::NTF) * 1024;
     constexpr int WLD = WL0 + WL1 + WL2 + WL3;                        // per draw
     constexpr int DRAWB = S::BB + (S::WM - 1) * S::XS + 32;          // per draw: one B image, partial-sum slots, scale words
     constexpr int LDSB = 2 * DRAWB + 16;
