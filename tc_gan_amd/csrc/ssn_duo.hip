@@ -36,6 +36,9 @@
 #ifndef SSN_DUO_EARLY
 #define SSN_DUO_EARLY 1         // row tiles a wave finishes right behind its own chain (forward kernels; 0 = none)
 #endif
+#ifndef SSN_DUO_EARLY_BWD
+#define SSN_DUO_EARLY_BWD 1     // adjoint sweep: the last row tile of a step after the window behind the previous step's chain (0 = off)
+#endif
 #ifndef SSN_DUO_ABLATE
 #define SSN_DUO_ABLATE 0        // diagnostic builds (timing only, wrong results): 1 = no nonlinearity, 2 = one FMA per MFMA,
                                 // 4 / 8 = serial part / chain at s_setprio 1
@@ -884,7 +887,9 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         for (int e = 0; e < 2; ++e) {
             const int i = 2 * tf + e;
             rowok[i] = row + e < M;
-            eps[i] = row + e < N ? a.eps_E : a.eps_I;
+            // (0 for a row or stimulus that does not exist: its delta = eps f' a is then 0 without a select in the loop;
+            // its f', carry and sums are zeros already -- out-of-range loads, zero rows of W^T, zero columns of the B image)
+            eps[i] = (row + e < M && live) ? (row + e < N ? a.eps_E : a.eps_I) : 0.f;
             gta[i] = (live && row + e < M) ? a.g_time_avg[((size_t)b * a.NB + s) * M + row + e] * inv : 0.f;
             carry[i] = dsum[i] = xn[i] = 0.f;
         }
@@ -919,9 +924,49 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         o.chain(b_rd, acc);
         if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
     };
-    auto serial = [&](auto WIN, auto PH, int tau) {
+    // The last row tile of a step AFTER the window can be finished early: right behind the chain of the step before, in
+    // that chain's phase (the wave would idle there while the partner wave of its SIMD is in a serial part 300-500 cycles
+    // longer than a chain): join, delta, carry, the f' load two steps ahead and the store of delta need registers and global
+    // memory only.  What it leaves for the serial phase: delta of that tile (2 values) and their maximum, for the scale test
+    // and the publication to the B image.
+    constexpr int TE = NTF - 1;
+    float de0 = 0.f, de1 = 0.f, dme = 0.f;
+    auto join_tile = [&](int tf, float usc) {
+        mf4 sm = acc[tf];
+        if constexpr (WS::HEAD_SHARED) {
+            if (tf == 0) {
+                const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
+            }
+        }
+        const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
+        const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
+        carry[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, carry[2 * tf]);
+        carry[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, carry[2 * tf + 1]);
+    };
+    auto early = [&](auto PH, int tau) {             // step tau (no window terms), tile TE; runs behind the chain of step tau + 1
+        constexpr int ph = decltype(PH)::value;
+        float (&dfc)[NE] = df3[(ph + 1) % 3];
+        float (&ndf)[NE] = df3[ph];
+        if (tau < T_) join_tile(TE, duo_pow2(-wexp - bused));
+        float dl[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * TE + e;
+            const float a_t = carry[i];
+            dl[e] = eps[i] * dfc[i] * a_t;
+            carry[i] = fmaf(-eps[i], a_t, a_t);
+            if (GEXT) dsum[i] += dl[e];
+        }
+        de0 = dl[0]; de1 = dl[1];
+        dme = fmaxf(__builtin_fabsf(dl[0]), __builtin_fabsf(dl[1]));
+        load2(rs_dlt, tau >= 3, at(TE, tau - 3), ndf[2 * TE], ndf[2 * TE + 1]);
+        store2(rs_dlt, tau >= 2, at(TE, tau - 2), dl[0], dl[1]);
+    };
+    auto serial = [&](auto WIN, auto PH, int tau, auto ED_) {
         constexpr bool win_on = decltype(WIN)::value;
         constexpr int ph = decltype(PH)::value;
+        constexpr bool ED = decltype(ED_)::value && !win_on && NTF > 1;      // tile TE of this step was finished early
         float (&dfc)[NE] = df3[(ph + 1) % 3];
         float (&ndf)[NE] = df3[ph];
         // loads for two steps ahead (f' into the rotating set; the trajectory row of the window is copied into place at the end)
@@ -942,27 +987,16 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         if (tau < T_) {                             // W^T delta_{tau+1} 2^(a + bused) from the accumulators of the last chain
             const float usc = duo_pow2(-wexp - bused);
 #pragma unroll
-            for (int tf = 0; tf < NTF; ++tf) {
-                mf4 sm = acc[tf];
-                if constexpr (WS::HEAD_SHARED) {
-                    if (tf == 0) {
-                        const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
-                        sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
-                    }
-                }
-                const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
-                const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
-                carry[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, carry[2 * tf]);
-                carry[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, carry[2 * tf + 1]);
-            }
+            for (int tf = 0; tf < NTF; ++tf)
+                if (!(ED && tf == TE)) join_tile(tf, usc);
         }
         float delta[NE], dm = 0.f;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            float gg = 0.f;
-            if constexpr (win_on) gg = direct(i, tau);
-            const float a_t = gg + carry[i];
-            delta[i] = (rowok[i] && live) ? eps[i] * dfc[i] * a_t : 0.f;
+            if (ED && i / 2 == TE) { delta[i] = (i & 1) ? de1 : de0; continue; }
+            float a_t = carry[i];
+            if constexpr (win_on) a_t += direct(i, tau);
+            delta[i] = eps[i] * dfc[i] * a_t;
             dm = fmaxf(dm, __builtin_fabsf(delta[i]));
             carry[i] = fmaf(-eps[i], a_t, a_t);                                   // (1 - eps) a_t
             if (GEXT) dsum[i] += delta[i];
@@ -972,8 +1006,9 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         // into the set the step before last used)
 #pragma unroll
         for (int tf = 0; tf < NTF; ++tf) {
-            load2(rs_dlt, tau >= 3, at(tf, tau - 3), ndf[2 * tf], ndf[2 * tf + 1]);
+            if (!(ED && tf == TE)) load2(rs_dlt, tau >= 3, at(tf, tau - 3), ndf[2 * tf], ndf[2 * tf + 1]);
         }
+        if constexpr (ED) dm = fmaxf(dm, dme);
         const float rs = live ? duo_pow2(bexp) : 0.f;
         if (!(dm * rs < 65504.f)) delta[0] = __builtin_nanf("");                   // outgrew the lagged scale: poison, do not clamp
 #pragma unroll
@@ -984,7 +1019,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
             const unsigned wr = b_wr + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW);
             *(LdsU)(size_t)wr = h;
             *(LdsU)(size_t)(wr + 128u) = m;
-            store2(rs_dlt, tau >= 2, at(tf, tau - 2), delta[2 * tf], delta[2 * tf + 1]);         // shifted: pairs with x_{tau-1}
+            if (!(ED && tf == TE)) store2(rs_dlt, tau >= 2, at(tf, tau - 2), delta[2 * tf], delta[2 * tf + 1]);   // shifted: pairs with x_{tau-1}
         }
         bused = bexp;
         // one LDS atomic per wave (64 lanes on one address serialise: 16.6 -> 9.x ms): wave maximum first, six DPP steps
@@ -996,11 +1031,55 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     constexpr std::integral_constant<bool, true> W1{};
     __syncthreads();                                                          // (B)
     if (d) __syncthreads();                            // draw 1 runs one phase behind draw 0
+#if SSN_DUO_STAMP
+    unsigned long long st_s = 0, st_b1 = 0, st_c = 0, st_b2 = 0; int st_n = 0;
+#endif
+    constexpr std::integral_constant<bool, false> E0{};
+    constexpr std::integral_constant<bool, true> E1{};
     auto step = [&](auto WIN, auto PH, int tau, const auto& o) {
-        serial(WIN, PH, tau);
+#if SSN_DUO_STAMP
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        serial(WIN, PH, tau, E0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        duo_phase_barrier();
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        chain(o);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        duo_phase_barrier();
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        if (!decltype(WIN)::value) { st_s += t1 - t0; st_b1 += t2 - t1; st_c += t3 - t2; st_b2 += t4 - t3; ++st_n; }   // steps after the window
+#else
+        serial(WIN, PH, tau, E0);
         duo_phase_barrier();
         chain(o);
         duo_phase_barrier();
+#endif
+    };
+    // a step after the window whose last tile was finished early, finishing the next step's last tile behind its own chain
+    auto step_e = [&](auto PH, auto PHN, int tau, bool more, const auto& o) {
+#if SSN_DUO_STAMP
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        serial(W0, PH, tau, E1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        duo_phase_barrier();
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        chain(o);
+        if (more) early(PHN, tau - 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        duo_phase_barrier();
+        const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+        st_s += t1 - t0; st_b1 += t2 - t1; st_c += t3 - t2; st_b2 += t4 - t3; ++st_n;
+#else
+        serial(W0, PH, tau, E1);
+        duo_phase_barrier();
+        chain(o);
+        if (more) early(PHN, tau - 1);
+        duo_phase_barrier();
+#endif
     };
     constexpr std::integral_constant<int, 0> P0{};
     constexpr std::integral_constant<int, 1> P1{};
@@ -1026,37 +1105,27 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     while (tau >= tw) step_any(W1, ops);
     OpsN opsn;                                         // the window is over: its registers go to W^T (fewer LDS reads per chain)
     opsn.promote_from(ops);
-#if SSN_DUO_STAMP
-    {
-        unsigned long long ts = 0, tb1 = 0, tc = 0, tb2 = 0; int n = 0;
-        for (; tau >= 1; --tau, ++n) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            if (ph == 0) serial(W0, P0, tau); else if (ph == 1) serial(W0, P1, tau); else serial(W0, P2, tau);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-            __syncthreads();
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            chain(opsn);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            __syncthreads();
-            const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-            ts += t1 - t0; tb1 += t2 - t1; tc += t3 - t2; tb2 += t4 - t3;
-            ph = ph == 2 ? 0 : ph + 1;
-        }
-        if (blockIdx.x == 0 && (WV == 0 || WV == 3) && d == 0 && lane == 0) {
-            unsigned long long* o = duo_stamps + (WV == 0 ? 0 : 4);
-            o[0] = tc; o[1] = tb2; o[2] = ts; o[3] = tb1; duo_stamps[8] = (unsigned long long)n;
-        }
-    }
-#else
     while (tau >= 1 && ph != 0) step_any(W0, opsn);
-    for (; tau >= 3; tau -= 3) {
-        step(W0, P0, tau, opsn);
-        step(W0, P1, tau - 1, opsn);
-        step(W0, P2, tau - 2, opsn);
+    if constexpr (SSN_DUO_EARLY_BWD && NTF > 3) {       // (the four-tile wave only: for the others chain + tile outlasts the serial part it shortens)
+        if (tau >= 3) early(P0, tau);                  // (primes the pipeline: once, outside a chain phase)
+        for (; tau >= 3; tau -= 3) {
+            step_e(P0, P1, tau, true, opsn);
+            step_e(P1, P2, tau - 1, true, opsn);
+            step_e(P2, P0, tau - 2, tau - 3 >= 3, opsn);
+        }
+    } else {
+        for (; tau >= 3; tau -= 3) {
+            step(W0, P0, tau, opsn);
+            step(W0, P1, tau - 1, opsn);
+            step(W0, P2, tau - 2, opsn);
+        }
     }
     while (tau >= 1) step_any(W0, opsn);
+#if SSN_DUO_STAMP
+    if (blockIdx.x == 0 && (WV == 0 || WV == 3) && d == 0 && lane == 0) {
+        unsigned long long* o = duo_stamps + (WV == 0 ? 0 : 4);
+        o[0] = st_c; o[1] = st_b2; o[2] = st_s; o[3] = st_b1; duo_stamps[8] = (unsigned long long)st_n;
+    }
 #endif
     if (!d) __syncthreads();
     if (GEXT && live) {
