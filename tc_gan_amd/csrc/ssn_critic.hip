@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <type_traits>
+#include <cstdlib>
 #include "ssn_host.h"
 
 namespace ssn {
@@ -279,7 +280,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
 }
 // the vector loads of gemm_bf16_pipe_kernel: 16-byte aligned bases, contiguous extents and leading strides in fours
 static bool gemm_pipe_ok(const GemmArgs& g) {
-    if (g.K < 64) return false;
+    // SSN_GEMM_PIPE=0: every GEMM through the general kernel (A/B runs and tests/test_critic_gpu.py; read once)
+    static const bool on = [] { const char* e = getenv("SSN_GEMM_PIPE"); return !(e && e[0] == '0'); }();
+    if (!on || g.K < 64) return false;
     auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
     if (!al(g.A) || !al(g.B)) return false;
     const bool akc = g.sak == 1, bkc = g.sbk == 1;

@@ -61,6 +61,43 @@ def test_critic_bf16_path_close_to_fp64():
     assert err < 3e-2, err
 
 
+def test_pipelined_bf16_gemm_agrees_with_the_general_kernel():
+    """`gemm_bf16_pipe_kernel` (16-byte loads three K tiles ahead) takes the bf16 GEMMs with K >= 64 and contiguous extents in
+    fours; `SSN_GEMM_PIPE=0` sends everything through the general kernel.  Same tile, same k order: loss, gradients and
+    critic outputs agree to fp32 summation noise (split-K slices are cut at multiples of 64 instead of 32) for shapes with
+    partial tiles in every index: rows not a multiple of 64, widths 72 / 100 / 132 (K tails of 8 / 36 / 4 beyond a tile of
+    64), and the C3 shape with its split-K weight gradients."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tc_gan_amd.critic import Critic\n"
+        "res = {}\n"
+        "for tag, batch, layers in (('a', 200, [72, 100, 132]), ('b', 1000, [512, 68]), ('c3', 1024, [512, 512, 512])):\n"
+        "    rs = np.random.RandomState(len(layers) * 7 + batch)\n"
+        "    c = Critic(8, layers, precision='bf16', seed=5)\n"
+        "    xg, xd = (torch.as_tensor(rs.rand(batch, 8) * 5, device='cuda', dtype=torch.float32) for _ in range(2))\n"
+        "    xp = 0.25 * xg + 0.75 * xd\n"
+        "    cond = torch.as_tensor(np.stack([np.full(batch, 20.), rs.rand(batch) * 2 - 1, rs.randint(0, 2, batch)], 1),\n"
+        "                           device='cuda', dtype=torch.float32)\n"
+        "    res['stats_' + tag] = c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()\n"
+        "    res['grads_' + tag] = c.grads.cpu().numpy()\n"
+        "    res['out_' + tag] = c.forward(xg, cond).cpu().numpy()\n"
+        "np.savez(sys.argv[1], **res)\n" % root)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for form in ('0', '1'):
+            path = os.path.join(tmp, 'pipe%s.npz' % form)
+            subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, SSN_GEMM_PIPE=form), timeout=300)
+            res[form] = dict(np.load(path))
+    for key, want in res['0'].items():
+        assert np.isfinite(want).all() and np.abs(want).max() > 0, key
+        np.testing.assert_allclose(res['1'][key], want, rtol=1e-5, atol=2e-6 * np.abs(want).max(), err_msg=key)
+
+
 def test_generator_side_input_gradient():
     c, params_o, xg, xd, xp, cond = _setup(96, 8, [64, 64], seed=11)
     x = og.t64(xg).clone().requires_grad_(True)
