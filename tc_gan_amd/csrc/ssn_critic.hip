@@ -182,16 +182,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(SplitKReduceArgs a) 
 
 
 // ---------------------------------------------------------------------------------
-// The bf16 GEMM for the shapes the critic spends its time in (batch x 512 x 512 and the like: K >= 64, the contiguous
-// extents multiples of 4).  Same tile (64 x 64 per workgroup, 2 x 2 waves of one 32 x 32 MFMA tile), same k order of the
+// The bf16 GEMM for the shapes the critic spends its time in (batch x 512 x 512 and the like: K >= 64).  Same tile (64 x 64 per workgroup, 2 x 2 waves of one 32 x 32 MFMA tile), same k order of the
 // accumulation -- what changes is how the operands arrive: the general kernel above issues one K tile of scalar loads per
 // iteration and waits for it, and at 16 iterations of about a microsecond of load latency each a 0.5 GFLOP GEMM took
 // 18 us.  Here every thread fetches 16-byte vectors along the contiguous index, THREE K tiles of 64 ahead (24 loads in
 // flight per thread), LDS is double buffered and an iteration has one barrier.
-//   AKC / BKC: k is the contiguous index of op(A) / op(B) (otherwise m / n is).
 // ---------------------------------------------------------------------------------
 typedef float gf4 __attribute__((ext_vector_type(4)));
-template <bool AKC, bool BKC>
+// operand modes: 0 = k contiguous (16-byte vectors along k), 1 = m / n contiguous (vectors along m / n), 2 = any strides
+// (scalar loads, k fastest: the 11-wide input side of the first layer, whose extents are not multiples of four)
+template <int AMODE, int BMODE>
 __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
     constexpr int BM = 64, BN = 64, BK = 64, LDK = BK + 8, NST = 3;
     __shared__ __align__(16) unsigned short As[2][BM][LDK];
@@ -205,47 +205,50 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
     const int q = tid & 15, p = tid >> 4;             // vector index along the contiguous extent, line within a group of 16
     gf4 ra[NST][4], rb[NST][4];
     const gf4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    auto load = [&](auto ST, int k0) {
-        constexpr int st = decltype(ST)::value;
+    // one operand tile (64 lines x 64 k) into 4 vectors per thread; X(line, k) = base[line * sl + k * sk], `lines` valid lines
+    auto fetch = [&](auto MODE, const float* base, long sl, long sk, int l0, int lines, int k0, gf4 (&r)[4]) {
+        constexpr int mode = decltype(MODE)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if constexpr (AKC) {                      // line = row m, vector = 4 consecutive k
-                const int m = m0 + p + 16 * i, k = k0 + 4 * q;
-                ra[st][i] = (m < g.M && k < kend) ? *reinterpret_cast<const gf4*>(g.A + (long)m * g.sam + k) : zero4;
-            } else {                                  // line = k, vector = 4 consecutive rows m
-                const int k = k0 + p + 16 * i, m = m0 + 4 * q;
-                ra[st][i] = (m < g.M && k < kend) ? *reinterpret_cast<const gf4*>(g.A + (long)k * g.sak + m) : zero4;
-            }
-            if constexpr (BKC) {
-                const int n = n0 + p + 16 * i, k = k0 + 4 * q;
-                rb[st][i] = (n < g.N && k < kend) ? *reinterpret_cast<const gf4*>(g.B + (long)n * g.sbn + k) : zero4;
-            } else {
-                const int k = k0 + p + 16 * i, n = n0 + 4 * q;
-                rb[st][i] = (n < g.N && k < kend) ? *reinterpret_cast<const gf4*>(g.B + (long)k * g.sbk + n) : zero4;
+            if constexpr (mode == 0) {                // line = p + 16 i, vector = 4 consecutive k
+                const int l = l0 + p + 16 * i, k = k0 + 4 * q;
+                r[i] = (l < lines && k < kend) ? *reinterpret_cast<const gf4*>(base + (long)l * sl + k) : zero4;
+            } else if constexpr (mode == 1) {         // k = p + 16 i, vector = 4 consecutive lines
+                const int k = k0 + p + 16 * i, l = l0 + 4 * q;
+                r[i] = (l < lines && k < kend) ? *reinterpret_cast<const gf4*>(base + (long)k * sk + l) : zero4;
+            } else {                                  // the element layout of mode 0, one load each
+                const int l = l0 + p + 16 * i;
+                gf4 v = zero4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = k0 + 4 * q + e;
+                    if (l < lines && k < kend) v[e] = base[(long)l * sl + (long)k * sk];
+                }
+                r[i] = v;
             }
         }
     };
-    auto stash = [&](auto ST, int buf) {
-        constexpr int st = decltype(ST)::value;
+    auto stash = [&](auto MODE, unsigned short (&T)[BM][LDK], const gf4 (&r)[4]) {
+        constexpr int mode = decltype(MODE)::value;
         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const gf4 a = ra[st][i], b = rb[st][i];
-            if constexpr (AKC) {
-                *reinterpret_cast<us4*>(&As[buf][p + 16 * i][4 * q]) = (us4){to_bf16(a.x), to_bf16(a.y), to_bf16(a.z), to_bf16(a.w)};
+            const gf4 a = r[i];
+            if constexpr (mode != 1) {
+                *reinterpret_cast<us4*>(&T[p + 16 * i][4 * q]) = (us4){to_bf16(a.x), to_bf16(a.y), to_bf16(a.z), to_bf16(a.w)};
             } else {
                 const int k = p + 16 * i;
-                As[buf][4 * q][k] = to_bf16(a.x); As[buf][4 * q + 1][k] = to_bf16(a.y);
-                As[buf][4 * q + 2][k] = to_bf16(a.z); As[buf][4 * q + 3][k] = to_bf16(a.w);
-            }
-            if constexpr (BKC) {
-                *reinterpret_cast<us4*>(&Bs[buf][p + 16 * i][4 * q]) = (us4){to_bf16(b.x), to_bf16(b.y), to_bf16(b.z), to_bf16(b.w)};
-            } else {
-                const int k = p + 16 * i;
-                Bs[buf][4 * q][k] = to_bf16(b.x); Bs[buf][4 * q + 1][k] = to_bf16(b.y);
-                Bs[buf][4 * q + 2][k] = to_bf16(b.z); Bs[buf][4 * q + 3][k] = to_bf16(b.w);
+                T[4 * q][k] = to_bf16(a.x); T[4 * q + 1][k] = to_bf16(a.y);
+                T[4 * q + 2][k] = to_bf16(a.z); T[4 * q + 3][k] = to_bf16(a.w);
             }
         }
+    };
+    constexpr std::integral_constant<int, AMODE> AM{};
+    constexpr std::integral_constant<int, BMODE> BMD{};
+    auto load = [&](auto ST, int k0) {
+        constexpr int st = decltype(ST)::value;
+        fetch(AM, g.A, g.sam, g.sak, m0, g.M, k0, ra[st]);
+        fetch(BMD, g.B, g.sbn, g.sbk, n0, g.N, k0, rb[st]);
     };
     f32x16 acc;
 #pragma unroll
@@ -254,8 +257,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
     // barrier is enough: a wave stores into buffer (t + 1) & 1 only behind barrier t, which every wave reaches after its
     // MFMA reads of iteration t - 1 from that buffer.
     auto step = [&](auto ST, int t) {
+        constexpr int st = decltype(ST)::value;
         const int buf = t & 1;
-        stash(ST, buf);
+        stash(AM, As[buf], ra[st]);
+        stash(BMD, Bs[buf], rb[st]);
         __syncthreads();
         if (t + NST < nt) load(ST, kbeg + (t + NST) * BK);
 #pragma unroll
@@ -278,19 +283,24 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
     }
     gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane);
 }
-// the vector loads of gemm_bf16_pipe_kernel: 16-byte aligned bases, contiguous extents and leading strides in fours
+// how gemm_bf16_pipe_kernel fetches an operand X(line, k) = base[line * sl + k * sk] with `lines` lines and K columns:
+// 16-byte vectors need an aligned base, a unit stride along the vector and the other stride and the extent in fours
+static int gemm_pipe_mode(const float* base, long sl, long sk, int lines, int K) {
+    const bool al = (reinterpret_cast<size_t>(base) & 15) == 0;
+    if (al && sk == 1 && K % 4 == 0 && sl % 4 == 0) return 0;
+    if (al && sl == 1 && lines % 4 == 0 && sk % 4 == 0) return 1;
+    return 2;
+}
 static bool gemm_pipe_ok(const GemmArgs& g) {
     // SSN_GEMM_PIPE=0: every GEMM through the general kernel (A/B runs and tests/test_critic_gpu.py; read once)
     static const bool on = [] { const char* e = getenv("SSN_GEMM_PIPE"); return !(e && e[0] == '0'); }();
-    if (!on || g.K < 64) return false;
-    auto al = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; };
-    if (!al(g.A) || !al(g.B)) return false;
-    const bool akc = g.sak == 1, bkc = g.sbk == 1;
-    if (!akc && g.sam != 1) return false;
-    if (!bkc && g.sbn != 1) return false;
-    if (akc ? (g.K % 4 || g.sam % 4) : (g.M % 4 || g.sak % 4)) return false;
-    if (bkc ? (g.K % 4 || g.sbn % 4) : (g.N % 4 || g.sbk % 4)) return false;
-    return true;
+    return on && g.K >= 64;
+}
+template <int AMODE>
+static void gemm_pipe_launch_b(int bmode, dim3 grid, hipStream_t st, const GemmArgs& g) {
+    if (bmode == 0)      hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AMODE, 0>), grid, dim3(256), 0, st, g);
+    else if (bmode == 1) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AMODE, 1>), grid, dim3(256), 0, st, g);
+    else                 hipLaunchKernelGGL((gemm_bf16_pipe_kernel<AMODE, 2>), grid, dim3(256), 0, st, g);
 }
 
 static int choose_splits(int M, int N, int K) {
@@ -355,11 +365,10 @@ static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
     }
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
     if (pipe) {
-        const bool akc = g.sak == 1, bkc = g.sbk == 1;
-        if (akc && bkc) hipLaunchKernelGGL((gemm_bf16_pipe_kernel<true, true>), grid, dim3(256), 0, st, g);
-        else if (akc)   hipLaunchKernelGGL((gemm_bf16_pipe_kernel<true, false>), grid, dim3(256), 0, st, g);
-        else if (bkc)   hipLaunchKernelGGL((gemm_bf16_pipe_kernel<false, true>), grid, dim3(256), 0, st, g);
-        else            hipLaunchKernelGGL((gemm_bf16_pipe_kernel<false, false>), grid, dim3(256), 0, st, g);
+        const int am = gemm_pipe_mode(g.A, g.sam, g.sak, g.M, g.K), bm = gemm_pipe_mode(g.B, g.sbn, g.sbk, g.N, g.K);
+        if (am == 0)      gemm_pipe_launch_b<0>(bm, grid, st, g);
+        else if (am == 1) gemm_pipe_launch_b<1>(bm, grid, st, g);
+        else              gemm_pipe_launch_b<2>(bm, grid, st, g);
     } else if (bf16) hipLaunchKernelGGL((gemm_mfma_kernel<true>), grid, dim3(256), 0, st, g);
     else      hipLaunchKernelGGL((gemm_mfma_kernel<false>), grid, dim3(256), 0, st, g);
     return hipGetLastError();
