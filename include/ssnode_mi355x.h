@@ -258,6 +258,21 @@ int ssn_gen_backward_ext_f64(const double *W, const double *traj, double *df_del
 int ssn_weight_grad_f32(const float *delta, const float *traj, float *gW, int B, long K, int M, int kernel, void *stream);
 int ssn_weight_grad_f64(const double *delta, const double *traj, double *gW, int B, long K, int M, int kernel, void *stream);
 /*
+ * The same product on the fp16 matrix cores: every operand as two fp16 numbers by round to nearest (x 2^e = h + m to 2^-24),
+ * three partial products per product, fp32 accumulation -- the accuracy of kernel 2 at half its matrix work.  fp16 has five
+ * exponent bits, so the caller supplies bounds: dmax device [B], dmax[b] >= max |delta[b]| (one power-of-two scale per
+ * draw; elements below 2^-40 of it are lost), and xmax >= max |traj| (host scalar, > 0 and finite: the rate bound of the
+ * saturating I/O function).  A bound that is too small overflows fp16: inf / NaN in gW, never a silently wrong value.
+ * ssn_gen_backward_max_f32 is ssn_gen_backward_ext_f32 plus that bound: when the sweep that runs tracks max |delta| per draw
+ * (the two-draw kernel, which needs it for its own scaling) it fills dmax[B] and sets *tracked = 1; otherwise *tracked = 0,
+ * dmax is untouched and ssn_weight_grad_f32 is the kernel to call.  fp32, M <= 224.
+ */
+int ssn_gen_backward_max_f32(const float *W, const float *traj, float *df_delta, const float *g_time_avg, float *g_ext,
+                             float *dmax, int *tracked, double c_dyn, double c_rate, int B, int NB, int M,
+                             const ssn_gen_params *p, void *stream);
+int ssn_weight_grad_scaled_f32(const float *delta, const float *traj, float *gW, int B, long K, int M, const float *dmax,
+                               float xmax, void *stream);
+/*
  * Chain rule W -> (J, D, S) of make_W_with_x (make_w_batch.py:19-34): out[b][pq][0..2] =
  * partial dL/dJ_pq, dL/dD_pq, dL/dS_pq of draw b (device fp64 [B][4][3]; sum over b on the caller's
  * side in a fixed order).  J, D, S are HOST arrays of 4.

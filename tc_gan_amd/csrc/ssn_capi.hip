@@ -492,7 +492,8 @@ int gen_forward_impl(const T* W, const T* ext, T* time_avg, T* dyn_row, T* rate_
 
 template <typename T>
 int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ext, double c_dyn, double c_rate, int B,
-                      int NB, int M, const ssn_gen_params* g, void* stream) {
+                      int NB, int M, const ssn_gen_params* g, void* stream, float* dmax = nullptr, int* tracked = nullptr) {
+    if (tracked) *tracked = 0;
     if (B == 0 || NB == 0) return 0;
     if (!g || !W || !traj || !delta || !gta || M <= 0 || (M & 1) || g->seqlen < 1 || g->skip_steps < 0 ||
         g->skip_steps >= g->seqlen || !ssn::gen_supported<T>(M)) {
@@ -515,9 +516,14 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
             const bool split_ok = ssn::gen_split_backward_supported(M, NB);
             a.split_narrow = g->kernel == 6;
             const bool split = split_ok && (g->kernel >= 4 || (g->kernel == 0 && forward_split_default()));
-            if (split_ok && (g->kernel == 8 || (g->kernel == 0 && forward_split_default() && duo_default(groups, B, NB))))
+            if (split_ok && (g->kernel == 8 || (g->kernel == 0 && forward_split_default() && duo_default(groups, B, NB)))) {
+                if (dmax && tracked) {                  // max |delta| per draw for ssn_weight_grad_scaled_f32 (atomic max of bit patterns)
+                    SSN_TRY(hipMemsetAsync(dmax, 0, sizeof(float) * (size_t)B, (hipStream_t)stream));
+                    a.dmax = reinterpret_cast<unsigned*>(dmax);
+                    *tracked = 1;
+                }
                 SSN_TRY(ssn::launch_gen_backward_duo(a, (hipStream_t)stream));
-            else if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
+            } else if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
             else SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
             return 0;
         }
@@ -818,6 +824,22 @@ int ssn_gen_backward_ext_f64(const double* W, const double* traj, double* df_del
                              double* g_ext, double c_dyn, double c_rate, int B, int NB, int M, const ssn_gen_params* p,
                              void* stream) {
     return gen_backward_impl<double>(W, traj, df_delta, g_time_avg, g_ext, c_dyn, c_rate, B, NB, M, p, stream);
+}
+int ssn_gen_backward_max_f32(const float* W, const float* traj, float* df_delta, const float* g_time_avg, float* g_ext,
+                             float* dmax, int* tracked, double c_dyn, double c_rate, int B, int NB, int M,
+                             const ssn_gen_params* p, void* stream) {
+    return gen_backward_impl<float>(W, traj, df_delta, g_time_avg, g_ext, c_dyn, c_rate, B, NB, M, p, stream, dmax, tracked);
+}
+int ssn_weight_grad_scaled_f32(const float* delta, const float* traj, float* gW, int B, long K, int M, const float* dmax,
+                               float xmax, void* stream) {
+    if (!delta || !traj || !gW || !dmax || B < 0 || K < 0 || M <= 0 || M > 224 || !(xmax > 0.f) || !(xmax < __builtin_inff()) ||
+        K * (long)M * 4 >= (1L << 31)) {
+        g_last_error = "ssn_weight_grad_scaled: invalid argument (fp32, M <= 224, K M < 2^29, dmax on the device, 0 < xmax < inf)";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_weight_grad_scaled(delta, traj, gW, B, K, M, reinterpret_cast<const unsigned*>(dmax), xmax,
+                                           (hipStream_t)stream));
+    return 0;
 }
 int ssn_weight_grad_f32(const float* delta, const float* traj, float* gW, int B, long K, int M, int kernel, void* stream) {
     if (B < 0 || K < 0 || M < 0 || (B > 0 && M > 0 && (!gW || (K > 0 && (!delta || !traj))))) {

@@ -920,6 +920,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
     int bused = 0;                                  // the scale exponent the draw's delta in LDS was written with
     unsigned lastref = 0u;
+    unsigned runmax = 0u;                           // max over the steps so far of max |delta_tau| (scalar): GenBwdArgs::dmax
     auto chain = [&](const auto& o) {
         o.chain(b_rd, acc);
         if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
@@ -982,6 +983,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         if (WV == 0 && lane == 0) *(LdsU)(size_t)slot(tau + 2) = 0u;             // next step's word (last read two phases ago)
         const unsigned ref = mprev ? mprev : lastref;
         lastref = ref;
+        runmax = runmax > mprev ? runmax : mprev;       // (delta_T .. delta_2 are stored; their maxima are read at tau = T - 1 .. 1)
         int bexp = 7 - ((int)((ref >> 23) & 0xffu) - 127);
         bexp = ref == 0u ? 0 : (bexp > 100 ? 100 : (bexp < -100 ? -100 : bexp));
         if (tau < T_) {                             // W^T delta_{tau+1} 2^(a + bused) from the accumulators of the last chain
@@ -1128,6 +1130,9 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     }
 #endif
     if (!d) __syncthreads();
+    // the bound ssn_gw.hip scales the draw's delta with (the prologue's estimate of max |delta_T| in the first word read
+    // only makes it larger; a poisoned step stores NaN and the products are NaN whatever the scale)
+    if (a.dmax && valid && WV == 0 && lane == 0) atomicMax(a.dmax + b, runmax);
     if (GEXT && live) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) {

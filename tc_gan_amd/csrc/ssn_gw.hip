@@ -12,13 +12,29 @@
 // one fp32 MFMA: the GEMM needs 2.4 ms of matrix-pipe time at C3 instead of 5.0 and becomes HBM-bound (15.8 GB).
 // The result carries fp32 input precision (tests/test_generator_gpu.py checks it against fp64 to ~1e-6).
 //
+// gw_split_kernel<NT, true> (round 3): the same GEMM with every operand as TWO fp16 numbers by round to nearest,
+// x 2^e = h + m, |x 2^e - h - m| <= 2^-24 |x 2^e| (h = rn16(s), m = rn16(s - h): 11 + 1 + 11 significant bits while m stays
+// above the fp16 subnormal step, i.e. for elements within 2^15 of the largest), and the three partial products that reach
+// 2^-24: dh xh + dh xm + dm xh (dropped: dm xm <= 2^-24 |d x|) on v_mfma_f32_32x32x16_f16: HALF the matrix work of the bf16
+// form at the same accuracy.  fp16 has 5 exponent bits, so each operand needs a power-of-two scale that brings its largest
+// magnitude to [2^14, 2^15): one per draw for Delta (max |delta| of the draw, which the two-draw adjoint sweep of
+// ssn_duo.hip tracks for its own scaling and hands over), one per call for X (the rate bound of the saturating I/O
+// function).  Values 2^-40 of the largest and below are lost -- against sum_k |d||x| of the same draw they do not count.
+//
 // One workgroup (8 waves) per draw keeps the whole M x M accumulator on chip (7 x 7 tiles of 32 x 32 at 2N = 200: wave
 // (rh, cq) owns tile rows rh*4.. and tile columns cq*2..), streams Delta and X in slabs of 16 k through LDS (split once
 // per element, shared by all waves; [row][k] layout, 48-byte row stride: conflict-free 16-byte operand reads), double
 // buffered, one barrier per slab, global loads two slabs ahead.  HBM traffic = the operands once + the result once.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <type_traits>
 #include "ssn_host.h"
+
+// Ablation builds for timing only (tools/ab_one.sh <tag> ssn_gw -DGW_ABLATE=n; results are wrong): 1 no MFMAs and no operand
+// reads, 2 no global loads inside the loop, 3 no split and no LDS stores, 4 MFMAs on operands read once (no LDS reads in the loop)
+#ifndef GW_ABLATE
+#define GW_ABLATE 0
+#endif
 
 namespace ssn {
 
@@ -48,6 +64,7 @@ template <> struct GwBlocks<4> {
 // stores.  LDS: [buffer][matrix][part] images of 256 rows (rows >= 2N hold zeros), layout below.
 struct GwStage {
     __amdgpu_buffer_rsrc_t rs;
+    float scale;         // fp16 form: the power of two this thread's matrix is multiplied with before the split
     int voff;            // byte offset of (k = 8 half, row 2 p), or -1 (row pair beyond the matrix: loads return 0)
     int k_stride;        // M * 4
     int pad;             // (16 - K % 16) % 16: slab s starts at k = 16 s - pad
@@ -110,25 +127,52 @@ __device__ __forceinline__ void gw_split_row(const float* v, gu4& ph, gu4& pm, g
 // a second plane 128 bytes further on: a staging thread writes rows 2 p and 2 p + 1 at a lane stride of 48 bytes in both
 // planes (conflict-free 16-byte stores), and the 16 consecutive rows of one ds_read_b128 lane group fall on 64 distinct
 // banks (the odd plane's skew of 32 banks = what 8 more even slots would add).
-constexpr unsigned GW_ROWB = 48, GW_ODD = 128 * GW_ROWB + 128, GW_PARTB = 2 * 128 * GW_ROWB + 256, GW_MATB = 3 * GW_PARTB,
-                   GW_BUFB = 2 * GW_MATB;
+constexpr unsigned GW_ROWB = 48, GW_ODD = 128 * GW_ROWB + 128, GW_PARTB = 2 * 128 * GW_ROWB + 256;
+template <bool F16> struct GwFmt {
+    static constexpr unsigned NP = F16 ? 2 : 3;          // parts per operand
+    static constexpr unsigned MATB = NP * GW_PARTB, BUFB = 2 * MATB;
+};
 __device__ __forceinline__ unsigned gw_row(unsigned r) { return (r >> 1) * GW_ROWB + (r & 1) * GW_ODD; }
 
+typedef _Float16 gh2 __attribute__((ext_vector_type(2)));
+typedef _Float16 gh8 __attribute__((ext_vector_type(8)));
+// 8 consecutive k of one row, fp16 form: s = x * scale = h + m by round to nearest (v_cvt_pk_f16_f32; 2.5 VALU per element)
+__device__ __forceinline__ void gw_split_row_f16(const float* v, float sc, gu4& ph, gu4& pm) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = v[2 * q] * sc, b = v[2 * q + 1] * sc;
+        const gh2 h = __builtin_convertvector((gf2){a, b}, gh2);
+        const float ra = a - (float)h[0], rb = b - (float)h[1];
+        ph[q] = __builtin_bit_cast(unsigned, h);
+        pm[q] = __builtin_bit_cast(unsigned, __builtin_convertvector((gf2){ra, rb}, gh2));
+    }
+}
+
+template <bool F16>
 __device__ __forceinline__ void gw_stage(const GwStage& g, char* buf, const float (&raw)[16]) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        gu4 ph, pm, pl;
-        gw_split_row(&raw[8 * rr], ph, pm, pl);
         char* p = buf + g.lds + rr * GW_ODD;
-        *reinterpret_cast<gu4*>(p) = ph;
-        *reinterpret_cast<gu4*>(p + GW_PARTB) = pm;
-        *reinterpret_cast<gu4*>(p + 2 * GW_PARTB) = pl;
+        if constexpr (F16) {
+            gu4 ph, pm;
+            gw_split_row_f16(&raw[8 * rr], g.scale, ph, pm);
+            *reinterpret_cast<gu4*>(p) = ph;
+            *reinterpret_cast<gu4*>(p + GW_PARTB) = pm;
+        } else {
+            gu4 ph, pm, pl;
+            gw_split_row(&raw[8 * rr], ph, pm, pl);
+            *reinterpret_cast<gu4*>(p) = ph;
+            *reinterpret_cast<gu4*>(p + GW_PARTB) = pm;
+            *reinterpret_cast<gu4*>(p + 2 * GW_PARTB) = pl;
+        }
     }
 }
 
 // The main loop of one wave class: an NR x NC block of tiles at tile (r0, c0).  Every class runs the same barriers.
-template <int NR, int NC>
-__device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, int r0, int c0, int lane, int half, float* out, int M) {
+template <int NR, int NC, bool F16>
+__device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, int r0, int c0, int lane, int half, float* out, int M,
+                                       float osc0, float osc1) {
+    constexpr unsigned GW_MATB = GwFmt<F16>::MATB, GW_BUFB = GwFmt<F16>::BUFB;
     gf16 acc[NR][NC];
 #pragma unroll
     for (int r = 0; r < NR; ++r)
@@ -140,17 +184,34 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
     const unsigned a_off = gw_row(r0 * 32 + orow) + ohalf * 16;                 // matrix 0, part 0
     const unsigned b_off = GW_MATB + gw_row(c0 * 32 + orow) + ohalf * 16;       // matrix 1, part 0
 
-    float rawA[16], rawB[16];
-    gw_fetch_first(g, half, rawA);
-    gw_stage(g, sm, rawA);
-    gw_fetch(g, 1, rawA);             // (slabs past the end read zeros)
-    gw_fetch(g, 2, rawB);
+    float raw[3][16];
+    gw_fetch_first(g, half, raw[0]);
+    gw_stage<F16>(g, sm, raw[0]);
+    gw_fetch(g, 1, raw[1]);           // (slabs past the end read zeros)
+    gw_fetch(g, 2, raw[2]);
+    gw_fetch(g, 3, raw[0]);
     __syncthreads();
 
     auto mma = [&](const char* buf) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const char* pa = buf + a_off + r * 16 * GW_ROWB;
+            if constexpr (F16) {
+                const gh8 ah = *reinterpret_cast<const gh8*>(pa);
+                const gh8 am = *reinterpret_cast<const gh8*>(pa + GW_PARTB);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const char* pb = buf + b_off + c * 16 * GW_ROWB;
+                    const gh8 bh = *reinterpret_cast<const gh8*>(pb);
+                    const gh8 bm = *reinterpret_cast<const gh8*>(pb + GW_PARTB);
+                    gf16 a = acc[r][c];                  // smallest partial products first
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, bh, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bm, a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, a, 0, 0, 0);
+                    acc[r][c] = a;
+                }
+                continue;
+            }
             const gb8 ah = *reinterpret_cast<const gb8*>(pa);
             const gb8 am = *reinterpret_cast<const gb8*>(pa + GW_PARTB);
             const gb8 al = *reinterpret_cast<const gb8*>(pa + 2 * GW_PARTB);
@@ -171,20 +232,39 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
             }
         }
     };
-    // Slab s is multiplied from buffer s & 1 while slab s + 1 (in registers since two iterations) is split into the
-    // other buffer and slab s + 3 is requested from HBM.  The three are independent and sit in one basic block: the
+    // Slab s is multiplied from buffer s & 1 while slab s + 1 (in registers since three iterations) is split into the
+    // other buffer and slab s + 4 is requested from HBM: three slabs = 77 KB per CU in flight (with two, the kernel ran at
+    // 4.3 TB/s = the bytes in flight over the loaded latency).  The three are independent and sit in one basic block: the
     // compiler puts the VALU of the split between the MFMAs (explicit sched_group_barrier pipelines changed nothing).
-    for (int s = 0; s < nslab; s += 2) {
+    // Register sets rotate with period 3, LDS buffers with period 2: six slabs per loop iteration, spelled out.
+    auto it = [&](int s, auto R, auto P) {
+        constexpr int r = decltype(R)::value, p = decltype(P)::value;
+#if GW_ABLATE == 4
         mma(sm);
-        gw_stage(g, sm + GW_BUFB, rawA);
-        gw_fetch(g, s + 3, rawA);
+        asm volatile("" ::: "memory");
+#elif GW_ABLATE != 1
+        mma(sm + p * GW_BUFB);
+#endif
+#if GW_ABLATE != 3
+        gw_stage<F16>(g, sm + (1 - p) * GW_BUFB, raw[r]);
+#endif
+#if GW_ABLATE != 2
+        gw_fetch(g, s + 4, raw[r]);
+#endif
         __syncthreads();
-        mma(sm + GW_BUFB);
-        gw_stage(g, sm, rawB);
-        gw_fetch(g, s + 4, rawB);
-        __syncthreads();
+    };
+    constexpr std::integral_constant<int, 0> I0{};
+    constexpr std::integral_constant<int, 1> I1{};
+    constexpr std::integral_constant<int, 2> I2{};
+    for (int s = 0; s < nslab; s += 6) {
+        it(s, I1, I0);
+        it(s + 1, I2, I1);
+        it(s + 2, I0, I0);
+        it(s + 3, I1, I1);
+        it(s + 4, I2, I0);
+        it(s + 5, I0, I1);
     }
-    // (an odd slab count multiplies one slab of zeros at the end)
+    // (a slab count that is not a multiple of six multiplies slabs of zeros at the end)
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -195,14 +275,26 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int i = (r0 + r) * 32 + (e & 3) + 8 * (e >> 2) + 4 * ohalf;
-                if (i < M && j < M) out[(size_t)i * M + j] = acc[r][c][e];
+                if (i < M && j < M) out[(size_t)i * M + j] = F16 ? acc[r][c][e] * osc0 * osc1 : acc[r][c][e];
             }
         }
 }
 
-template <int NT>
+// e = 14 - floor(log2 v) from the bit pattern of v > 0, clamped to +-100 (0 and denormals: 100; inf / NaN: -100, the
+// products are then inf / NaN like the operands)
+__device__ __forceinline__ int gw_exp(unsigned bits) {
+    const int biased = (int)((bits >> 23) & 0xffu);
+    const int e = 14 - ((biased ? biased : 1) - 127);
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__device__ __forceinline__ float gw_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+
+// F16: dmax[b] = bit pattern of max |delta[b]| (or of any bound on it), xmax = a bound on |traj|
+template <int NT, bool F16>
 __global__ void __launch_bounds__(512, 2) gw_split_kernel(const float* __restrict__ delta, const float* __restrict__ traj,
-                                                          float* __restrict__ gW, long K, int M) {
+                                                          float* __restrict__ gW, long K, int M,
+                                                          const unsigned* __restrict__ dmax, float xmax) {
+    constexpr unsigned GW_MATB = GwFmt<F16>::MATB;
     extern __shared__ __align__(16) char sm[];           // 2 buffers of GW_BUFB bytes
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long KM = K * (long)M;
@@ -215,17 +307,24 @@ __global__ void __launch_bounds__(512, 2) gw_split_kernel(const float* __restric
     g.k_stride = M * 4;
     g.pad = (int)((16 - K % 16) % 16);
     g.lds = (unsigned)mat * GW_MATB + gw_row(2 * pair) + half * 16;
+    float osc0 = 1.f, osc1 = 1.f;
+    g.scale = 1.f;
+    if constexpr (F16) {
+        const int ed = gw_exp(dmax[b]), ex = gw_exp(__builtin_bit_cast(unsigned, xmax));
+        g.scale = gw_pow2(mat == 0 ? ed : ex);
+        osc0 = gw_pow2(-ed); osc1 = gw_pow2(-ex);
+    }
     const int nslab = (int)((K + 15) / 16);
     float* out = gW + (size_t)b * M * M;
     using BL = GwBlocks<NT>;
     const int cls = __builtin_amdgcn_readfirstlane(BL::cls(wave));
     const int r0 = __builtin_amdgcn_readfirstlane(BL::r0(wave)), c0 = __builtin_amdgcn_readfirstlane(BL::c0(wave));
     if constexpr (NT == 7) {
-        if (cls == 0) gw_run<2, 3>(g, sm, nslab, r0, c0, lane, half, out, M);
-        else if (cls == 1) gw_run<1, 7>(g, sm, nslab, r0, c0, lane, half, out, M);
-        else gw_run<6, 1>(g, sm, nslab, r0, c0, lane, half, out, M);
+        if (cls == 0) gw_run<2, 3, F16>(g, sm, nslab, r0, c0, lane, half, out, M, osc0, osc1);
+        else if (cls == 1) gw_run<1, 7, F16>(g, sm, nslab, r0, c0, lane, half, out, M, osc0, osc1);
+        else gw_run<6, 1, F16>(g, sm, nslab, r0, c0, lane, half, out, M, osc0, osc1);
     } else {
-        gw_run<2, 1>(g, sm, nslab, r0, c0, lane, half, out, M);
+        gw_run<2, 1, F16>(g, sm, nslab, r0, c0, lane, half, out, M, osc0, osc1);
     }
 }
 
@@ -253,40 +352,47 @@ __global__ void __launch_bounds__(256) gw_simple_kernel(const T* __restrict__ de
     if (i0 + ti < M && j0 + tj < M) gW[(size_t)b * M * M + (size_t)(i0 + ti) * M + j0 + tj] = acc;
 }
 
+template <int NT, bool F16>
+static hipError_t gw_launch_split(const float* delta, const float* traj, float* gW, int B, long K, int M, const unsigned* dmax,
+                                  float xmax, hipStream_t st) {
+    const size_t lds = 2 * (size_t)GwFmt<F16>::BUFB;     // 150528 (bf16 x 3) / 100352 (fp16 x 2) bytes: one workgroup per CU
+    static bool once = false;
+    if (!once) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gw_split_kernel<NT, F16>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        once = true;
+    }
+    hipLaunchKernelGGL((gw_split_kernel<NT, F16>), dim3(B), dim3(512), lds, st, delta, traj, gW, K, M, dmax, xmax);
+    return hipGetLastError();
+}
+static bool gw_split_ok(long K, int M) { return M <= 224 && K * (long)M * 4 < (1L << 31); }
+
 template <typename T>
 hipError_t launch_weight_grad(const T* delta, const T* traj, T* gW, int B, long K, int M, int kernel, hipStream_t st) {
     if (B <= 0 || M <= 0) return hipSuccess;
     if (K <= 0) return hipMemsetAsync(gW, 0, sizeof(T) * (size_t)B * M * M, st);
     if constexpr (sizeof(T) == 4) {
         // kernel: 0 automatic, 1 plain-FMA kernel, 2 split-bf16 MFMA kernel
-        const bool split_ok = M <= 224 && K * (long)M * 4 < (1L << 31);
+        const bool split_ok = gw_split_ok(K, M);
         if (kernel == 2 && !split_ok) return hipErrorInvalidValue;
         if ((kernel == 0 && split_ok && M > 32) || kernel == 2) {
-            const size_t lds = 2 * (size_t)GW_BUFB;      // 150528 bytes: one workgroup per CU
-            hipError_t e;
-            if (M <= 128) {
-                static bool once4 = false;
-                if (!once4) {
-                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gw_split_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) return e;
-                    once4 = true;
-                }
-                hipLaunchKernelGGL((gw_split_kernel<4>), dim3(B), dim3(512), lds, st, delta, traj, gW, K, M);
-            } else {
-                static bool once7 = false;
-                if (!once7) {
-                    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gw_split_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) return e;
-                    once7 = true;
-                }
-                hipLaunchKernelGGL((gw_split_kernel<7>), dim3(B), dim3(512), lds, st, delta, traj, gW, K, M);
-            }
-            return hipGetLastError();
+            if (M <= 128) return gw_launch_split<4, false>(delta, traj, gW, B, K, M, nullptr, 0.f, st);
+            return gw_launch_split<7, false>(delta, traj, gW, B, K, M, nullptr, 0.f, st);
         }
     }
     const int nt = (M + 15) / 16;
     hipLaunchKernelGGL((gw_simple_kernel<T>), dim3((unsigned)((long)B * nt * nt)), dim3(256), 0, st, delta, traj, gW, K, M);
     return hipGetLastError();
+}
+// The fp16 two-part form: dmax[b] = bit pattern of a bound on |delta[b]| (device), xmax = a bound on |traj| (> 0, finite)
+hipError_t launch_weight_grad_scaled(const float* delta, const float* traj, float* gW, int B, long K, int M, const unsigned* dmax,
+                                     float xmax, hipStream_t st) {
+    if (B <= 0 || M <= 0) return hipSuccess;
+    if (K <= 0) return hipMemsetAsync(gW, 0, sizeof(float) * (size_t)B * M * M, st);
+    if (!gw_split_ok(K, M) || !dmax || !(xmax > 0.f) || !(xmax < __builtin_inff())) return hipErrorInvalidValue;
+    if (M <= 128) return gw_launch_split<4, true>(delta, traj, gW, B, K, M, dmax, xmax, st);
+    return gw_launch_split<7, true>(delta, traj, gW, B, K, M, dmax, xmax, st);
 }
 template hipError_t launch_weight_grad<float>(const float*, const float*, float*, int, long, int, int, hipStream_t);
 template hipError_t launch_weight_grad<double>(const double*, const double*, double*, int, long, int, int, hipStream_t);

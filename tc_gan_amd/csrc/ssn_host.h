@@ -49,6 +49,8 @@ struct GenBwdArgs {
     T eps_E, eps_I, theta, c_dyn, c_rate;
     int mfma_groups = 2;
     int split_narrow = 0;  // as GenFwdArgs::split_narrow
+    unsigned* dmax = nullptr;   // [B] or nullptr: atomic max of the bit patterns of |delta| the sweep stores for draw b (zeroed by
+                                // the caller; the two-draw kernel of ssn_duo.hip only -- it tracks the value for its own scaling)
 };
 template <typename T>
 struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };
@@ -99,6 +101,9 @@ template <typename T> hipError_t launch_jds_grad(const T* gW, const T* z, const 
 
 // ssn_gw.hip: gW[b] = delta[b]^T traj[b] over K rows ([K][M] row-major each); kernel 0 auto, 1 plain FMA, 2 split-bf16 MFMA
 template <typename T> hipError_t launch_weight_grad(const T* delta, const T* traj, T* gW, int B, long K, int M, int kernel, hipStream_t st);
+// the same on two fp16 parts per operand (3 partial products): dmax[b] bounds |delta[b]| (bit pattern, device), xmax bounds |traj|
+hipError_t launch_weight_grad_scaled(const float* delta, const float* traj, float* gW, int B, long K, int M, const unsigned* dmax,
+                                     float xmax, hipStream_t st);
 
 // ssn_critic.hip
 struct OptArgs {

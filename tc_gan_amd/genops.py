@@ -87,31 +87,66 @@ def gen_forward(W, ext, gp, save=False):
     return out
 
 
-def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp, want_g_ext=False):
+def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp, want_g_ext=False, want_dmax=False):
     """Adjoint sweep; `df` is overwritten by the shifted delta and returned (with dL/d ext when asked).
-    c_dyn / c_rate multiply SUM(dyn_row) / SUM(rate_row) in the loss."""
+    c_dyn / c_rate multiply SUM(dyn_row) / SUM(rate_row) in the loss.
+    ``want_dmax`` (fp32): the last element of the returned tuple is max |delta| per draw, a (B,) tensor, when the sweep
+    that ran tracks it (``ssn_gen_backward_max_f32``: the two-draw kernel), else None -- the bound `weight_grad` needs
+    for its fp16 form."""
     clib.require_gpu()
     B, NB, T, M = traj.shape
     suffix, _ = _DT[W.dtype]
     g_time_avg = g_time_avg.to(W.dtype).contiguous()
     g_ext = torch.empty((B, NB, M), device=W.device, dtype=W.dtype) if want_g_ext else None
-    rc = getattr(libssnode, 'ssn_gen_backward_ext_' + suffix)(
-        W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(),
-        g_ext.data_ptr() if want_g_ext else None, float(c_dyn), float(c_rate),
-        B, NB, M, ctypes.byref(gp), _stream())
-    clib.check(rc, 'ssn_gen_backward_ext_' + suffix)
-    return (df, g_ext) if want_g_ext else df
+    dmax = None
+    if want_dmax and suffix == 'f32':
+        dmax = torch.empty((B,), device=W.device, dtype=torch.float32)
+        tracked = ctypes.c_int(0)
+        rc = libssnode.ssn_gen_backward_max_f32(
+            W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(),
+            g_ext.data_ptr() if want_g_ext else None, dmax.data_ptr(), ctypes.byref(tracked), float(c_dyn), float(c_rate),
+            B, NB, M, ctypes.byref(gp), _stream())
+        clib.check(rc, 'ssn_gen_backward_max_f32')
+        if not tracked.value:
+            dmax = None
+    else:
+        rc = getattr(libssnode, 'ssn_gen_backward_ext_' + suffix)(
+            W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(),
+            g_ext.data_ptr() if want_g_ext else None, float(c_dyn), float(c_rate),
+            B, NB, M, ctypes.byref(gp), _stream())
+        clib.check(rc, 'ssn_gen_backward_ext_' + suffix)
+    out = (df,) + ((g_ext,) if want_g_ext else ()) + ((dmax,) if want_dmax else ())
+    return out if len(out) > 1 else df
 
 
-def weight_grad(delta, traj, kernel=0):
+def rate_bound(gp):
+    """A bound on every rate of the fixed-time generator started at 0, or None: with the saturating I/O function and
+    dt <= tau each Euler step is a convex combination of the state and f(u) <= rate_hard_bound (networks/ssn.py:566-576)."""
+    if gp.io_type == clib.IO_CODES['asym_tanh'] and 0 < gp.dt <= min(gp.tau_E, gp.tau_I) and 0 < gp.rate_hard_bound < float('inf'):
+        return float(gp.rate_hard_bound)
+    return None
+
+
+def weight_grad(delta, traj, kernel=0, dmax=None, xmax=None):
     """dL/dW[b] = delta[b]^T . traj[b] over K = NB*T (``ssn_weight_grad_*``; kernel: 0 automatic, 1 plain FMAs,
-    2 split-bf16 MFMA)."""
+    2 split-bf16 MFMA: three bf16 parts per operand, six partial products; 3 the fp16 form of ``ssn_weight_grad_scaled_f32``:
+    two fp16 parts per operand by round to nearest, three partial products -- it needs ``dmax`` (B,) >= max |delta[b]| on the
+    device and a scalar ``xmax`` >= max |traj|, and with kernel 0 it is taken whenever both are given)."""
     clib.require_gpu()
     B, NB, T, M = traj.shape
     suffix, _ = _DT[traj.dtype]
     delta = delta.contiguous(); traj = traj.contiguous()
     assert delta.shape == traj.shape and delta.dtype == traj.dtype
     gW = torch.empty((B, M, M), device=traj.device, dtype=traj.dtype)
+    scaled_ok = suffix == 'f32' and dmax is not None and xmax is not None and 32 < M <= 224 and NB * T * M < (1 << 29)
+    if kernel == 3 and not scaled_ok:
+        raise ValueError('weight_grad kernel 3 needs fp32, 32 < M <= 224, dmax and xmax')
+    if scaled_ok and kernel in (0, 3):
+        assert dmax.shape == (B,) and dmax.dtype == torch.float32 and dmax.is_cuda
+        rc = libssnode.ssn_weight_grad_scaled_f32(delta.data_ptr(), traj.data_ptr(), gW.data_ptr(), B, NB * T, M,
+                                                  dmax.contiguous().data_ptr(), float(xmax), _stream())
+        clib.check(rc, 'ssn_weight_grad_scaled_f32')
+        return gW
     rc = getattr(libssnode, 'ssn_weight_grad_' + suffix)(delta.data_ptr(), traj.data_ptr(), gW.data_ptr(), B, NB * T, M,
                                                          int(kernel), _stream())
     clib.check(rc, 'ssn_weight_grad_' + suffix)

@@ -352,9 +352,10 @@ class TuningCurveGenerator(object):
             g_ta = torch.zeros_like(fwd['time_avg'])
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
         res = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
-                                  rate_cost / fwd['n_rate'], sv['gp'], want_g_ext=self.heteroin)
-        delta, g_ext = res if self.heteroin else (res, None)
-        gW = genops.weight_grad(delta, fwd['traj'])
+                                  rate_cost / fwd['n_rate'], sv['gp'], want_g_ext=self.heteroin, want_dmax=True)
+        delta, g_ext, dmax = res if self.heteroin else (res[0], None, res[1])
+        # (fp16 two-part form of dL/dW where the sweep handed over max |delta| per draw and the rates are bounded)
+        gW = genops.weight_grad(delta, fwd['traj'], dmax=dmax, xmax=genops.rate_bound(sv['gp']))
         gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S, as_tensor=as_tensor)
         grads = dict(J=gJ, D=gD, S=gS)
         if self.heteroin:

@@ -188,8 +188,10 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
     for kernel in (1, 2, 3, 4, 5, 6, 8):
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=kernel, **GEN)
         out = genops.gen_forward(W, ext, gp, save=True)
-        delta = genops.gen_backward(W, out['traj'], out['df'], gta, 1e-3, 1e-3, gp)
-        gW = genops.weight_grad(delta, out['traj'])
+        delta, dmax = genops.gen_backward(W, out['traj'], out['df'], gta, 1e-3, 1e-3, gp, want_dmax=True)
+        assert (dmax is not None) == (kernel == 8)
+        # (kernel 8: dL/dW on the fp16 two-part form, as the generator update runs it)
+        gW = genops.weight_grad(delta, out['traj'], dmax=dmax, xmax=genops.rate_bound(gp))
         res[kernel] = (out['time_avg'].cpu().numpy(), float(out['dynamics_penalty']), float(out['rate_penalty']),
                        gW.cpu().numpy())
         del out, delta, gW
@@ -206,7 +208,8 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
 @pytest.mark.parametrize('B,NB,T,M,dtype,kernel', [
     (3, 2, 5, 20, 'float64', 0), (2, 4, 7, 20, 'float32', 1), (2, 8, 30, 100, 'float32', 2), (3, 8, 50, 200, 'float32', 0),
     (2, 8, 37, 202, 'float32', 2), (2, 3, 11, 224, 'float32', 2), (1, 8, 20, 258, 'float32', 0), (2, 8, 1, 200, 'float32', 2),
-    (2, 8, 1200, 200, 'float32', 0)])
+    (2, 8, 1200, 200, 'float32', 0), (2, 8, 30, 100, 'float32', 3), (3, 8, 50, 200, 'float32', 3), (2, 8, 37, 202, 'float32', 3),
+    (2, 3, 11, 224, 'float32', 3), (2, 8, 1, 200, 'float32', 3), (2, 8, 1200, 200, 'float32', 3)])
 def test_weight_grad_kernels_vs_fp64_matmul(B, NB, T, M, dtype, kernel):
     """dL/dW[b] = delta[b]^T traj[b] (csrc/ssn_gw.hip) against numpy fp64.  The split-bf16 MFMA kernel must deliver fp32
     input precision: every fp32 operand is the exact sum of its three bf16 terms and only partial products below 2^-24
@@ -217,7 +220,9 @@ def test_weight_grad_kernels_vs_fp64_matmul(B, NB, T, M, dtype, kernel):
     d = (rs.randn(B, NB, T, M) * np.exp(rs.uniform(-12, 0, (B, NB, T, M)))).astype(dtype)
     x = (rs.rand(B, NB, T, M) * 100 * np.exp(rs.uniform(-6, 0, (B, NB, T, M)))).astype(dtype)
     want = np.einsum('bki,bkj->bij', d.reshape(B, NB * T, M).astype('float64'), x.reshape(B, NB * T, M).astype('float64'))
-    got = genops.weight_grad(torch.as_tensor(d).cuda(), torch.as_tensor(x).cuda(), kernel=kernel).cpu().numpy()
+    # kernel 3 (fp16 two-part form) takes its scales from bounds: max |delta| per draw, and a loose one on the rates
+    bounds = dict(dmax=torch.as_tensor(np.abs(d).reshape(B, -1).max(axis=1)).cuda(), xmax=1000.0) if kernel == 3 else {}
+    got = genops.weight_grad(torch.as_tensor(d).cuda(), torch.as_tensor(x).cuda(), kernel=kernel, **bounds).cpu().numpy()
     assert got.shape == (B, M, M)
     # scale of one output element: sum_k |d||x| -- the bound every floating-point dot product is measured against
     scale = np.einsum('bki,bkj->bij', np.abs(d.reshape(B, NB * T, M)).astype('float64'),
@@ -232,6 +237,77 @@ def test_weight_grad_kernels_vs_fp64_matmul(B, NB, T, M, dtype, kernel):
             e[k] = (np.abs(r - want) / (scale + 1e-300)).max()
         # the split-bf16 MFMA kernel is at least as accurate as an fp32 FMA chain over the same K
         assert e[2] < tol and e[2] <= 1.5 * e[1] + 1e-7, e
+        if kernel == 3:         # ... and so is the fp16 two-part form (operands to 2^-24, the dropped m * m term 2^-24)
+            assert err.max() <= 1.5 * e[1] + 1e-7, (err.max(), e)
+
+
+def test_scaled_weight_grad_ranges_and_refusals():
+    """`ssn_weight_grad_scaled_f32`: the per-draw power-of-two scale makes the result independent of the magnitude of delta
+    (draws of 1e-30 and 1e+20 next to each other), an all-zero draw gives zeros, a bound far above the data still gives fp32
+    accuracy (the parts keep 2^-40 of the bound), a bound BELOW the data overflows to inf / NaN instead of a wrong finite
+    value, and NaN in an operand reaches the output."""
+    from tc_gan_amd import genops
+    rs = np.random.RandomState(5)
+    B, NB, T, M = 4, 8, 40, 200
+    d = rs.randn(B, NB, T, M).astype('float32')
+    x = (rs.rand(B, NB, T, M) * 300).astype('float32')
+    mags = np.array([1e-30, 1.0, 1e20, 0.0], dtype='float32')
+    d *= mags[:, None, None, None]
+    want = np.einsum('bki,bkj->bij', d.reshape(B, NB * T, M).astype('float64'), x.reshape(B, NB * T, M).astype('float64'))
+    scale = np.einsum('bki,bkj->bij', np.abs(d.reshape(B, NB * T, M)).astype('float64'),
+                      np.abs(x.reshape(B, NB * T, M)).astype('float64'))
+    dt, xt = torch.as_tensor(d).cuda(), torch.as_tensor(x).cuda()
+    dmax = torch.as_tensor(np.abs(d).reshape(B, -1).max(axis=1)).cuda()
+    for loose in (1.0, 2.0 ** 12):
+        got = genops.weight_grad(dt, xt, kernel=3, dmax=dmax * loose, xmax=300.0 * loose).cpu().numpy()
+        assert np.isfinite(got).all() and (got[3] == 0).all()
+        err = np.abs(got[:3] - want[:3]) / scale[:3]
+        assert err.max() < 2e-6, (loose, err.max())
+    bad = genops.weight_grad(dt, xt, kernel=3, dmax=dmax * 2.0 ** -6, xmax=300.0).cpu().numpy()
+    assert not np.isfinite(bad[1]).any()
+    dn = dt.clone(); dn[1, 3, 7, 11] = float('nan')
+    got = genops.weight_grad(dn, xt, kernel=3, dmax=dmax, xmax=300.0).cpu().numpy()
+    assert np.isnan(got[1, 11]).all() and np.isfinite(got[0]).all() and np.isfinite(got[2]).all()
+    with pytest.raises(ValueError):
+        genops.weight_grad(dt, xt, kernel=3)
+    with pytest.raises(Exception):
+        genops.weight_grad(dt, xt, kernel=3, dmax=dmax, xmax=float('inf'))
+
+
+@pytest.mark.parametrize('io_type', ['asym_tanh', 'asym_power'])
+def test_two_draw_adjoint_hands_over_max_delta(io_type):
+    """`ssn_gen_backward_max_f32`: the two-draw sweep (kernel 8) returns max |delta| per draw -- a bound on everything it
+    stored (at most the prologue's estimate of the first step above the true maximum) -- and dL/dW from the fp16 form with
+    that bound agrees with the bf16 x 3 form; the other sweeps report `not tracked`."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    N, B, NB, T, skip = 100, 5, 8, 120, 80
+    jds = on.new_JDS()
+    rs = np.random.RandomState(11)
+    z = torch.as_tensor(rs.rand(B, 2 * N, 2 * N), device='cuda', dtype=torch.float32)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    bws = np.tile(np.asarray(P['bandwidths'])[None, :], (B, 1))
+    ext = stimuli.stimulus_batch(bws, np.full_like(bws, 20.0), P['smoothness'], N, dtype='float32')
+    gta = torch.as_tensor(rs.randn(B, NB, 2 * N) * np.array([1e-6, 1.0, 1e4, 1.0, 0.0])[:, None, None], device='cuda',
+                          dtype=torch.float32)
+    fwd_kernel = 8 if io_type == 'asym_tanh' else 2
+    gpf = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=fwd_kernel, **dict(GEN, io_type=io_type))
+    out = genops.gen_forward(W, ext, gpf, save=True)
+    gp8 = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=8, **dict(GEN, io_type=io_type))
+    delta, dmax = genops.gen_backward(W, out['traj'], out['df'].clone(), gta, 0.0, 0.0, gp8, want_dmax=True)
+    assert dmax is not None and dmax.shape == (B,)
+    true = delta.abs().reshape(B, -1).max(dim=1).values.cpu().numpy()
+    got = dmax.cpu().numpy()
+    assert (got >= true).all() and (got <= np.maximum(true * 4, 1e-30)).all(), (got, true)
+    assert got[4] == 0.0
+    xmax = genops.rate_bound(gp8)
+    assert (xmax is not None) == (io_type == 'asym_tanh')
+    a = genops.weight_grad(delta, out['traj'], kernel=2).cpu().numpy()
+    b = genops.weight_grad(delta, out['traj'], kernel=3, dmax=dmax, xmax=float(out['traj'].max()) + 1.0).cpu().numpy()
+    for i in range(B):
+        np.testing.assert_allclose(b[i], a[i], rtol=0, atol=2e-6 * max(np.abs(a[i]).max(), 1e-300) * np.sqrt(NB * T))
+    gp2 = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=2, **dict(GEN, io_type=io_type))
+    res = genops.gen_backward(W, out['traj'], out['df'].clone(), gta, 0.0, 0.0, gp2, want_dmax=True)
+    assert res[1] is None
 
 
 def test_split_kernel_refuses_unbounded_io_functions():

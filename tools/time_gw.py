@@ -21,7 +21,9 @@ def timeit(fn, n=5):
 
 flops = 2.0 * B * M * M * NB * T
 bytes_ = 2.0 * B * NB * T * M * 4
+dmax = d.abs().reshape(B, -1).max(dim=1).values
 for name, fn in [('split-bf16 MFMA', lambda: genops.weight_grad(d, x, kernel=2)),
+                 ('fp16 two-part MFMA', lambda: genops.weight_grad(d, x, kernel=3, dmax=dmax, xmax=1000.0)),
                  ('rocBLAS bmm', lambda: torch.bmm(d.reshape(B, NB * T, M).transpose(1, 2), x.reshape(B, NB * T, M)))]:
     if ONLY and ONLY not in name:
         continue
@@ -29,8 +31,10 @@ for name, fn in [('split-bf16 MFMA', lambda: genops.weight_grad(d, x, kernel=2))
     print('%-18s %.2f ms  %.1f TFLOP/s  %.2f TB/s of operands' % (name, ms, flops / ms * 1e-9, bytes_ / ms * 1e-9))
 if ONLY:
     sys.exit(0)
+a16 = genops.weight_grad(d, x, kernel=3, dmax=dmax, xmax=1000.0)
 a = genops.weight_grad(d, x, kernel=2)
 r = torch.bmm(d.reshape(B, NB * T, M).transpose(1, 2).double(), x.reshape(B, NB * T, M).double())
-print('max rel err vs fp64: split %.2e, rocBLAS fp32 %.2e' % (
+print('max rel err vs fp64: fp16 two-part %.2e, split %.2e, rocBLAS fp32 %.2e' % (
+    float(((a16.double() - r).abs() / r.abs().max()).max()),
     float(((a.double() - r).abs() / r.abs().max()).max()),
     float(((torch.bmm(d.reshape(B, NB * T, M).transpose(1, 2), x.reshape(B, NB * T, M)).double() - r).abs() / r.abs().max()).max())))
