@@ -206,7 +206,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
     def timed_loop(gen_kernel):
         """warm-up + `steps` GAN iterations of a FRESH GAN (same seeds), barrier + synchronize on both sides, MAX over ranks."""
         gan, shape, bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision, gen_kernel=gen_kernel)
-        gan.reducer.timed = world > 1
+        gan.reducer.timed = dist.is_initialized()
         it = gan.learning()
 
         def one_iter():
@@ -219,19 +219,19 @@ def run_c3(args, rank, world, local_rank, paper=False):
             one_iter()
         gan.host_draw_seconds = 0.0
         gan.reducer.collective_ms()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             info = one_iter()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         phases = None
-        if world > 1:
+        if dist.is_initialized():
             t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -324,7 +324,7 @@ def run_c5(args, rank, world, local_rank):
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for _ in range(args.warmup):
         out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -333,11 +333,11 @@ def run_c5(args, rank, world, local_rank):
         out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
         ev[k][1].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -456,8 +456,17 @@ def main():
     local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
     torch.cuda.set_device(local_rank)
     clib.require_gpu()
-    if world > 1:
+    # BENCH_FORCE_DIST=1: join a process group even as a single rank, so that the collectives of the N > 1 path (flat-buffer
+    # all-reduce per update, barriers, max-over-ranks timing) run through the chosen backend -- RCCL -- on a one-GPU box
+    force_dist = world == 1 and os.environ.get('BENCH_FORCE_DIST') == '1'
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if force_dist:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ.setdefault('MASTER_PORT', str(sk.getsockname()[1]))
+            os.environ['TCGAN_DIST_SINGLE_RANK'] = '1'       # GradientAllReducer: reduce over the one rank, too
         dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
@@ -505,13 +514,13 @@ def main():
                 out['extras'][name] = dict({k: res[k] for k in keep if k in res}, wall_s=time.perf_counter() - t_extra)
                 torch.cuda.empty_cache()
     # what actually ran: the process group's own size and backend (1 / none for a single process)
-    out['world_size'] = dist.get_world_size() if world > 1 else 1
-    out['dist_backend'] = dist.get_backend() if world > 1 else None
+    out['world_size'] = dist.get_world_size() if dist.is_initialized() else 1
+    out['dist_backend'] = dist.get_backend() if dist.is_initialized() else None
     assert out['n_gpus'] == args.gpus == out['world_size']
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
@@ -565,18 +574,18 @@ def run_solver(args, rank, world, local_rank):
 
     for _ in range(args.warmup):
         one_step()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

@@ -173,7 +173,10 @@ class GradientAllReducer(object):
     def __init__(self):
         import torch.distributed as dist
         self.dist = dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # (TCGAN_DIST_SINGLE_RANK=1: run the collectives in a one-rank group as well -- the mean over one rank is the
+        # identity; bench.py uses it to put the all-reduce path through RCCL on a one-GPU box)
+        self.on = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size() > 1 or os.environ.get('TCGAN_DIST_SINGLE_RANK') == '1')
         self.world = dist.get_world_size() if self.on else 1
         self.rank = dist.get_rank() if self.on else 0
         # per-phase timing for multi-GPU diagnosis (bench.py --gpus N): device time between two events around every

@@ -81,6 +81,27 @@ def test_gpus_2_starts_its_own_ranks():
     assert 'cpu_baseline' not in d                      # rank 0 at N = 1 only
 
 
+def test_single_rank_group_runs_the_collectives_on_rccl():
+    """The one way to put RCCL under this code on a one-GPU box: BENCH_FORCE_DIST=1 joins a one-rank `nccl` (= RCCL) group,
+    and every collective of the N > 1 path -- the flat-buffer all-reduce per critic / generator update, the barriers and the
+    max-over-ranks reductions of the timing -- runs through it.  The mean over one rank is the identity: the run must end on
+    the loss of the plain single-process run, bit for bit."""
+    env = dict(os.environ, BENCH_FORCE_DIST='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'BENCH_DIST_BACKEND'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'c3paper', '--steps', '3', '--warmup', '1']
+    out = subprocess.run(cmd, check=True, env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
+    lines = [l for l in out if l.startswith('{')]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d['dist_backend'] == 'nccl' and d['world_size'] == 1 and d['n_gpus'] == 1
+    ph = d['phases']
+    assert ph['collectives_per_iteration'] >= 2 and ph['allreduce_ms']['max'] > 0
+    plain = _bench('--workload', 'c3paper', '--steps', '3', '--warmup', '1')
+    assert plain['dist_backend'] is None and 'phases' not in plain
+    assert d['last_gen_loss'] == plain['last_gen_loss']
+
+
 def test_gpus_mismatch_is_refused():
     """A launcher that started a different number of ranks than --gpus names: no line, non-zero exit."""
     env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
