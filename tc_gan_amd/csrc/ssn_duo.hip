@@ -129,6 +129,37 @@ __device__ __forceinline__ float dpp_ror8(float x) {                  // lane li
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));
 }
 
+// Join of the two parts of a row tile's sums.  After the chain lanes s and 8 + s of a 16-lane row hold, for rows 0 .. 3 of the
+// tile (registers x, y, z, w), the products with the two fp16 parts of stimulus s; lane s (DPP banks 0, 1 of its row)
+// finishes rows 0, 1 and lane 8 + s (banks 2, 3) rows 2, 3: value e of a lane is lo_e + ror8(lo_e) in banks 0, 1 and
+// hi_e + ror8(hi_e) in banks 2, 3.  Two DPP adds with complementary bank masks write each half of the row from its own
+// register -- no selects (the builtin form, `hi ? z : x` twice and one DPP add, is three instructions per value).
+// Inline asm hides the instructions from the compiler's hazard recognizer, so the wait states are spelled out: FIRST = the
+// first join after a chain or after compiler-generated VALU writes of the operands: 11 wait states cover a finished
+// 8-pass MFMA -> VALU read and the 2 a VALU write -> DPP read needs.  The joins are volatile: they keep their order.
+// MEASURED (C3 forward, same box, both builds loaded in alternation): 3.20 ms with the asm form, 3.21 ms with the builtin
+// form -- 7 instructions fewer per serial part (of ~130) buy nothing, the wait states cost what the selects did.  The
+// builtin form is the default; -DSSN_DUO_JOIN_ASM=1 builds the other one (parity-green on the same tests).
+#ifndef SSN_DUO_JOIN_ASM
+#define SSN_DUO_JOIN_ASM 0
+#endif
+// (`also0/1`: the operands of the tile's SECOND join, named as inputs of the first so that compiler-generated writes
+// of them -- the partial sum of a neighbour wave added to a shared tile -- sit in front of the wait states as well.)
+template <bool FIRST>
+__device__ __forceinline__ float duo_join(float lo, float hi, int is_hi, float also0 = 0.f, float also1 = 0.f) {
+#if SSN_DUO_JOIN_ASM
+    float r;
+    if (FIRST) asm volatile("s_nop 10\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3"
+                            : "=v"(r) : "v"(lo), "v"(hi), "v"(also0), "v"(also1));
+    else asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3" : "=v"(r) : "v"(lo));
+    asm volatile("v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(r) : "v"(hi));
+    return r;
+#else
+    const float k = is_hi ? hi : lo, o = is_hi ? lo : hi;
+    return k + dpp_ror8(o);
+#endif
+}
+
 // max over the wave of a non-negative float (bit patterns order like the values), the same value in every lane's SGPR copy
 __device__ __forceinline__ unsigned duo_wave_max_bits(float x) {
     unsigned v = __builtin_bit_cast(unsigned, x);
@@ -402,14 +433,14 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
                         sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
                     }
                 }
-                // lane s (hi = 0) keeps rows 0, 1 and offers rows 2, 3 of its part; lane 8 + s keeps 2, 3 and offers 0, 1
-                const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
-                const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
+                // lane s (hi = 0) finishes rows 0, 1, lane 8 + s rows 2, 3 (duo_join)
+                const float j0 = tf == T0 ? duo_join<true>(sm.x, sm.z, hi, sm.y, sm.w) : duo_join<false>(sm.x, sm.z, hi);
+                const float j1 = duo_join<false>(sm.y, sm.w, hi);
                 if (is_tail) {
-                    uu[NV - 1] = fmaf(duo_tail_take(k0 + dpp_ror8(o0), k1 + dpp_ror8(o1)), usc, ex[NE - 1]);
+                    uu[NV - 1] = fmaf(duo_tail_take(j0, j1), usc, ex[NE - 1]);
                 } else {
-                    uu[2 * (tf - T0)] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
-                    uu[2 * (tf - T0) + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
+                    uu[2 * (tf - T0)] = fmaf(j0, usc, ex[2 * tf]);
+                    uu[2 * (tf - T0) + 1] = fmaf(j1, usc, ex[2 * tf + 1]);
                 }
             }
 #pragma unroll
@@ -695,10 +726,9 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
                     sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
                 }
             }
-            const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
-            const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
-            uu[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, ex[2 * tf]);
-            uu[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, ex[2 * tf + 1]);
+            const float j0 = tf == 0 ? duo_join<true>(sm.x, sm.z, hi, sm.y, sm.w) : duo_join<false>(sm.x, sm.z, hi);
+            uu[2 * tf] = fmaf(j0, usc, ex[2 * tf]);
+            uu[2 * tf + 1] = fmaf(duo_join<false>(sm.y, sm.w, hi), usc, ex[2 * tf + 1]);
         }
         duo_eval<false, NE>(io, uu, ff, dfn);
         float r1[NE], dmax = -1.f, rmax = -__builtin_inff();
@@ -940,10 +970,9 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
                 sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
             }
         }
-        const float k0 = hi ? sm.z : sm.x, k1 = hi ? sm.w : sm.y;
-        const float o0 = hi ? sm.x : sm.z, o1 = hi ? sm.y : sm.w;
-        carry[2 * tf] = fmaf(k0 + dpp_ror8(o0), usc, carry[2 * tf]);
-        carry[2 * tf + 1] = fmaf(k1 + dpp_ror8(o1), usc, carry[2 * tf + 1]);
+        // (every join_tile call may be the first reader of a chain's sums: the wait states go with each tile's first join)
+        carry[2 * tf] = fmaf(duo_join<true>(sm.x, sm.z, hi, sm.y, sm.w), usc, carry[2 * tf]);
+        carry[2 * tf + 1] = fmaf(duo_join<false>(sm.y, sm.w, hi), usc, carry[2 * tf + 1]);
     };
     auto early = [&](auto PH, int tau) {             // step tau (no window terms), tile TE; runs behind the chain of step tau + 1
         constexpr int ph = decltype(PH)::value;

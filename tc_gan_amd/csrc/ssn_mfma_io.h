@@ -80,7 +80,12 @@ struct IoSelect {
         for (int i = 0; i < NV; ++i) {
             f[i] = (v[i] < 0.f) ? 0.f : pw[i];
             if (WANT_DF) df[i] = (v[i] > 0.f) ? rv[i] : 0.f;
-            if (i) asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(v[i]));      // (ignores NaN operands)
+        }
+        // max of the NV values, two per instruction (v_max / v_max3 ignore NaN operands: NaN takes no saturating branch)
+#pragma unroll
+        for (int i = 1; i < NV; i += 2) {
+            if (i + 1 < NV) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(vmax) : "v"(vmax), "v"(v[i]), "v"(v[i + 1]));
+            else asm("v_max_f32 %0, %1, %2" : "=v"(vmax) : "v"(vmax), "v"(v[i]));
         }
         if (__builtin_amdgcn_ballot_w64(vmax > v0_low) != 0) {
             // all NV saturating values unconditionally (pinned: left alone the compiler puts each one under its own
