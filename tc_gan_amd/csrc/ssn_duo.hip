@@ -36,6 +36,14 @@
 #ifndef SSN_DUO_EARLY
 #define SSN_DUO_EARLY 1         // row tiles a wave finishes right behind its own chain (forward kernels; 0 = none)
 #endif
+#ifndef SSN_DUO_EARLY_MASK
+#define SSN_DUO_EARLY_MASK 0xf  // ... for the waves w of a draw with bit w set (the others finish every tile in the serial phase)
+#endif
+#ifndef SSN_DUO_PREB
+#define SSN_DUO_PREB 0          // forward: 1 = the B operand of the wave's own k tile is read in front of the phase barrier and the
+                                // chain starts with that tile (measured at C3, same box, three alternating runs: 3.14 ms against
+                                // 3.16 -- the first read behind the barrier is not what stretches a chain; off)
+#endif
 #ifndef SSN_DUO_EARLY_BWD
 #define SSN_DUO_EARLY_BWD 1     // adjoint sweep: the last row tile of a step after the window behind the previous step's chain (0 = off)
 #endif
@@ -53,6 +61,10 @@ namespace ssn {
 
 #if SSN_DUO_STAMP
 __device__ unsigned long long duo_stamps[16];
+// SSN_DUO_STAMP=2 (forward only): workgroup 0, every wave w = 0 .. 7: [8 w + 0 .. 5] = chain, early tile, barrier, rest of the
+// serial part, publication, barrier (ticks summed over the steps before the window); [8 w + 6] = ticks from the first to the
+// last step; [8 w + 7] = steps
+__device__ unsigned long long duo_stamps_fine[64];
 #endif
 
 typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
@@ -246,14 +258,34 @@ struct DuoOperands {
         }
         wl = o.wl + (unsigned)((NR - NR2) * 1024);
     }
-    // acc[t] = (W_h + W_m)[row tile RT0 + t, my k range] . B, B read from the image at LDS byte address rd (per lane)
-    __device__ __forceinline__ void chain(unsigned rd, mf4 (&acc)[NT]) const {
+    // The k tile whose B rows (row tiles 2 kt and 2 kt + 1) this wave finishes and publishes ITSELF, or -1: its B operand can
+    // be read back right after the wave's own stores (the DS instructions of one wave execute in order), in front of the
+    // barrier that the other k tiles have to wait for.
+    static constexpr int own_kt() {
+        for (int kt = 0; kt < S::NKT; ++kt) {
+            const int r0 = 2 * kt, r1 = 2 * kt + 1;
+            const bool in0 = r0 >= RT0 && r0 < RT0 + WS::NTF;
+            const bool in1 = r1 >= S::NRT || (r1 >= RT0 && r1 < RT0 + WS::NTF);
+            if (in0 && in1) return kt;
+        }
+        return -1;
+    }
+    static __device__ __forceinline__ hv8 read_b(unsigned rd, int kt) {
         using LdsB = const __attribute__((address_space(3))) hv8*;
+        return *(LdsB)(size_t)(rd + (unsigned)(kt * 4 * S::BROW));
+    }
+    // acc[t] = (W_h + W_m)[row tile RT0 + t, my k range] . B, B read from the image at LDS byte address rd (per lane).
+    // ROT: the k tiles in the order own_kt(), own_kt() + 1, ... (mod NKT); PRE: the first of them comes in `bpre`.
+    template <bool ROT = false, bool PRE = false>
+    __device__ __forceinline__ void chain(unsigned rd, mf4 (&acc)[NT], const hv8& bpre = hv8{}) const {
+        using LdsB = const __attribute__((address_space(3))) hv8*;
+        constexpr int K0 = (ROT && own_kt() >= 0) ? own_kt() : 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kt = 0; kt < S::NKT; ++kt) {
-            const hv8 b1 = *(LdsB)(size_t)(rd + (unsigned)(kt * 4 * S::BROW));
+        for (int kk = 0; kk < S::NKT; ++kk) {
+            const int kt = (K0 + kk) % S::NKT;
+            const hv8 b1 = (PRE && ROT && own_kt() >= 0 && kk == 0) ? bpre : read_b(rd, kt);
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -399,10 +431,13 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     const unsigned sync = bimg + (unsigned)S::SYNC;
     bool dead = false;
     mf4 acc[NT];
+    // lock-step form: the B operand of the k tile this wave publishes itself is read in front of the barrier (see own_kt)
+    constexpr bool PREB = !FREE && SSN_DUO_PREB && Ops::own_kt() >= 0;
+    hv8 bpre = hv8{};
     auto chain = [&](int it) {
         // free-running form: all four waves of the draw must have stored the state of step it - 1 (image it & 1)
         if (FREE && it > 0) duo_wait_ge(sync, S::WM * it, dead);
-        ops.chain(b_rd + (FREE ? (unsigned)((it & 1) * S::BB) : 0u), acc);
+        ops.template chain<SSN_DUO_PREB != 0, PREB>(b_rd + (FREE ? (unsigned)((it & 1) * S::BB) : 0u), acc, bpre);
         if constexpr (WS::TAIL_SHARED) {
             *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
             if (FREE) duo_signal_set(sync + 4u * (1 + WV), (unsigned)(it + 1), lane);
@@ -500,9 +535,10 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             *(LdsH)(size_t)(wr + 128u) = (unsigned short)m;
         }
         if (FREE) duo_signal_add(sync, lane);
+        if constexpr (PREB) bpre = Ops::read_b(b_rd, Ops::own_kt());
     };
     // row tiles finished behind the own chain: the last ones (never the first, which may wait for a neighbour's partial sum)
-    constexpr int EARLY = FREE ? 0 : (SSN_DUO_EARLY < NP - 1 ? SSN_DUO_EARLY : NP - 1);
+    constexpr int EARLY = (FREE || !((SSN_DUO_EARLY_MASK >> WV) & 1)) ? 0 : (SSN_DUO_EARLY < NP - 1 ? SSN_DUO_EARLY : NP - 1);
     constexpr std::integral_constant<int, 0> TB{};
     constexpr std::integral_constant<int, NP - EARLY> TM{};
     constexpr std::integral_constant<int, NP> TE{};
@@ -517,13 +553,46 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     constexpr std::integral_constant<bool, true> W1{};
     const int nskip = a.skip < T_ ? (a.skip > 0 ? a.skip : 0) : T_;
     __syncthreads();                                                          // (B)
+    if constexpr (PREB) bpre = Ops::read_b(b_rd, Ops::own_kt());               // (the initial image: zeros)
     if constexpr (FREE) {
         // no workgroup barrier from here on: the four waves of a draw meet at their own counters, the two draws drift
         for (int it = 0; it < nskip; ++it) { chain(it); serial(W0, it); }
         for (int it = nskip; it < T_; ++it) { chain(it); serial(W1, it); }
     } else {
         if (d) __syncthreads();                        // draw 1 runs one phase behind draw 0
-#if SSN_DUO_STAMP
+#if SSN_DUO_STAMP == 2
+        {
+            unsigned long long acc6[6] = {0, 0, 0, 0, 0, 0};
+            auto now = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return (unsigned long long)__builtin_amdgcn_s_memtime(); };
+            const unsigned long long tstart = now();
+            for (int it = 0; it < nskip; ++it) {
+                const unsigned long long t0 = now();
+                chain(it);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t1 = now();
+                early(W0, it);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t2 = now();
+                __syncthreads();
+                const unsigned long long t3 = now();
+                compute(W0, it, TB, TM, HAS_TAIL);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t4 = now();
+                publish(it);
+                const unsigned long long t5 = now();
+                __syncthreads();
+                const unsigned long long t6 = now();
+                acc6[0] += t1 - t0; acc6[1] += t2 - t1; acc6[2] += t3 - t2; acc6[3] += t4 - t3; acc6[4] += t5 - t4; acc6[5] += t6 - t5;
+            }
+            const unsigned long long tend = now();
+            if (blockIdx.x == 0 && lane == 0) {
+                const int w = 4 * d + WV;
+                for (int i = 0; i < 6; ++i) duo_stamps_fine[8 * w + i] = acc6[i];
+                duo_stamps_fine[8 * w + 6] = tend - tstart;
+                duo_stamps_fine[8 * w + 7] = (unsigned long long)nskip;
+            }
+        }
+#elif SSN_DUO_STAMP
         unsigned long long tc = 0, tb1 = 0, ts = 0, tb2 = 0;
         for (int it = 0; it < nskip; ++it) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -1292,6 +1361,9 @@ hipError_t launch_gen_backward_duo(const GenBwdArgs<float>& a, hipStream_t st) {
 }  // namespace ssn
 
 #if SSN_DUO_STAMP
+extern "C" int ssn_debug_duo_stamps_fine(unsigned long long* out64) {
+    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(ssn::duo_stamps_fine), 64 * sizeof(unsigned long long));
+}
 extern "C" int ssn_debug_duo_stamps(unsigned long long* out16) {
     return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(ssn::duo_stamps), 16 * sizeof(unsigned long long));
 }

@@ -37,7 +37,18 @@ def main():
         ta = genops.gen_forward(W, ext, gp)['time_avg']
         if ref is None:
             ref = ta
-        if k == 8 and hasattr(genops.libssnode, 'ssn_debug_duo_stamps'):      # diagnostic build (-DSSN_DUO_STAMP=1)
+        if k == 8 and '--fine' in args and hasattr(genops.libssnode, 'ssn_debug_duo_stamps_fine'):   # -DSSN_DUO_STAMP=2
+            import ctypes
+            buf = (ctypes.c_ulonglong * 64)()
+            torch.cuda.synchronize()
+            genops.libssnode.ssn_debug_duo_stamps_fine(buf)
+            for w in range(8):
+                n = max(int(buf[8 * w + 7]), 1)
+                seg = [buf[8 * w + i] / n for i in range(6)]
+                print('  draw %d wave %d: chain %5.0f early %5.0f barrier %5.0f | serial %5.0f publish %5.0f barrier %5.0f | step %6.0f ticks (%d steps)'
+                      % (w // 4, w % 4, *seg, buf[8 * w + 6] / n, n))
+            print('  (kernel %.3f ms for %d steps: compare with the ticks per step to calibrate the counter)' % (ms, T))
+        elif k == 8 and hasattr(genops.libssnode, 'ssn_debug_duo_stamps'):      # diagnostic build (-DSSN_DUO_STAMP=1)
             import ctypes
             buf = (ctypes.c_ulonglong * 16)()
             torch.cuda.synchronize()
