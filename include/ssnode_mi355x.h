@@ -439,6 +439,16 @@ int ssn_interpolate_f32(const float *eps, const float *xd, const float *xg, floa
  * ranks of a data-parallel job each fill their own rows of ONE global stream.  `out` is a device pointer. */
 int ssn_philox_uniform_f32(unsigned long long seed, unsigned long long offset, float *out, unsigned long long n, void *stream);
 int ssn_philox_uniform_f64(unsigned long long seed, unsigned long long offset, double *out, unsigned long long n, void *stream);
+/*
+ * ssn_philox_uniform_* followed by ssn_build_w_* in one launch: W[b] = make_W_with_x(z[b]; J, D, S) with z = the B*M*M
+ * stream elements from `offset` on (bit for bit the numbers ssn_philox_uniform_* writes).  z: device [B][M][M] to keep the
+ * draw (the generator update's chain rule reads it), or NULL -- then the noise never touches memory.  M = 2N must be a
+ * multiple of 4 and W (and z) 16-byte aligned; otherwise invalid-argument, and the two calls above are the path.
+ */
+int ssn_build_w_philox_f32(unsigned long long seed, unsigned long long offset, const float *J, const float *D, const float *S,
+                           float *W, float *z, int B, int N, void *stream);
+int ssn_build_w_philox_f64(unsigned long long seed, unsigned long long offset, const double *J, const double *D, const double *S,
+                           double *W, double *z, int B, int N, void *stream);
 /* The heterogeneous-input SSN's noise from the same stream, in one launch (networks/ssn.py:679-720): zin[i] = +1 / -1
  * (u < 0.5; bernoulli != 0) or 2 u - 1, and amp[i] = 1 + v[i % M] * zin[i] (v: device [M], the input variability per
  * neuron); zin, amp: device [n]. */

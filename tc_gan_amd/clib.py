@@ -137,6 +137,11 @@ for _name in ('ssn_lu_solve_f32', 'ssn_lu_solve_f64'):
 for _name in ('ssn_weight_grad_f32', 'ssn_weight_grad_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_int, c_void_p]
     getattr(libssnode, _name).restype = c_int
+libssnode.ssn_build_w_philox_f32.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, POINTER(c_float), POINTER(c_float),
+                                             POINTER(c_float), c_void_p, c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_build_w_philox_f64.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, POINTER(c_double), POINTER(c_double),
+                                             POINTER(c_double), c_void_p, c_void_p, c_int, c_int, c_void_p]
+libssnode.ssn_build_w_philox_f32.restype = libssnode.ssn_build_w_philox_f64.restype = c_int
 libssnode.ssn_weight_grad_scaled_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_float, c_void_p]
 libssnode.ssn_weight_grad_scaled_f32.restype = c_int
 for _name in ('ssn_philox_uniform_f32', 'ssn_philox_uniform_f64'):
@@ -261,7 +266,7 @@ DECLARED_SYMBOLS = (
     'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
     'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
-    'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32',
+    'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
 )
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]

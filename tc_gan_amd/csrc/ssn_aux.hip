@@ -258,6 +258,69 @@ hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long off
     hipLaunchKernelGGL((philox_uniform_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, seed, offset, out, n);
     return hipGetLastError();
 }
+// W straight from the noise stream: element e of this call's z is stream element offset + e (the numbers
+// philox_uniform_kernel writes for the same seed and offset), W as build_w_kernel forms it; z itself is written only when
+// the caller keeps it (the generator step's chain rule needs it, the five critic-phase forwards of a GAN iteration do not):
+// 4 instead of 12 bytes of HBM traffic per element and one launch instead of two.  One thread per 4 consecutive columns.
+template <typename T>
+__global__ void __launch_bounds__(256) build_w_philox_kernel(unsigned long long seed, unsigned long long offset, T* __restrict__ W,
+                                                             T* __restrict__ zout, JDS<T> p, int N, long total_vec) {
+    const int M = 2 * N;
+    const T inv_nm1 = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
+    const unsigned mis = (unsigned)(offset & 3ull);           // (uniform) the 4 elements straddle two Philox blocks when != 0
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total_vec; v += (long)gridDim.x * blockDim.x) {
+        const long e0 = v * 4;
+        const unsigned long long g0 = offset + (unsigned long long)e0, blk = g0 >> 2;
+        unsigned w[8];
+        philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
+        if (mis) philox4x32_10((unsigned)(blk + 1), (unsigned)((blk + 1) >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w + 4);
+        const int col0 = (int)(e0 % M);
+        const int row = (int)((e0 / M) % M);
+        const int pp = row >= N, i = row - pp * N;
+        T zin[4], wout[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned bits = mis == 0 ? w[t] : (mis == 1 ? w[t + 1] : (mis == 2 ? w[t + 2] : w[t + 3]));
+            zin[t] = (T)((float)(bits >> 8) * (1.0f / 16777216.0f));
+            const int col = col0 + t;
+            const int qq = col >= N, j = col - qq * N;
+            const int pq = pp * 2 + qq;
+            const T dx = (T)(i - j) * inv_nm1;
+            const T g = exp(-(dx * dx) * p.inv2s2[pq]);
+            const T sgn = qq ? (T)-1 : (T)1;
+            wout[t] = g * (sgn * p.J[pq] + sgn * p.D[pq] * zin[t]);
+        }
+        using V4 = T __attribute__((ext_vector_type(4)));
+        V4 q; q.x = wout[0]; q.y = wout[1]; q.z = wout[2]; q.w = wout[3];
+        *reinterpret_cast<V4*>(W + e0) = q;
+        if (zout) {
+            V4 zq; zq.x = zin[0]; zq.y = zin[1]; zq.z = zin[2]; zq.w = zin[3];
+            *reinterpret_cast<V4*>(zout + e0) = zq;
+        }
+    }
+}
+// M % 4 == 0 and 16-byte aligned outputs (the caller checks; other shapes take the two-kernel path)
+template <typename T>
+hipError_t launch_build_w_philox(unsigned long long seed, unsigned long long offset, const T* jds12, T* W, T* zout, int B, int N,
+                                 hipStream_t st) {
+    JDS<T> p;
+    for (int q = 0; q < 4; ++q) {
+        p.J[q] = jds12[q];
+        p.D[q] = jds12[4 + q];
+        p.inv2s2[q] = (T)1 / ((T)2 * jds12[8 + q] * jds12[8 + q]);
+    }
+    const int M = 2 * N;
+    const long total = (long)B * M * M;
+    if (total == 0) return hipSuccess;
+    if (M % 4 != 0 || (((uintptr_t)W | (uintptr_t)zout) % (4 * sizeof(T))) != 0) return hipErrorInvalidValue;
+    const long nvec = total / 4;
+    const int blocks = (int)((nvec + 255) / 256 < 256 * 16 ? (nvec + 255) / 256 : 256 * 16);
+    hipLaunchKernelGGL((build_w_philox_kernel<T>), dim3(blocks), dim3(256), 0, st, seed, offset, W, zout, p, N, nvec);
+    return hipGetLastError();
+}
+template hipError_t launch_build_w_philox<float>(unsigned long long, unsigned long long, const float*, float*, float*, int, int, hipStream_t);
+template hipError_t launch_build_w_philox<double>(unsigned long long, unsigned long long, const double*, double*, double*, int, int, hipStream_t);
+
 // The heterogeneous-input SSN's per-neuron input variability in one launch (networks/ssn.py:679-720): element i of the
 // draw gets z = +1 / -1 (u < 0.5, `dist_in = 'bernoulli'`) or 2 u - 1 ('uniform') from the same stream element u as
 // philox_uniform_kernel would give it, and amp = 1 + v[i % M] * z (v = the population's input variability per neuron).

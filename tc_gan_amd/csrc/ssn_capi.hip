@@ -929,6 +929,20 @@ int ssn_build_w_f64(const double* z, const double* J, const double* D, const dou
     SSN_TRY(ssn::launch_build_w<double>(z, jds, W, B, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_build_w_philox_f32(unsigned long long seed, unsigned long long offset, const float* J, const float* D, const float* S,
+                           float* W, float* z, int B, int N, void* stream) {
+    float jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_build_w_philox<float>(seed, offset, jds, W, z, B, N, (hipStream_t)stream));
+    return 0;
+}
+int ssn_build_w_philox_f64(unsigned long long seed, unsigned long long offset, const double* J, const double* D, const double* S,
+                           double* W, double* z, int B, int N, void* stream) {
+    double jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    SSN_TRY(ssn::launch_build_w_philox<double>(seed, offset, jds, W, z, B, N, (hipStream_t)stream));
+    return 0;
+}
 int ssn_stimulus_f32(const float* bw, const float* con, float smoothness, float* ext, int B, int NB, int N, void* stream) {
     SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, nullptr, ext, B, NB, N, (hipStream_t)stream));
     return 0;

@@ -173,6 +173,7 @@ template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st);
 template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st);
 template <typename T> hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long offset, T* out, unsigned long long n, hipStream_t st);
+template <typename T> hipError_t launch_build_w_philox(unsigned long long seed, unsigned long long offset, const T* jds12, T* W, T* zout, int B, int N, hipStream_t st);
 template <typename T> hipError_t launch_philox_amp(unsigned long long seed, unsigned long long offset, const T* v, T* zin, T* amp, unsigned long long n, int M, int bernoulli, hipStream_t st);
 template <typename T> hipError_t launch_probe_scatter(const T* g, const long* ids, const long* probes, T* g_ta, int n, int B, int NB, int M, hipStream_t st);
 long segment_sqnorms_ws_doubles(int n);

@@ -62,6 +62,36 @@ def make_flat_param_names(named_params):
     return tuple(names)
 
 
+class PhiloxDraw(object):
+    """A slice of a `DeviceNoise` stream that has been reserved but not generated."""
+
+    def __init__(self, seed, offset, shape, tdtype):
+        self.seed, self.offset, self.shape, self.tdtype = int(seed), int(offset), tuple(shape), tdtype
+
+    def materialize(self):
+        out = torch.empty(self.shape, device='cuda', dtype=self.tdtype)
+        fn = clib.libssnode.ssn_philox_uniform_f32 if self.tdtype == torch.float32 else clib.libssnode.ssn_philox_uniform_f64
+        clib.check(fn(self.seed, self.offset, out.data_ptr(), out.numel(), clib.stream_ptr()), 'ssn_philox_uniform')
+        return out
+
+    def weights(self, N, J, D, S, keep_z):
+        """(z or None, W): `make_W_with_x` of the draw in one launch; z is written only when `keep_z`."""
+        import ctypes
+        B, M, M2 = self.shape
+        assert M == M2 == 2 * N
+        if M % 4:
+            z = self.materialize()
+            return z, generate_weight_batch(N, J, D, S, z, dtype={torch.float32: 'float32', torch.float64: 'float64'}[self.tdtype])
+        W = torch.empty(self.shape, device='cuda', dtype=self.tdtype)
+        z = torch.empty_like(W) if keep_z else None
+        ct, fn = ((ctypes.c_float, clib.libssnode.ssn_build_w_philox_f32) if self.tdtype == torch.float32
+                  else (ctypes.c_double, clib.libssnode.ssn_build_w_philox_f64))
+        arrs = [(ct * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (J, D, S)]
+        clib.check(fn(self.seed, self.offset, arrs[0], arrs[1], arrs[2], W.data_ptr(), z.data_ptr() if keep_z else None,
+                      int(B), int(N), clib.stream_ptr()), 'ssn_build_w_philox')
+        return z, W
+
+
 class DeviceNoise(object):
     """Uniform [0, 1) noise drawn on the device from ONE counter-based stream (Philox4x32-10, `ssn_philox_uniform_*`).
 
@@ -81,6 +111,13 @@ class DeviceNoise(object):
         offset = self.position + self.rank * n
         self.position += self.world * n
         return offset
+
+    def lazy_uniform(self, local_shape, tdtype):
+        """The next `uniform` draw of this shape, NOT generated: its place in the stream (`PhiloxDraw`).  The consumer either
+        materialises it or hands (seed, offset) to a kernel that generates the numbers where it uses them
+        (`ssn_build_w_philox_*`: W from the draw without the draw ever being stored)."""
+        n = int(np.prod(local_shape))
+        return PhiloxDraw(self.seed, self.take(n), tuple(local_shape), tdtype)
 
     def uniform(self, local_shape, tdtype):
         out = torch.empty(tuple(local_shape), device='cuda', dtype=tdtype)
@@ -228,7 +265,8 @@ class TuningCurveGenerator(object):
         num_models = np.shape(stimulator_bandwidths)[0]
         M = self.num_neurons
         if self._zgen is not None:
-            noise = dict(model_zs=self._zgen.uniform((num_models, M, M), self.tdtype))
+            # (reserved, not generated: _device_inputs forms W straight from the stream -- `PhiloxDraw.weights`)
+            noise = dict(model_zs=self._zgen.lazy_uniform((num_models, M, M), self.tdtype))
             if self.heteroin:
                 vs = self._input_variability()
                 zin, amp = self._zgen.signs_and_amp((num_models, M), self.tdtype, vs, self.dist_in == 'bernoulli')
@@ -277,6 +315,9 @@ class TuningCurveGenerator(object):
         # the un-amplified stimulus is only needed by the V gradient of a BPTT step
         self._ext_base = (stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
                           if self.heteroin and save else None)
+        if isinstance(model_zs, PhiloxDraw):
+            z, W = model_zs.weights(self.num_sites, self.J, self.D, self.S, keep_z=save)
+            return ext, z, W
         if torch.is_tensor(model_zs):
             z = model_zs.to('cuda', self.tdtype).contiguous()
         else:
