@@ -311,6 +311,22 @@ int ssn_critic_input_grad(const float *params, const int *dims, int nlayers, con
                           int batch, int hide_cell_type, float scale, float *gx, float *stats,
                           float *workspace, int precision, void *stream);
 
+/* The same three passes with the hidden nonlinearity x > 0 ? x : leak * x, 0 <= leak <= 1: lasagne's `rectify` (0),
+ * `leaky_rectify` (0.01), `very_leaky_rectify` (1/3), `linear` / `identity` (1) -- the piecewise-linear choices of
+ * simple_discriminator.py:139-152, for which the input gradient stays a linear chain with fixed slopes and the WGAN-GP double
+ * backward keeps its form.  Plain (not layer-normalised) layers, layer-by-layer path. */
+int ssn_critic_forward_leaky(const float *params, const int *dims, int nlayers, const float *x, const float *cond,
+                             int batch, int hide_cell_type, float leak, float *out, float *workspace, int precision,
+                             void *stream);
+int ssn_critic_loss_grad_leaky(const float *params, const int *dims, int nlayers,
+                               const float *xg, const float *cg, const float *xd, const float *cd,
+                               const float *xp, const float *cp, int ng, int nd, int np, float lmd,
+                               int hide_cell_type, float leak, float *grads, float *stats, float *dvals,
+                               float *workspace, int precision, void *stream);
+int ssn_critic_input_grad_leaky(const float *params, const int *dims, int nlayers, const float *x, const float *cond,
+                                int batch, int hide_cell_type, float leak, float scale, float *gx, float *stats,
+                                float *workspace, int precision, void *stream);
+
 /* The same three passes for a critic whose hidden layer l is layer-normalised when layer_norm[l] != 0
  * (simple_discriminator.py:51-75: Dense(no bias) -> LayerNorm (eps 1e-4, no parameters) -> Bias -> ReLU;
  * same [W_l, b_l] parameter layout).  layer_norm: HOST int[L] or NULL (all plain).  The WGAN-GP double

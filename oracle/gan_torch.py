@@ -134,7 +134,10 @@ def critic_forward(params, x, cond, normalization='none', nonlinearity='rectify'
     h = torch.cat([x, c], dim=1)
     nl = len(params) // 2
     norms = normalization if isinstance(normalization, (list, tuple)) else [normalization] * nl
-    act = {'rectify': torch.relu, 'tanh': torch.tanh, 'linear': lambda t: t}[nonlinearity]
+    # (lasagne.nonlinearities: leaky_rectify = LeakyRectify(0.01), very_leaky_rectify = LeakyRectify(1 / 3))
+    act = {'rectify': torch.relu, 'tanh': torch.tanh, 'linear': lambda t: t, 'identity': lambda t: t,
+           'leaky_rectify': lambda t: torch.nn.functional.leaky_relu(t, 0.01),
+           'very_leaky_rectify': lambda t: torch.nn.functional.leaky_relu(t, 1.0 / 3.0)}[nonlinearity]
     for l in range(nl):
         Wl, bl = params[2 * l], params[2 * l + 1]
         pre = h @ Wl

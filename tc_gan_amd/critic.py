@@ -21,6 +21,10 @@ def _stream():
     return clib.stream_ptr()
 
 
+# lasagne.nonlinearities names -> slope below zero (rectify, LeakyRectify(0.01), LeakyRectify(1/3), identity)
+LEAK = {'rectify': 0.0, 'leaky_rectify': 0.01, 'very_leaky_rectify': 1.0 / 3.0, 'linear': 1.0, 'identity': 1.0}
+
+
 class Critic(object):
     """MLP critic: input = [tuning curve (nx), contrast, |norm_probe|, cell_type]."""
 
@@ -30,8 +34,18 @@ class Critic(object):
         if len(norms) != len(layers) or any(n not in ('none', 'layer') for n in norms):
             raise ValueError('normalization must be none/layer (or one per layer): {!r}'.format(normalization))
         self.normalization = norms
-        if nonlinearity != 'rectify':
-            raise NotImplementedError("only nonlinearity='rectify' is implemented on the GPU path")
+        # hidden nonlinearity (simple_discriminator.py:139-152 takes any name of lasagne.nonlinearities): the piecewise-linear
+        # ones are x > 0 ? x : leak * x and keep the hand-derived double backward of the gradient penalty (fixed slopes
+        # instead of fixed masks); a smooth one would add second-derivative terms to every layer of that chain.
+        if nonlinearity not in LEAK:
+            raise NotImplementedError('critic nonlinearity {!r}: the GPU path has the piecewise-linear ones {}'.format(
+                nonlinearity, sorted(LEAK)))
+        self.nonlinearity = nonlinearity
+        self.leak = LEAK[nonlinearity]
+        if self.leak and 'layer' in norms:
+            # (with a non-rectify nonlinearity the reference's layer-normalised layer gains a learnable ScaleLayer,
+            # simple_discriminator.py:57-75: another parameter set, not built)
+            raise NotImplementedError('layer normalization with nonlinearity {!r} (needs the ScaleLayer)'.format(nonlinearity))
         clib.require_gpu()
         self.nx = int(nx)
         self.layers = [int(w) for w in layers]
@@ -152,6 +166,11 @@ class Critic(object):
                 self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
                 self.hide_cell_type, out.data_ptr(), ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward_norm')
             return out
+        if self.leak:
+            clib.check(libssnode.ssn_critic_forward_leaky(
+                self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch, self.hide_cell_type,
+                self.leak, out.data_ptr(), ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward_leaky')
+            return out
         clib.check(libssnode.ssn_critic_forward(self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(),
                                                 cond.data_ptr(), batch, self.hide_cell_type, out.data_ptr(),
                                                 ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward')
@@ -169,6 +188,13 @@ class Critic(object):
                 xd.data_ptr(), cd.data_ptr(), xp.data_ptr(), cp.data_ptr(), ng, nd, npn, float(lmd), self.hide_cell_type,
                 self.grads.data_ptr(), self.stats.data_ptr(), self._dvals.data_ptr(), ws.data_ptr(), self.precision,
                 _stream()), 'ssn_critic_loss_grad_norm')
+            return self.stats
+        if self.leak:
+            clib.check(libssnode.ssn_critic_loss_grad_leaky(
+                self.params.data_ptr(), self._dims_c, self.nlayers, xg.data_ptr(), cg.data_ptr(), xd.data_ptr(),
+                cd.data_ptr(), xp.data_ptr(), cp.data_ptr(), ng, nd, npn, float(lmd), self.hide_cell_type, self.leak,
+                self.grads.data_ptr(), self.stats.data_ptr(), self._dvals.data_ptr(), ws.data_ptr(), self.precision,
+                _stream()), 'ssn_critic_loss_grad_leaky')
             return self.stats
         clib.check(libssnode.ssn_critic_loss_grad(
             self.params.data_ptr(), self._dims_c, self.nlayers, xg.data_ptr(), cg.data_ptr(), xd.data_ptr(),
@@ -197,6 +223,12 @@ class Critic(object):
                 self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
                 self.hide_cell_type, float(scale), gx.data_ptr(), self.stats.data_ptr(), ws.data_ptr(), self.precision,
                 _stream()), 'ssn_critic_input_grad_norm')
+            return gx, self.stats[0]
+        if self.leak:
+            clib.check(libssnode.ssn_critic_input_grad_leaky(
+                self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
+                self.hide_cell_type, self.leak, float(scale), gx.data_ptr(), self.stats.data_ptr(), ws.data_ptr(),
+                self.precision, _stream()), 'ssn_critic_input_grad_leaky')
             return gx, self.stats[0]
         clib.check(libssnode.ssn_critic_input_grad(
             self.params.data_ptr(), self._dims_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,

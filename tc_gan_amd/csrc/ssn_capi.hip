@@ -621,6 +621,31 @@ size_t ssn_critic_norm_workspace_floats(const int* dims, int nlayers, int batch_
     const size_t base = ssn::critic_norm_workspace_floats(dims, nlayers, batch_gd, batch_p);
     return ssn::critic_fused_supported(dims, nlayers) ? max_sz(base, ssn::critic_fused_workspace_floats(dims, nlayers, batch_gd, batch_p)) : base;
 }
+// The same three calls for a hidden nonlinearity x > 0 ? x : leak * x (lasagne's leaky_rectify = 0.01, very_leaky_rectify = 1/3,
+// linear = 1; plain layers only).  Always the layer-by-layer path.
+int ssn_critic_forward_leaky(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                             int hide_cell_type, float leak, float* out, float* workspace, int precision, void* stream) {
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_forward(params, dims, nlayers, x, cond, batch, hide_cell_type, out, workspace, precision == 0,
+                                (hipStream_t)stream, leak));
+    return 0;
+}
+int ssn_critic_loss_grad_leaky(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
+                               const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
+                               float lmd, int hide_cell_type, float leak, float* grads, float* stats, float* dvals,
+                               float* workspace, int precision, void* stream) {
+    SSN_TRY(ssn::critic_loss_grad(params, dims, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type, grads,
+                                  stats, dvals, workspace, precision == 0, (hipStream_t)stream, leak));
+    return 0;
+}
+int ssn_critic_input_grad_leaky(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
+                                int hide_cell_type, float leak, float scale, float* gx, float* stats, float* workspace,
+                                int precision, void* stream) {
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_input_grad(params, dims, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats, workspace,
+                                   precision == 0, (hipStream_t)stream, leak));
+    return 0;
+}
 int ssn_critic_forward_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* x,
                             const float* cond, int batch, int hide_cell_type, float* out, float* workspace, int precision,
                             void* stream) {

@@ -48,7 +48,8 @@ struct GemmArgs {
     int M, N, K;
     float alpha, beta;                 // C = alpha*acc + beta*C   (PLAIN only)
     const float* bias;                 // [N]          (BIAS_RELU)
-    const float* mask; long ldm;       // [M][ldm] > 0 (MASK): C = acc * (mask > 0)
+    const float* mask; long ldm;       // [M][ldm] > 0 (MASK): C = acc * (mask > 0 ? 1 : leak)
+    float leak;                        // slope of the hidden nonlinearity below zero: 0 rectify, 0.01 / 1/3 leaky, 1 linear
     int epilogue;
     int kchunk;                        // K range per blockIdx.z (split-K; PLAIN with beta == 1 only)
     float* partial;                    // split-K: slice z writes its tile sums to partial[z][m*N + n] (no atomics)
@@ -63,8 +64,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& a
         if (m < g.M && n < g.N) {
             float v = acc[reg];
             float* c = g.C + m * g.ldc + n;
-            if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : 0.f; }
-            else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : 0.f; }
+            if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : g.leak * v; }
+            else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : g.leak * v; }
             else if (gridDim.z > 1) { g.partial[((long)blockIdx.z * g.M + m) * g.N + n] = v; continue; }   // split-K partial
             else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
             *c = v;
@@ -392,13 +393,14 @@ __global__ void __launch_bounds__(256) critic_input_kernel(const float* __restri
     }
 }
 
-// v_L[b][k] = (h_L[b][k] > 0) * w_out[k] * up[b]   (up = per-sample upstream of D; nullptr -> 1)
+// v_L[b][k] = (h_L[b][k] > 0 ? 1 : leak) * w_out[k] * up[b]   (up = per-sample upstream of D; nullptr -> 1)
 __global__ void __launch_bounds__(256) critic_outgrad_kernel(const float* __restrict__ hL, const float* __restrict__ wout,
                                                              const float* __restrict__ up, float* __restrict__ vL,
-                                                             int batch, int nL) {
+                                                             int batch, int nL, float leak) {
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)batch * nL; e += gridDim.x * 256L) {
         const int b = (int)(e / nL), k = (int)(e % nL);
-        vL[e] = (hL[e] > 0.f) ? wout[k] * (up ? up[b] : 1.f) : 0.f;
+        const float v = wout[k] * (up ? up[b] : 1.f);
+        vL[e] = (hL[e] > 0.f) ? v : leak * v;
     }
 }
 
@@ -512,11 +514,13 @@ struct CriticNet {
     const float* b[9];
     const float* wout;     // [n_L]
     long nparams;
+    float leak;            // hidden nonlinearity: x > 0 ? x : leak * x (0 = rectify; the sign of h_l is the sign of its pre-activation)
 };
 
-static bool parse_net(const float* params, const int* dims, int nlayers, CriticNet& net) {
-    if (nlayers < 0 || nlayers > 8) return false;
+static bool parse_net(const float* params, const int* dims, int nlayers, CriticNet& net, float leak = 0.f) {
+    if (nlayers < 0 || nlayers > 8 || !(leak >= 0.f) || leak > 1.f) return false;
     net.nlayers = nlayers;
+    net.leak = leak;
     long off = 0;
     for (int l = 0; l <= nlayers; ++l) net.dims[l] = dims[l];
     for (int l = 0; l < nlayers; ++l) {
@@ -539,7 +543,7 @@ static hipError_t critic_forward_pass(const CriticNet& net, float* const* h, flo
         g.B = net.W[l]; g.sbk = net.dims[l + 1]; g.sbn = 1;
         g.C = h[l + 1]; g.ldc = net.dims[l + 1];
         g.M = batch; g.N = net.dims[l + 1]; g.K = net.dims[l];
-        g.bias = net.b[l]; g.epilogue = EPI_BIAS_RELU;
+        g.bias = net.b[l]; g.epilogue = EPI_BIAS_RELU; g.leak = net.leak;
         if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
     }
     GemmArgs g{};
@@ -580,7 +584,7 @@ static hipError_t critic_backward_chain(const CriticNet& net, float* const* h, f
             g.A = v[l + 1]; g.sam = nout; g.sak = 1;
             g.B = net.W[l]; g.sbk = 1; g.sbn = nout;        // op(B)(k, i) = W[i][k]
             g.C = v[l]; g.ldc = nin; g.M = batch; g.N = nin; g.K = nout;
-            if (l > 0) { g.epilogue = EPI_MASK; g.mask = h[l]; g.ldm = nin; }
+            if (l > 0) { g.epilogue = EPI_MASK; g.mask = h[l]; g.ldm = nin; g.leak = net.leak; }
             else { g.alpha = 1.f; g.beta = 0.f; g.epilogue = EPI_PLAIN; }
             if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
         }
@@ -598,9 +602,9 @@ size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int b
 
 // D values for a batch (inference / accuracy): out[batch]
 hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
-                          int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st) {
+                          int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st, float leak) {
     CriticNet net;
-    if (!parse_net(params, dims, nlayers, net)) return hipErrorInvalidValue;
+    if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
     const int nx = dims[0] - 3;
     float* h[10];
     float* p = ws;
@@ -613,9 +617,9 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
 hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
                             const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
                             float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* ws, bool bf16,
-                            hipStream_t st) {
+                            hipStream_t st, float leak) {
     CriticNet net;
-    if (!parse_net(params, dims, nlayers, net)) return hipErrorInvalidValue;
+    if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
     hipError_t e;
     const int L = nlayers, nx = dims[0] - 3;
     const int bgd = ng + nd;
@@ -648,14 +652,14 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
         g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
         if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)bgd * dims[L])), dim3(256), 0, st, h[L], net.wout, up, v[L], bgd, dims[L]);
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)bgd * dims[L])), dim3(256), 0, st, h[L], net.wout, up, v[L], bgd, dims[L], net.leak);
     if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st)) != hipSuccess) return e;
 
     // ---------------- (2) gradient penalty on xp ------------------------------------------------
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type);
     if ((e = critic_forward_pass(net, hp, dp, np, bf16, st)) != hipSuccess) return e;
     // input gradient g = dD/dh0 per sample: v_L = m_L * w_out, chain down to vp[0]
-    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, st, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L]);
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, st, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L], net.leak);
     if ((e = critic_backward_chain(net, hp, vp, np, nullptr, true, bf16, st)) != hipSuccess) return e;
     // penalty and its gradient w.r.t. g: ep[0] = ghat (np x n0)
     hipLaunchKernelGGL(gp_head_kernel, dim3(1), dim3(256), 0, st, vp[0], ep[0], stats + 2, np, dims[0], nx);
@@ -677,7 +681,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
             g.A = ep[l]; g.sam = nin; g.sak = 1;
             g.B = net.W[l]; g.sbk = nout; g.sbn = 1;
             g.C = ep[l + 1]; g.ldc = nout; g.M = np; g.N = nout; g.K = nin;
-            g.epilogue = EPI_MASK; g.mask = hp[l + 1]; g.ldm = nout;
+            g.epilogue = EPI_MASK; g.mask = hp[l + 1]; g.ldm = nout; g.leak = net.leak;
             if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
         }
         off += (long)nin * nout + nout;
@@ -693,9 +697,10 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
 // Gradient of  -mean D(x)  w.r.t. the tuning-curve part of the input (generator side, wgan.py:236):
 // gx[batch][nx];  also returns mean D in stats[0].
 hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
-                             int hide_cell_type, float scale, float* gx, float* stats, float* ws, bool bf16, hipStream_t st) {
+                             int hide_cell_type, float scale, float* gx, float* stats, float* ws, bool bf16, hipStream_t st,
+                             float leak) {
     CriticNet net;
-    if (!parse_net(params, dims, nlayers, net)) return hipErrorInvalidValue;
+    if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
     hipError_t e;
     const int L = nlayers, nx = dims[0] - 3;
     float *h[10], *v[10];
@@ -706,7 +711,7 @@ hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, 
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type);
     if ((e = critic_forward_pass(net, h, dv, batch, bf16, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dv, stats, batch, 0);
-    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)batch * dims[L])), dim3(256), 0, st, h[L], net.wout, (const float*)nullptr, v[L], batch, dims[L]);
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)batch * dims[L])), dim3(256), 0, st, h[L], net.wout, (const float*)nullptr, v[L], batch, dims[L], net.leak);
     if ((e = critic_backward_chain(net, h, v, batch, nullptr, true, bf16, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(gather_scale_kernel, dim3(blocks_for((long)batch * nx)), dim3(256), 0, st, v[0], gx, batch, dims[0], nx, scale);
     return hipGetLastError();

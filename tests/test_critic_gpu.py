@@ -44,6 +44,42 @@ def test_critic_loss_and_gradient_fp32(batch, nx, layers):
     assert abs(c.accuracy(xg, cond, xd, cond) - (stats[0] - stats[1])) < 1e-5
 
 
+@pytest.mark.parametrize('nonlinearity', ['leaky_rectify', 'very_leaky_rectify', 'linear'])
+@pytest.mark.parametrize('batch,nx,layers', [(7, 4, [9]), (130, 8, [128, 128, 128]), (256, 8, [512, 512, 512])])
+def test_piecewise_linear_nonlinearities(nonlinearity, batch, nx, layers):
+    """simple_discriminator.py:139-152 takes any `lasagne.nonlinearities` name for the hidden layers (CLI
+    `--disc-nonlinearity`); the piecewise-linear ones (LeakyRectify(0.01), LeakyRectify(1/3), identity) keep the input gradient a
+    linear chain with fixed slopes, so loss, WGAN-GP double backward, critic values and the generator-side input gradient run
+    on the same kernels with a slope.  Against torch autograd on the fp64 restatement, like the rectify cases."""
+    from tc_gan_amd.critic import Critic
+    rs = np.random.RandomState(batch + len(nonlinearity))
+    c = Critic(nx, layers, seed=batch, precision='fp32', nonlinearity=nonlinearity)
+    params_o = [og.t64(p) for p in c.get_param_values()]
+    xg, xd = rs.rand(batch, nx) * 5, rs.rand(batch, nx) * 5
+    eps = rs.rand(batch, 1)
+    xp = eps * xd + (1 - eps) * xg
+    cond = np.stack([np.full(batch, 20.), rs.rand(batch) * 2 - 1, rs.randint(0, 2, batch)], axis=1)
+    ps = [p.clone().requires_grad_(True) for p in params_o]
+    tg, td, tp, tc = (og.t64(a) for a in (xg, xd, xp, cond))
+    loss_o = og.critic_loss(ps, tg, td, tp, tc, tc, tc, 10.0, nonlinearity=nonlinearity)
+    flat_o = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(loss_o, ps)])
+    stats = c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(loss_o), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(c.grads.cpu().numpy(), flat_o, rtol=1e-3, atol=2e-5 * np.abs(flat_o).max())
+    np.testing.assert_allclose(c.forward(xg, cond).cpu().numpy(),
+                               og.critic_forward(params_o, tg, tc, nonlinearity=nonlinearity)[:, 0].numpy(), rtol=1e-4, atol=1e-5)
+    x = tg.clone().requires_grad_(True)
+    want = torch.autograd.grad(-og.critic_forward(params_o, x, tc, nonlinearity=nonlinearity).mean(), x)[0].numpy()
+    gx, _ = c.input_grad(xg, cond, -1.0 / batch)
+    np.testing.assert_allclose(gx.cpu().numpy(), want, rtol=1e-3, atol=2e-5 * np.abs(want).max())
+    # and what stays out: smooth nonlinearities, LayerNorm with a non-rectify nonlinearity (the reference adds a ScaleLayer)
+    with pytest.raises(NotImplementedError):
+        Critic(nx, layers, nonlinearity='tanh')
+    if layers:
+        with pytest.raises(NotImplementedError):
+            Critic(nx, layers, nonlinearity=nonlinearity, normalization='layer')
+
+
 def test_critic_bf16_path_close_to_fp64():
     from tc_gan_amd.critic import Critic
     c, params_o, xg, xd, xp, cond = _setup(512, 8, [256, 256], seed=3)

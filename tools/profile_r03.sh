@@ -19,5 +19,6 @@ bash tools/pmc_run.sh r03_fwd tools/time_fwd.py 8 4 > $out/pmc_fwd.log 2>&1
 bash tools/pmc_run.sh r03_fwdsave tools/time_fwd.py 8 --save > $out/pmc_fwdsave.log 2>&1
 bash tools/pmc_run.sh r03_solve tools/time_solver.py 8 6 > $out/pmc_solve.log 2>&1
 bash tools/pmc_run.sh r03_adj tools/time_adj.py > $out/pmc_adj.log 2>&1
+bash tools/pmc_run.sh r03_gw tools/time_gw.py MFMA > $out/pmc_gw.log 2>&1
 bash tools/pmc_run.sh r03_c2 bench.py --steps 3 --warmup 1 --secondary-steps 0 --no-extras --no-cpu-baseline > $out/pmc_c2.log 2>&1
 ls $out
