@@ -458,8 +458,8 @@ int ssn_philox_uniform_f64(unsigned long long seed, unsigned long long offset, d
 /*
  * ssn_philox_uniform_* followed by ssn_build_w_* in one launch: W[b] = make_W_with_x(z[b]; J, D, S) with z = the B*M*M
  * stream elements from `offset` on (bit for bit the numbers ssn_philox_uniform_* writes).  z: device [B][M][M] to keep the
- * draw (the generator update's chain rule reads it), or NULL -- then the noise never touches memory.  M = 2N must be a
- * multiple of 4 and W (and z) 16-byte aligned; otherwise invalid-argument, and the two calls above are the path.
+ * draw (the generator update's chain rule reads it), or NULL -- then the noise never touches memory.  W (and z) must be
+ * 16-byte aligned; otherwise invalid-argument, and the two calls above are the path.
  */
 int ssn_build_w_philox_f32(unsigned long long seed, unsigned long long offset, const float *J, const float *D, const float *S,
                            float *W, float *z, int B, int N, void *stream);

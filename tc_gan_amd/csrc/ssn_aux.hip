@@ -274,20 +274,19 @@ __global__ void __launch_bounds__(256) build_w_philox_kernel(unsigned long long 
         unsigned w[8];
         philox4x32_10((unsigned)blk, (unsigned)(blk >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w);
         if (mis) philox4x32_10((unsigned)(blk + 1), (unsigned)((blk + 1) >> 32), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32), w + 4);
-        const int col0 = (int)(e0 % M);
-        const int row = (int)((e0 / M) % M);
-        const int pp = row >= N, i = row - pp * N;
-        T zin[4], wout[4];
+        int col = (int)(e0 % M), row = (int)((e0 / M) % M);       // (M even: 4 | M * M, so a group of 4 never leaves its draw,
+        T zin[4], wout[4];                                          //  but with M % 4 == 2 it may run over the end of a row)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const unsigned bits = mis == 0 ? w[t] : (mis == 1 ? w[t + 1] : (mis == 2 ? w[t + 2] : w[t + 3]));
             zin[t] = (T)((float)(bits >> 8) * (1.0f / 16777216.0f));
-            const int col = col0 + t;
+            const int pp = row >= N, i = row - pp * N;
             const int qq = col >= N, j = col - qq * N;
             const int pq = pp * 2 + qq;
             const T dx = (T)(i - j) * inv_nm1;
             const T g = exp(-(dx * dx) * p.inv2s2[pq]);
             const T sgn = qq ? (T)-1 : (T)1;
+            if (++col == M) { col = 0; if (++row == M) row = 0; }
             wout[t] = g * (sgn * p.J[pq] + sgn * p.D[pq] * zin[t]);
         }
         using V4 = T __attribute__((ext_vector_type(4)));
@@ -299,7 +298,7 @@ __global__ void __launch_bounds__(256) build_w_philox_kernel(unsigned long long 
         }
     }
 }
-// M % 4 == 0 and 16-byte aligned outputs (the caller checks; other shapes take the two-kernel path)
+// M even and 16-byte aligned outputs (the caller checks; other shapes take the two-kernel path)
 template <typename T>
 hipError_t launch_build_w_philox(unsigned long long seed, unsigned long long offset, const T* jds12, T* W, T* zout, int B, int N,
                                  hipStream_t st) {
@@ -312,7 +311,7 @@ hipError_t launch_build_w_philox(unsigned long long seed, unsigned long long off
     const int M = 2 * N;
     const long total = (long)B * M * M;
     if (total == 0) return hipSuccess;
-    if (M % 4 != 0 || (((uintptr_t)W | (uintptr_t)zout) % (4 * sizeof(T))) != 0) return hipErrorInvalidValue;
+    if ((((uintptr_t)W | (uintptr_t)zout) % (4 * sizeof(T))) != 0) return hipErrorInvalidValue;      // (M = 2N: 4 | M * M)
     const long nvec = total / 4;
     const int blocks = (int)((nvec + 255) / 256 < 256 * 16 ? (nvec + 255) / 256 : 256 * 16);
     hipLaunchKernelGGL((build_w_philox_kernel<T>), dim3(blocks), dim3(256), 0, st, seed, offset, W, zout, p, N, nvec);

@@ -79,9 +79,6 @@ class PhiloxDraw(object):
         import ctypes
         B, M, M2 = self.shape
         assert M == M2 == 2 * N
-        if M % 4:
-            z = self.materialize()
-            return z, generate_weight_batch(N, J, D, S, z, dtype={torch.float32: 'float32', torch.float64: 'float64'}[self.tdtype])
         W = torch.empty(self.shape, device='cuda', dtype=self.tdtype)
         z = torch.empty_like(W) if keep_z else None
         ct, fn = ((ctypes.c_float, clib.libssnode.ssn_build_w_philox_f32) if self.tdtype == torch.float32
