@@ -441,6 +441,13 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))            # before anything touches the GPU
 
+    # Exactly ONE line on stdout: libraries write there as well (RCCL prints a five-line version banner when its first
+    # communicator comes up), so the stream the caller reads is kept aside for the JSON line and file descriptor 1 points at
+    # stderr for the rest of the run.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from tc_gan_amd import clib
@@ -496,7 +503,7 @@ def main():
             # them too: C2 with the 8 bandwidths every real caller uses, C5, C1 through the drop-in symbols, the paper's shape.
             out['extras'] = {}
             keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
-                    'gen_kernel', 'forward_variant')
+                    'gen_kernel', 'forward_variant', 'last_gen_loss')
             for name, workload, steps, warmup, kw in (('c2nb8', 'c2nb8', 3, 1, {}), ('c5', 'c5', 5, 1, {}),
                                                       ('c1_dropin', 'c1', 1, 0, dict(via='dropin', cpu_sample=128)),
                                                       ('c3paper', 'c3paper', 20, 5, {})):
@@ -513,16 +520,49 @@ def main():
                     res = run_solver(sub, rank, world, local_rank)
                 out['extras'][name] = dict({k: res[k] for k in keep if k in res}, wall_s=time.perf_counter() - t_extra)
                 torch.cuda.empty_cache()
+            if not dist.is_initialized() and backend == 'nccl':
+                # RCCL on the one card there is: the paper-shape loop once more inside a ONE-rank nccl group, every collective
+                # of the N > 1 path (flat-buffer all-reduce per update, barriers, max-over-ranks timing) going through RCCL.
+                # Says nothing about xGMI; it shows that the communicator comes up and what a collective costs in stream order.
+                t_extra = time.perf_counter()
+                try:
+                    out['extras']['c3paper_rccl1'] = dict(run_single_rank_group(args, local_rank), wall_s=time.perf_counter() - t_extra)
+                except Exception as err:                      # (a rehearsal must not take the line down with it)
+                    out['extras']['c3paper_rccl1'] = {'error': repr(err)[:300], 'wall_s': time.perf_counter() - t_extra}
+                torch.cuda.empty_cache()
     # what actually ran: the process group's own size and backend (1 / none for a single process)
     out['world_size'] = dist.get_world_size() if dist.is_initialized() else 1
     out['dist_backend'] = dist.get_backend() if dist.is_initialized() else None
     assert out['n_gpus'] == args.gpus == out['world_size']
     if rank == 0:
-        print(json.dumps(out))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
+    os.close(json_fd)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_single_rank_group(args, local_rank):
+    """`--workload c3paper` for a few steps as the only rank of an `nccl` (= RCCL) process group (see BENCH_FORCE_DIST)."""
+    import socket
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+    os.environ['TCGAN_DIST_SINGLE_RANK'] = '1'
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        sub = argparse.Namespace(**dict(vars(args), workload='c3paper', steps=20, warmup=5, variant=-1, no_cpu_baseline=True))
+        res = run_c3(sub, 0, 1, local_rank, paper=True)
+        return {'ms_per_step': res['ms_per_step'], 'value': res['value'], 'unit': res['unit'], 'steps': 20, 'warmup': 5,
+                'phases': res.get('phases'), 'dist_backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                'last_gen_loss': res.get('last_gen_loss'),
+                'config': {'workload': 'C3 paper shape as the single rank of an RCCL group: one flat all-reduce per update '
+                                       '(mean over one rank = identity), barriers and timing reductions through RCCL'}}
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop('TCGAN_DIST_SINGLE_RANK', None)
 
 
 def run_solver(args, rank, world, local_rank):

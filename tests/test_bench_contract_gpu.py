@@ -41,7 +41,13 @@ def test_default_workload_line():
     assert sec['forward_variant'] == 8 and 'duo' in sec['roofline']['kernel']         # what the library picked, by its own word
     assert sec['fp32_mfma']['steps'] == sec['steps'] and sec['fp32_mfma']['warmup'] == sec['warmup']
     ex = d['extras']
-    assert set(ex) == {'c2nb8', 'c5', 'c1_dropin', 'c3paper'}
+    assert set(ex) == {'c2nb8', 'c5', 'c1_dropin', 'c3paper', 'c3paper_rccl1'}
+    rc = ex.pop('c3paper_rccl1')                  # the paper-shape loop as the single rank of an RCCL group
+    assert 'error' not in rc, rc
+    assert rc['dist_backend'] == 'nccl' and rc['world_size'] == 1 and rc['ms_per_step'] > 0
+    assert rc['phases']['collectives_per_iteration'] >= 2 and rc['phases']['allreduce_ms']['max'] > 0
+    assert rc['last_gen_loss'] == ex['c3paper']['last_gen_loss']            # mean over one rank = identity, bit for bit
+    assert d['dist_backend'] is None and d['world_size'] == 1              # (the line itself is a plain single process)
     for name, e in ex.items():
         assert e['value'] > 0 and e['ms_per_step'] > 0 and 'workload' in e['config'], name
         assert name == 'c1_dropin' or {'bound', 'achieved', 'peak', 'frac'} <= set(e['roofline']), name
@@ -91,9 +97,8 @@ def test_single_rank_group_runs_the_collectives_on_rccl():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'c3paper', '--steps', '3', '--warmup', '1']
     out = subprocess.run(cmd, check=True, env=env, capture_output=True, text=True, timeout=600).stdout.strip().splitlines()
-    lines = [l for l in out if l.startswith('{')]
-    assert len(lines) == 1, out
-    d = json.loads(lines[0])
+    assert len(out) == 1, out                 # RCCL's version banner goes to stderr, not into the stream the driver reads
+    d = json.loads(out[0])
     assert d['dist_backend'] == 'nccl' and d['world_size'] == 1 and d['n_gpus'] == 1
     ph = d['phases']
     assert ph['collectives_per_iteration'] >= 2 and ph['allreduce_ms']['max'] > 0
