@@ -44,6 +44,9 @@
                                 // chain starts with that tile (measured at C3, same box, three alternating runs: 3.14 ms against
                                 // 3.16 -- the first read behind the barrier is not what stretches a chain; off)
 #endif
+#ifndef SSN_DUO_EARLY_SOLVE
+#define SSN_DUO_EARLY_SOLVE 1   // solver: the candidate state of a wave's last row tile behind its own chain (0 = all in the serial phase)
+#endif
 #ifndef SSN_DUO_EARLY_BWD
 #define SSN_DUO_EARLY_BWD 1     // adjoint sweep: the last row tile of a step after the window behind the previous step's chain (0 = off)
 #endif
@@ -784,26 +787,44 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
         my_frozen = my_frozen || stop;
         frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
     };
-    auto serial = [&](int it) {
-        float uu[NE], ff[NE], dfn[NE];
-#pragma unroll
-        for (int tf = 0; tf < NTF; ++tf) {
-            mf4 sm = acc[tf];
-            if constexpr (WS::HEAD_SHARED) {
-                if (tf == 0) {
-                    const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
-                    sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
-                }
+    // u of the two values of row tile tf from the chain's sums (join of the two parts, scale, external input)
+    auto tile_u = [&](int tf, bool first, float& u0, float& u1) {
+        mf4 sm = acc[tf];
+        if constexpr (WS::HEAD_SHARED) {
+            if (tf == 0) {
+                const mf4 xp = *(LdsF4)(size_t)(xs + (unsigned)((WV - 1) * S::XS));
+                sm.x += xp.x; sm.y += xp.y; sm.z += xp.z; sm.w += xp.w;
             }
-            const float j0 = tf == 0 ? duo_join<true>(sm.x, sm.z, hi, sm.y, sm.w) : duo_join<false>(sm.x, sm.z, hi);
-            uu[2 * tf] = fmaf(j0, usc, ex[2 * tf]);
-            uu[2 * tf + 1] = fmaf(duo_join<false>(sm.y, sm.w, hi), usc, ex[2 * tf + 1]);
         }
-        duo_eval<false, NE>(io, uu, ff, dfn);
+        const float j0 = first ? duo_join<true>(sm.x, sm.z, hi, sm.y, sm.w) : duo_join<false>(sm.x, sm.z, hi);
+        u0 = fmaf(j0, usc, ex[2 * tf]);
+        u1 = fmaf(duo_join<false>(sm.y, sm.w, hi), usc, ex[2 * tf + 1]);
+    };
+    // One row tile early (as the forward, 3.13c): the wave that has ended its chain computes the candidate state of its LAST
+    // row tile right behind the chain, in the chain's phase -- join, f(u), Euler step: registers only; whether the step is
+    // applied, the stop flags, the previous state and the publication stay in the serial phase.  Same values bit for bit.
+    constexpr int TE = NTF - 1;
+    constexpr bool EARLY = SSN_DUO_EARLY_SOLVE == 2 ? NTF > 3 : (SSN_DUO_EARLY_SOLVE && NTF > 1);    // (2: the four-tile wave only)
+    constexpr int NS = EARLY ? NE - 2 : NE;                 // values the serial phase still finishes (row tiles 0 .. TE - 1)
+    float r1e[2] = {0.f, 0.f};
+    auto early = [&]() {
+        if constexpr (EARLY) {
+            float uu[2], ff[2], dfn[2] = {0.f, 0.f};
+            tile_u(TE, true, uu[0], uu[1]);
+            duo_eval<false, 2>(io, uu, ff, dfn);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) r1e[e] = rc[2 * TE + e] + (-rc[2 * TE + e] + ff[e]) * eps[2 * TE + e];
+        }
+    };
+    auto serial = [&](int it) {
+        float uu[NS], ff[NS], dfn[NS];
+#pragma unroll
+        for (int tf = 0; tf < NS / 2; ++tf) tile_u(tf, tf == 0, uu[2 * tf], uu[2 * tf + 1]);
+        duo_eval<false, NS>(io, uu, ff, dfn);
         float r1[NE], dmax = -1.f, rmax = -__builtin_inff();
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
-            r1[i] = rc[i] + (-rc[i] + ff[i]) * eps[i];                           // ssnode.c:64-67
+            r1[i] = i < NS ? rc[i] + (-rc[i] + ff[i % NS]) * eps[i] : r1e[(i - NS) & 1];          // ssnode.c:64-67
             dmax = fmaxf(dmax, rowok[i] ? fabsf(r1[i] - rc[i]) : -1.f);
             rmax = fmaxf(rmax, rowok[i] ? r1[i] : -__builtin_inff());
         }
@@ -832,7 +853,7 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
         if (chain_phase && p >= d) {
             if (!finished && it >= 1) verdict(it - 1, word);
             if (frozen == 0xffu || it >= max_iter) finished = true;
-            if (!finished) chain();
+            if (!finished) { chain(); early(); }
         } else if (p >= d) {
             if (!finished) serial(it);
             ++it;
