@@ -284,7 +284,9 @@ def run_c3(args, rank, world, local_rank, paper=False):
         'metric': 'GAN iters/sec', 'value': iters_per_s * world, 'unit': '%d-model GAN iterations/s' % models,
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (critic GEMMs %s%s)' % (args.disc_precision, '; generator W.r on fp16 matrix cores as an exact-product split of 23-bit operands' if variant in SPLIT_VARIANTS else ''),
+        'dtype': 'f32 (critic GEMMs %s%s)' % (args.disc_precision, ('; generator W.r on fp16 matrix cores as an exact-product split of 23-bit operands' +
+                                                                 ('; dL/dW on fp16 matrix cores, operands as two fp16 parts to 2^-24' if variant == 8 else ''))
+                                                                if variant in SPLIT_VARIANTS else ''),
         'data': 'synthetic',
         'config': {'workload': ('C3 paper shape (scripts/fig4/gan/run.json): 2N=202, 128 models x 8 bandwidths per GPU, '
                                 'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
