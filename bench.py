@@ -219,6 +219,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
             one_iter()
         gan.host_draw_seconds = 0.0
         gan.reducer.collective_ms()
+        calls0 = gan.reducer.calls
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
@@ -244,7 +245,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             phases = {'allreduce_ms': {'max': float(hi[0]), 'min': float(lo[0])},
                       'host_draw_ms': {'max': float(hi[1]), 'min': float(lo[1])},
-                      'collectives_per_iteration': gan.critic_iters + 1}
+                      'collectives_per_iteration': (gan.reducer.calls - calls0) / args.steps}
         assert np.isfinite(info.gen_loss)
         return gan, shape, bandwidths, elapsed, info, phases
 

@@ -183,6 +183,7 @@ class GradientAllReducer(object):
         # collective, summed on demand; off by default (two event records per update)
         self.timed = False
         self._events = []
+        self.calls = 0                         # collectives issued so far
 
     def collective_ms(self):
         """Device milliseconds spent in the all-reduces since the last call (synchronises)."""
@@ -193,28 +194,40 @@ class GradientAllReducer(object):
         self._events = []
         return total
 
+    def _sum(self, t):
+        """One all-reduce (sum) of `t`, in stream order; timed between two events when `self.timed`."""
+        self.calls += 1
+        if self.timed and t.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            ev[1].record()
+            self._events.append(ev)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        if self.world > 1:
+            t /= self.world
+
     def mean_(self, *tensors):
-        """In-place mean over ranks of several tensors through ONE collective (one persistent flat fp32 buffer per
-        total size: no allocation per update)."""
+        """In-place mean over ranks of several tensors through ONE collective.  A single contiguous fp32 tensor is reduced
+        where it is; several go through a persistent flat fp32 buffer (one per total size: a step alternates between a
+        few sizes, nothing is allocated per update)."""
         if not self.on:
             return
+        if len(tensors) == 1 and tensors[0].dtype == torch.float32 and tensors[0].is_contiguous():
+            self._sum(tensors[0])
+            return
         n = sum(t.numel() for t in tensors)
-        flat = getattr(self, '_flat', None)
-        if flat is None or flat.numel() != n or flat.device != tensors[0].device:
-            flat = self._flat = torch.empty(n, device=tensors[0].device, dtype=torch.float32)
+        flats = self.__dict__.setdefault('_flats', {})
+        key = (n, tensors[0].device)
+        flat = flats.get(key)
+        if flat is None:
+            flat = flats[key] = torch.empty(n, device=tensors[0].device, dtype=torch.float32)
         off = 0
         for t in tensors:
             flat[off:off + t.numel()].copy_(t.reshape(-1))
             off += t.numel()
-        if self.timed and flat.is_cuda:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
-            ev[1].record()
-            self._events.append(ev)
-        else:
-            self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM)
-        flat /= self.world
+        self._sum(flat)
         off = 0
         for t in tensors:
             t.copy_(flat[off:off + t.numel()].reshape(t.shape))
@@ -345,8 +358,7 @@ class ConditionalBPTTWassersteinGAN(object):
         gen_out, local = ctx.gen_out, ctx.local
         xg = gen_out.prober_tuning_curve
         pens = torch.stack([gen_out.model_rate_penalty.reshape(()).to(torch.float32),
-                            gen_out.model_dynamics_penalty.reshape(()).to(torch.float32)])
-        self.reducer.mean_(pens)
+                            gen_out.model_dynamics_penalty.reshape(()).to(torch.float32)])     # (averaged over ranks below)
         per = local.batchsize
         r0 = self.reducer.rank * per if self.reducer.on else 0
         xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
@@ -360,7 +372,7 @@ class ConditionalBPTTWassersteinGAN(object):
         ctx.snapshot = self.disc_updater.snapshot(self.disc.params) if self.disc_rate_penalty_bound > 0 else None
         with self.disc_train_watch:
             stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
-            self.reducer.mean_(self.disc.grads, stats)
+            self.reducer.mean_(self.disc.grads, stats, pens)      # ONE collective: gradients, loss statistics, the two penalties
             self.disc_updater(self.disc.params, self.disc.grads)
         acc = self.disc.accuracy_device(xg, cd, xd, cd)
         self.reducer.mean_(acc)
