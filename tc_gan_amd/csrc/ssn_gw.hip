@@ -31,7 +31,7 @@
 #include "ssn_host.h"
 
 // Ablation builds for timing only (tools/ab_one.sh <tag> ssn_gw -DGW_ABLATE=n; results are wrong): 1 no MFMAs and no operand
-// reads, 2 no global loads inside the loop, 3 no split and no LDS stores, 4 MFMAs on operands read once (no LDS reads in the loop)
+// reads, 2 no global loads inside the loop, 3 no split and no LDS stores
 #ifndef GW_ABLATE
 #define GW_ABLATE 0
 #endif
@@ -239,10 +239,7 @@ __device__ __forceinline__ void gw_run(const GwStage& g, char* sm, int nslab, in
     // Register sets rotate with period 3, LDS buffers with period 2: six slabs per loop iteration, spelled out.
     auto it = [&](int s, auto R, auto P) {
         constexpr int r = decltype(R)::value, p = decltype(P)::value;
-#if GW_ABLATE == 4
-        mma(sm);
-        asm volatile("" ::: "memory");
-#elif GW_ABLATE != 1
+#if GW_ABLATE != 1
         mma(sm + p * GW_BUFB);
 #endif
 #if GW_ABLATE != 3
