@@ -35,6 +35,9 @@ def make_gen_params(io_type='asym_tanh', k=0.01, n=2.2, tau_E=10., tau_I=1., dt=
 
 
 _PEN_SCRATCH = {}
+# Measurement hook (bench.py): a list to which every plain (save=False) `gen_forward` call appends the pair of events
+# recorded around its forward launch -- the kernel's duration INSIDE a running loop, on its launch stream; None = off.
+FORWARD_EVENTS = None
 
 
 def _penalty_scratch(device):
@@ -68,11 +71,18 @@ def gen_forward(W, ext, gp, save=False):
     if save:
         traj = torch.empty((B, NB, T, M), device=W.device, dtype=W.dtype)
         df = torch.empty_like(traj)
+    ev = None
+    if FORWARD_EVENTS is not None and not save:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     rc = getattr(libssnode, 'ssn_gen_forward_' + suffix)(
         W.data_ptr(), ext.data_ptr(), ta.data_ptr(), dyn.data_ptr(), rate.data_ptr(),
         traj.data_ptr() if save else None, df.data_ptr() if save else None,
         B, NB, M, ctypes.byref(gp), _stream())
     clib.check(rc, 'ssn_gen_forward_' + suffix)
+    if ev is not None:
+        ev[1].record()
+        FORWARD_EVENTS.append(ev)
     n_dyn = B * (T - skip - 1) * NB * M
     n_rate = B * (T - skip) * NB * M
     # both penalty means in one launch (fp64 sums in a fixed order), instead of two reductions and two scalings
