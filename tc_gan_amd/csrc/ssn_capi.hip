@@ -523,7 +523,14 @@ int gen_backward_impl(const T* W, const T* traj, T* delta, const T* gta, T* g_ex
                     *tracked = 1;
                 }
                 SSN_TRY(ssn::launch_gen_backward_duo(a, (hipStream_t)stream));
-            } else if (split) SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
+            } else if (split) {
+                if (dmax && tracked) {                  // (the alternating split sweep keeps the same per-step maxima)
+                    SSN_TRY(hipMemsetAsync(dmax, 0, sizeof(float) * (size_t)B, (hipStream_t)stream));
+                    a.dmax = reinterpret_cast<unsigned*>(dmax);
+                    *tracked = 1;
+                }
+                SSN_TRY(ssn::launch_gen_backward_split(a, (hipStream_t)stream));
+            }
             else SSN_TRY(ssn::launch_gen_backward_mfma(a, (hipStream_t)stream));
             return 0;
         }

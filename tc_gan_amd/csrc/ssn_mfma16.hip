@@ -717,6 +717,7 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
     float pxm[2][4], pdf[2][4];                   // loads in flight for the END of the group's next serial part
     int bused[2] = {0, 0};                        // the scale exponent the group's delta in LDS was written with
     unsigned lastref[2] = {0u, 0u};
+    unsigned runmax[2] = {0u, 0u};                // max over the steps so far of max |delta_tau| of the group: GenBwdArgs::dmax
     auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, int off, float (&out)[4]) {
         if (quad) {
             const mf4 q = __builtin_bit_cast(mf4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
@@ -807,6 +808,7 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
         if (lane == 0) *(LdsAtom)(size_t)slot(g, tau + 2) = 0u;                 // next step's slot (last read a phase pair ago)
         const unsigned ref = mprev ? mprev : lastref[g];
         lastref[g] = ref;
+        runmax[g] = runmax[g] > mprev ? runmax[g] : mprev;       // (delta_T .. delta_2 are stored; their maxima are read at tau = T - 1 .. 1)
         int bexp = 7 - ((int)((ref >> 23) & 0xffu) - 127);
         bexp = ref == 0u ? 0 : (bexp > 100 ? 100 : (bexp < -100 ? -100 : bexp));
         if (tau < T_) {
@@ -889,6 +891,9 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
         __syncthreads();
     }
 #endif
+    // the bound ssn_gw.hip scales the draw's delta with (ssn_weight_grad_scaled_f32); the unscaled delta is what was stored,
+    // whatever its fp16 image in LDS saturated to
+    if (a.dmax && sw == 0 && lane == 0) atomicMax(a.dmax + b, runmax[0] > runmax[1] ? runmax[0] : runmax[1]);
     if (a.g_ext) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {

@@ -189,8 +189,8 @@ def test_full_size_c3_forward_and_adjoint_agree_across_kernels():
         gp = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=kernel, **GEN)
         out = genops.gen_forward(W, ext, gp, save=True)
         delta, dmax = genops.gen_backward(W, out['traj'], out['df'], gta, 1e-3, 1e-3, gp, want_dmax=True)
-        assert (dmax is not None) == (kernel == 8)
-        # (kernel 8: dL/dW on the fp16 two-part form, as the generator update runs it)
+        assert (dmax is not None) == (kernel in (4, 5, 6, 8))
+        # (the fp16-split sweeps: dL/dW on the fp16 two-part form, as the generator update runs it)
         gW = genops.weight_grad(delta, out['traj'], dmax=dmax, xmax=genops.rate_bound(gp))
         res[kernel] = (out['time_avg'].cpu().numpy(), float(out['dynamics_penalty']), float(out['rate_penalty']),
                        gW.cpu().numpy())
@@ -274,11 +274,12 @@ def test_scaled_weight_grad_ranges_and_refusals():
         genops.weight_grad(dt, xt, kernel=3, dmax=dmax, xmax=float('inf'))
 
 
+@pytest.mark.parametrize('bwd_kernel', [8, 4, 5])
 @pytest.mark.parametrize('io_type', ['asym_tanh', 'asym_power'])
-def test_two_draw_adjoint_hands_over_max_delta(io_type):
-    """`ssn_gen_backward_max_f32`: the two-draw sweep (kernel 8) returns max |delta| per draw -- a bound on everything it
-    stored (at most the prologue's estimate of the first step above the true maximum) -- and dL/dW from the fp16 form with
-    that bound agrees with the bf16 x 3 form; the other sweeps report `not tracked`."""
+def test_two_draw_adjoint_hands_over_max_delta(io_type, bwd_kernel):
+    """`ssn_gen_backward_max_f32`: the fp16-split sweeps (two-draw form 8, alternating forms 4 / 5) return max |delta| per draw
+    -- a bound on everything they stored (at most the prologue's estimate of the first step above the true maximum) -- and
+    dL/dW from the fp16 form with that bound agrees with the bf16 x 3 form; the other sweeps report `not tracked`."""
     from tc_gan_amd import genops, stimuli, weight_gen
     N, B, NB, T, skip = 100, 5, 8, 120, 80
     jds = on.new_JDS()
@@ -292,7 +293,7 @@ def test_two_draw_adjoint_hands_over_max_delta(io_type):
     fwd_kernel = 8 if io_type == 'asym_tanh' else 2
     gpf = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=fwd_kernel, **dict(GEN, io_type=io_type))
     out = genops.gen_forward(W, ext, gpf, save=True)
-    gp8 = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=8, **dict(GEN, io_type=io_type))
+    gp8 = genops.make_gen_params(seqlen=T, skip_steps=skip, rate_penalty_threshold=5.0, kernel=bwd_kernel, **dict(GEN, io_type=io_type))
     delta, dmax = genops.gen_backward(W, out['traj'], out['df'].clone(), gta, 0.0, 0.0, gp8, want_dmax=True)
     assert dmax is not None and dmax.shape == (B,)
     true = delta.abs().reshape(B, -1).max(dim=1).values.cpu().numpy()
