@@ -264,7 +264,7 @@ int ssn_weight_grad_f64(const double *delta, const double *traj, double *gW, int
  * draw; elements below 2^-40 of it are lost), and xmax >= max |traj| (host scalar, > 0 and finite: the rate bound of the
  * saturating I/O function).  A bound that is too small overflows fp16: inf / NaN in gW, never a silently wrong value.
  * ssn_gen_backward_max_f32 is ssn_gen_backward_ext_f32 plus that bound: when the sweep that runs tracks max |delta| per draw
- * (the two-draw kernel, which needs it for its own scaling) it fills dmax[B] and sets *tracked = 1; otherwise *tracked = 0,
+ * (the fp16-split kernels 4 / 5 / 6 / 8, which need it for their own scaling) it fills dmax[B] and sets *tracked = 1; otherwise *tracked = 0,
  * dmax is untouched and ssn_weight_grad_f32 is the kernel to call.  fp32, M <= 224.
  */
 int ssn_gen_backward_max_f32(const float *W, const float *traj, float *df_delta, const float *g_time_avg, float *g_ext,

@@ -50,7 +50,7 @@ struct GenBwdArgs {
     int mfma_groups = 2;
     int split_narrow = 0;  // as GenFwdArgs::split_narrow
     unsigned* dmax = nullptr;   // [B] or nullptr: atomic max of the bit patterns of |delta| the sweep stores for draw b (zeroed by
-                                // the caller; the two-draw kernel of ssn_duo.hip only -- it tracks the value for its own scaling)
+                                // the caller; the fp16-split sweeps of ssn_duo.hip / ssn_mfma16.hip only -- they track it for their own scaling)
 };
 template <typename T>
 struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };

@@ -101,7 +101,7 @@ def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp, want_g_ext=False, w
     """Adjoint sweep; `df` is overwritten by the shifted delta and returned (with dL/d ext when asked).
     c_dyn / c_rate multiply SUM(dyn_row) / SUM(rate_row) in the loss.
     ``want_dmax`` (fp32): the last element of the returned tuple is max |delta| per draw, a (B,) tensor, when the sweep
-    that ran tracks it (``ssn_gen_backward_max_f32``: the two-draw kernel), else None -- the bound `weight_grad` needs
+    that ran tracks it (``ssn_gen_backward_max_f32``: the fp16-split kernels 4 / 5 / 6 / 8), else None -- the bound `weight_grad` needs
     for its fp16 form."""
     clib.require_gpu()
     B, NB, T, M = traj.shape
