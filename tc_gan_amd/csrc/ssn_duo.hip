@@ -42,7 +42,9 @@
 #ifndef SSN_DUO_PREB
 #define SSN_DUO_PREB 0          // forward: 1 = the B operand of the wave's own k tile is read in front of the phase barrier and the
                                 // chain starts with that tile (measured at C3, same box, three alternating runs: 3.14 ms against
-                                // 3.16 -- the first read behind the barrier is not what stretches a chain; off)
+                                // 3.16 -- the first read behind the barrier is not what stretches a chain; off); 2 = the MFMAs of
+                                // that tile as well, at the end of the serial phase (3.17-3.22 against 3.13-3.14: they take
+                                // from the partner wave's chain what they save the own one)
 #endif
 #ifndef SSN_DUO_EARLY_SOLVE
 #define SSN_DUO_EARLY_SOLVE 1   // solver: the candidate state of a wave's last row tile behind its own chain (0 = all in the serial phase)
@@ -279,14 +281,18 @@ struct DuoOperands {
     }
     // acc[t] = (W_h + W_m)[row tile RT0 + t, my k range] . B, B read from the image at LDS byte address rd (per lane).
     // ROT: the k tiles in the order own_kt(), own_kt() + 1, ... (mod NKT); PRE: the first of them comes in `bpre`.
-    template <bool ROT = false, bool PRE = false>
+    // KA .. KB: the part of that order to run (the whole chain by default; SSN_DUO_PREB = 2 runs [0, 1) -- the wave's own k
+    // tile -- in front of the barrier, at the end of the serial phase, and [1, NKT) behind it); the sums start at zero with KA = 0.
+    template <bool ROT = false, bool PRE = false, int KA = 0, int KB = S::NKT>
     __device__ __forceinline__ void chain(unsigned rd, mf4 (&acc)[NT], const hv8& bpre = hv8{}) const {
         using LdsB = const __attribute__((address_space(3))) hv8*;
         constexpr int K0 = (ROT && own_kt() >= 0) ? own_kt() : 0;
+        if constexpr (KA == 0) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-        for (int kk = 0; kk < S::NKT; ++kk) {
+        for (int kk = KA; kk < KB; ++kk) {
             const int kt = (K0 + kk) % S::NKT;
             const hv8 b1 = (PRE && ROT && own_kt() >= 0 && kk == 0) ? bpre : read_b(rd, kt);
 #pragma unroll
@@ -440,7 +446,8 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     auto chain = [&](int it) {
         // free-running form: all four waves of the draw must have stored the state of step it - 1 (image it & 1)
         if (FREE && it > 0) duo_wait_ge(sync, S::WM * it, dead);
-        ops.template chain<SSN_DUO_PREB != 0, PREB>(b_rd + (FREE ? (unsigned)((it & 1) * S::BB) : 0u), acc, bpre);
+        if constexpr (PREB && SSN_DUO_PREB == 2) ops.template chain<true, true, 1>(b_rd, acc, bpre);      // (its head ran in front of the barrier)
+        else ops.template chain<SSN_DUO_PREB != 0, PREB>(b_rd + (FREE ? (unsigned)((it & 1) * S::BB) : 0u), acc, bpre);
         if constexpr (WS::TAIL_SHARED) {
             *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
             if (FREE) duo_signal_set(sync + 4u * (1 + WV), (unsigned)(it + 1), lane);
@@ -538,7 +545,10 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
             *(LdsH)(size_t)(wr + 128u) = (unsigned short)m;
         }
         if (FREE) duo_signal_add(sync, lane);
-        if constexpr (PREB) bpre = Ops::read_b(b_rd, Ops::own_kt());
+        if constexpr (PREB) {
+            bpre = Ops::read_b(b_rd, Ops::own_kt());
+            if constexpr (SSN_DUO_PREB == 2) ops.template chain<true, true, 0, 1>(b_rd, acc, bpre);      // head of the next step's chain
+        }
     };
     // row tiles finished behind the own chain: the last ones (never the first, which may wait for a neighbour's partial sum)
     constexpr int EARLY = (FREE || !((SSN_DUO_EARLY_MASK >> WV) & 1)) ? 0 : (SSN_DUO_EARLY < NP - 1 ? SSN_DUO_EARLY : NP - 1);
@@ -556,7 +566,10 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
     constexpr std::integral_constant<bool, true> W1{};
     const int nskip = a.skip < T_ ? (a.skip > 0 ? a.skip : 0) : T_;
     __syncthreads();                                                          // (B)
-    if constexpr (PREB) bpre = Ops::read_b(b_rd, Ops::own_kt());               // (the initial image: zeros)
+    if constexpr (PREB) {                                                      // (the initial image: zeros)
+        bpre = Ops::read_b(b_rd, Ops::own_kt());
+        if constexpr (SSN_DUO_PREB == 2) ops.template chain<true, true, 0, 1>(b_rd, acc, bpre);
+    }
     if constexpr (FREE) {
         // no workgroup barrier from here on: the four waves of a draw meet at their own counters, the two draws drift
         for (int it = 0; it < nskip; ++it) { chain(it); serial(W0, it); }
