@@ -327,6 +327,13 @@ int ssn_critic_input_grad_leaky(const float *params, const int *dims, int nlayer
                                 int batch, int hide_cell_type, float leak, float scale, float *gx, float *stats,
                                 float *workspace, int precision, void *stream);
 
+/* acc[0] = mean D(xg) - mean D(xd) (the "accuracy" of cwgan.py:139-147, logged after every critic update) in one call: two
+ * forwards into dvals (device [ng + nd], scratch), one reduction in a fixed order.  layer_norm: HOST int[L] or NULL; leak as
+ * above; workspace as for ssn_critic_forward* with batch = max(ng, nd). */
+int ssn_critic_accuracy(const float *params, const int *dims, const int *layer_norm, int nlayers, float leak,
+                        const float *xg, const float *cg, const float *xd, const float *cd, int ng, int nd,
+                        int hide_cell_type, float *acc, float *dvals, float *workspace, int precision, void *stream);
+
 /* The same three passes for a critic whose hidden layer l is layer-normalised when layer_norm[l] != 0
  * (simple_discriminator.py:51-75: Dense(no bias) -> LayerNorm (eps 1e-4, no parameters) -> Bias -> ReLU;
  * same [W_l, b_l] parameter layout).  layer_norm: HOST int[L] or NULL (all plain).  The WGAN-GP double

@@ -213,6 +213,9 @@ libssnode.ssn_critic_input_grad_leaky.argtypes = [c_void_p, _ip, c_int, c_void_p
                                                   c_void_p, c_void_p, c_void_p, c_int, c_void_p]
 for _name in ('ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky'):
     getattr(libssnode, _name).restype = c_int
+libssnode.ssn_critic_accuracy.argtypes = [c_void_p, _ip, _ip, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                          c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_accuracy.restype = c_int
 libssnode.ssn_critic_norm_workspace_floats.argtypes = [_ip, c_int, c_int, c_int]
 libssnode.ssn_critic_norm_workspace_floats.restype = ctypes.c_size_t
 libssnode.ssn_critic_forward_norm.argtypes = [c_void_p, _ip, _ip, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
@@ -275,7 +278,7 @@ DECLARED_SYMBOLS = (
     'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
     'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
-    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky',
+    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy',
 )
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]

@@ -142,12 +142,15 @@ class Critic(object):
 
     # -- passes ----------------------------------------------------------------------
     def _workspace(self, bgd, bp):
+        """Scratch for a call with these batch sizes: ONE buffer that only grows (a step alternates between the sizes of the
+        loss pass and of the forwards; the sizes are asked for once per shape)."""
         key = (bgd, bp)
-        if self._ws_key != key:
+        need = self.__dict__.setdefault('_ws_need', {}).get(key)
+        if need is None:
             fn = libssnode.ssn_critic_norm_workspace_floats if self.layer_norm else libssnode.ssn_critic_workspace_floats
-            n = int(fn(self._dims_c, self.nlayers, int(bgd), int(bp)))
-            self._ws = torch.empty(n, device=self.device, dtype=torch.float32)
-            self._ws_key = key
+            need = self._ws_need[key] = int(fn(self._dims_c, self.nlayers, int(bgd), int(bp)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, device=self.device, dtype=torch.float32)
         return self._ws
 
     @staticmethod
@@ -236,10 +239,23 @@ class Critic(object):
             _stream()), 'ssn_critic_input_grad')
         return gx, self.stats[0]
 
-    def accuracy_device(self, xg, cg, xd, cd):
-        """mean D(xg) - mean D(xd) (cwgan.py:139-147) as a 1-element device tensor, no host wait (two forwards: every
-        output row depends on its own input row only, and stacking the rows would cost two more launches)."""
-        return (self.forward(xg, cg).mean() - self.forward(xd, cd).mean()).reshape(1)
+    def accuracy_device(self, xg, cg, xd, cd, out=None):
+        """mean D(xg) - mean D(xd) (cwgan.py:139-147) as a 1-element device tensor (`out`, when given), no host wait:
+        ONE library call (`ssn_critic_accuracy`: two forwards -- every output row depends on its own input row only, and
+        stacking the rows would cost two more launches -- and one reduction in a fixed order)."""
+        xg, cg, xd, cd = (self._f32(t) for t in (xg, cg, xd, cd))
+        ng, nd = xg.shape[0], xd.shape[0]
+        ws = self._workspace(max(ng, nd), 0)
+        if out is None:
+            out = torch.empty(1, device=self.device, dtype=torch.float32)
+        dv = self.__dict__.get('_acc_dvals')
+        if dv is None or dv.numel() < ng + nd:
+            dv = self._acc_dvals = torch.empty(ng + nd, device=self.device, dtype=torch.float32)
+        clib.check(libssnode.ssn_critic_accuracy(
+            self.params.data_ptr(), self._dims_c, self._norm_c if self.layer_norm else None, self.nlayers, float(self.leak),
+            xg.data_ptr(), cg.data_ptr(), xd.data_ptr(), cd.data_ptr(), ng, nd, self.hide_cell_type, out.data_ptr(),
+            dv.data_ptr(), ws.data_ptr(), self.precision, _stream()), 'ssn_critic_accuracy')
+        return out
 
     def accuracy(self, xg, cg, xd, cd):
         return float(self.accuracy_device(xg, cg, xd, cd)[0])

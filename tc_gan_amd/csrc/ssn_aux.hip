@@ -404,6 +404,25 @@ __global__ void __launch_bounds__(256) penalty_means_kernel(const T* __restrict_
         *ticket = 0;
     }
 }
+// out[0] = mean(d[0:ng]) - mean(d[ng:ng+nd])   (one workgroup, fixed order: the critic's "accuracy", cwgan.py:139-147)
+__global__ void __launch_bounds__(256) mean_diff_kernel(const float* __restrict__ d, float* __restrict__ out, int ng, int nd) {
+    __shared__ float red[2][256];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < ng; i += 256) a += d[i];
+    for (int i = threadIdx.x; i < nd; i += 256) b += d[ng + i];
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (ng ? red[0][0] / ng : 0.f) - (nd ? red[1][0] / nd : 0.f);
+}
+hipError_t launch_mean_diff(const float* d, int ng, int nd, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(mean_diff_kernel, dim3(1), dim3(256), 0, st, d, out, ng, nd);
+    return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws,
                                 double* out, hipStream_t st) {

@@ -691,6 +691,27 @@ int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* 
                                         workspace, precision == 0, (hipStream_t)stream));
     return 0;
 }
+// mean D(xg) - mean D(xd) in one call (two critic forwards into `dvals`, one reduction in a fixed order): layer_norm NULL or all
+// zero = plain layers, leak as in the _leaky entry points.
+int ssn_critic_accuracy(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
+                        const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type, float* acc,
+                        float* dvals, float* workspace, int precision, void* stream) {
+    bool norm = false;
+    for (int l = 0; layer_norm && l < nlayers; ++l) norm = norm || layer_norm[l] != 0;
+    const struct { const float* x; const float* c; int n; float* out; } part[2] = {{xg, cg, ng, dvals}, {xd, cd, nd, dvals + ng}};
+    for (int i = 0; i < 2; ++i) {
+        int rc;
+        if (norm) rc = ssn_critic_forward_norm(params, dims, layer_norm, nlayers, part[i].x, part[i].c, part[i].n, hide_cell_type,
+                                               part[i].out, workspace, precision, stream);
+        else if (leak != 0.f) rc = ssn_critic_forward_leaky(params, dims, nlayers, part[i].x, part[i].c, part[i].n, hide_cell_type,
+                                                            leak, part[i].out, workspace, precision, stream);
+        else rc = ssn_critic_forward(params, dims, nlayers, part[i].x, part[i].c, part[i].n, hide_cell_type, part[i].out,
+                                     workspace, precision, stream);
+        if (rc) return rc;
+    }
+    SSN_TRY(ssn::launch_mean_diff(dvals, ng, nd, acc, (hipStream_t)stream));
+    return 0;
+}
 int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, void* stream) {
     if (!o || n < 0 || o->kind < 0 || o->kind > 2) {
         g_last_error = "ssn_optimizer_step: invalid argument";

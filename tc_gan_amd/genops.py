@@ -91,7 +91,7 @@ def gen_forward(W, ext, gp, save=False):
         dyn.data_ptr(), rate.data_ptr(), dyn.numel(), (1.0 / n_dyn) if n_dyn > 0 else float('nan'), 1.0 / n_rate,
         _penalty_scratch(W.device).data_ptr(), pens.data_ptr(), _stream())
     clib.check(rc, 'ssn_penalty_means_' + suffix)
-    out = dict(time_avg=ta, dynamics_penalty=pens[0], rate_penalty=pens[1], n_dyn=n_dyn, n_rate=n_rate)
+    out = dict(time_avg=ta, dynamics_penalty=pens[0], rate_penalty=pens[1], penalties=pens, n_dyn=n_dyn, n_rate=n_rate)
     if save:
         out.update(traj=traj, df=df)
     return out

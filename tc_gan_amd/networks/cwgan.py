@@ -349,7 +349,7 @@ class ConditionalBPTTWassersteinGAN(object):
         batch, eps_full, noise = drawn if drawn is not None else self._draw_disc()
         with self.gen_forward_watch:
             gen_out, local = self.gen_forward(batch, noise)
-        return Namespace(batch=batch, eps_full=eps_full, gen_out=gen_out, local=local,
+        return Namespace(batch=batch, eps_full=eps_full, gen_out=gen_out, local=local, pens64=self.gen.last_penalties,
                          gen_time=self.gen_forward_watch.times[-1])
 
     def _launch_disc(self, ctx):
@@ -357,8 +357,7 @@ class ConditionalBPTTWassersteinGAN(object):
         host memory with an asynchronous copy followed by an event."""
         gen_out, local = ctx.gen_out, ctx.local
         xg = gen_out.prober_tuning_curve
-        pens = torch.stack([gen_out.model_rate_penalty.reshape(()).to(torch.float32),
-                            gen_out.model_dynamics_penalty.reshape(()).to(torch.float32)])     # (averaged over ranks below)
+        pens = ctx.pens64.to(torch.float32)          # [dynamics_penalty, rate_penalty] of this step's forward (averaged over ranks below)
         per = local.batchsize
         r0 = self.reducer.rank * per if self.reducer.on else 0
         xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
@@ -376,11 +375,16 @@ class ConditionalBPTTWassersteinGAN(object):
             self.disc_updater(self.disc.params, self.disc.grads)
         acc = self.disc.accuracy_device(xg, cd, xd, cd)
         self.reducer.mean_(acc)
-        # the four scalars of the step + the per-tensor sums of squares of the updated critic (disc_param_stats)
-        tail = torch.cat([pens, stats[3:4].to(torch.float32), acc.to(torch.float32), self.disc.param_sqnorms_device()])
-        ctx.host = torch.empty(tail.numel(), dtype=torch.float32, pin_memory=True)
+        # the four scalars of the step [dynamics penalty, rate penalty, loss, accuracy] + the per-tensor sums of squares of
+        # the updated critic (disc_param_stats); pinned buffers and events come from a small ring (a step is read before the
+        # ring comes round: at most two steps are in flight)
+        tail = torch.cat([pens, stats[3:4], acc, self.disc.param_sqnorms_device()])
+        ring = self.__dict__.setdefault('_host_ring', [])
+        if not ring or ring[0][0].numel() != tail.numel():
+            ring[:] = [(torch.empty(tail.numel(), dtype=torch.float32, pin_memory=True), torch.cuda.Event()) for _ in range(4)]
+        self._host_ring_pos = (getattr(self, '_host_ring_pos', -1) + 1) % len(ring)
+        ctx.host, ctx.event = ring[self._host_ring_pos]
         ctx.host.copy_(tail, non_blocking=True)
-        ctx.event = torch.cuda.Event()
         ctx.event.record()
         ctx.disc_time = self.disc_train_watch.times[-1]
 
@@ -388,8 +392,8 @@ class ConditionalBPTTWassersteinGAN(object):
         """Wait for the scalars of a launched step (only for its own kernels: later launches are not waited for)."""
         if ctx.event is not None:
             ctx.event.synchronize()
-        host = ctx.host.numpy()
-        if ctx.snapshot is not None and float(host[0]) > self.disc_rate_penalty_bound:
+        host = ctx.host.numpy().copy()               # (the pinned buffer goes back to the ring)
+        if ctx.snapshot is not None and float(host[1]) > self.disc_rate_penalty_bound:
             self.disc_updater.restore(self.disc.params, ctx.snapshot)            # the skipped step of cwgan.py:493-498
             ctx.skipped = True
             host = np.array([host[0], host[1], np.nan, np.nan], dtype='float32')
@@ -402,7 +406,7 @@ class ConditionalBPTTWassersteinGAN(object):
         info.cd = info.cg = info.cp = ctx.cd
         info.batch = ctx.batch
         info.gen_time = ctx.gen_time
-        info.rate_penalty, info.dynamics_penalty = float(host[0]), float(host[1])
+        info.dynamics_penalty, info.rate_penalty = float(host[0]), float(host[1])
         info.disc_loss, info.accuracy = float(host[2]), float(host[3])
         info.disc_time = np.nan if ctx.skipped else ctx.disc_time
         return info

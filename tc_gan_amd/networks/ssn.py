@@ -356,6 +356,7 @@ class TuningCurveGenerator(object):
         gp = self.gen_params(theta)
         fwd = genops.gen_forward(W, ext, gp, save=save)
         tc, ids, pr = self._probe(fwd['time_avg'], **probe_kw)
+        self.last_penalties = fwd['penalties']        # fp64 [dynamics_penalty, rate_penalty] of this call, one device tensor
         vals = [fwd['dynamics_penalty']]
         if self.include_rate_penalty:
             vals.append(fwd['rate_penalty'])
