@@ -66,7 +66,8 @@ def gen_forward(W, ext, gp, save=False):
     assert W.shape == (B, M, M)
     T, skip = gp.seqlen, gp.skip_steps
     suffix, _ = _DT[W.dtype]
-    ta = torch.empty_like(ext); dyn = torch.empty_like(ext); rate = torch.empty_like(ext)
+    ta3 = torch.empty((3,) + tuple(ext.shape), device=ext.device, dtype=ext.dtype)      # one allocation: time_avg, dyn_row, rate_row
+    ta, dyn, rate = ta3[0], ta3[1], ta3[2]
     traj = df = None
     if save:
         traj = torch.empty((B, NB, T, M), device=W.device, dtype=W.dtype)

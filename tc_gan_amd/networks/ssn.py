@@ -290,7 +290,12 @@ class TuningCurveGenerator(object):
         return dev
 
     def _input_variability(self):
-        return self._cached_upload('vs', np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'), self.tdtype)
+        # (per-neuron vector from the population values; rebuilt only when V changed -- twice per forward otherwise)
+        v = np.asarray(self.V, dtype='float64')
+        hit = self.__dict__.get('_vs_of')
+        if hit is None or hit[0].shape != v.shape or not np.array_equal(hit[0], v):
+            hit = self._vs_of = (v.copy(), np.asarray(neu_array(self.vpop, self.num_sites), dtype='float64'))
+        return self._cached_upload('vs', hit[1], self.tdtype)
 
     def _device_inputs(self, stimulator_bandwidths, stimulator_contrasts, model_zs, model_zs_in=None, save=True):
         bw = stimulator_bandwidths if torch.is_tensor(stimulator_bandwidths) else \
