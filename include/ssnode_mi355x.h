@@ -363,6 +363,28 @@ typedef struct ssn_opt_params {
 /* In-place update of p[n] from g[n]; s1, s2 optimizer state (adam: m, v; rmsprop: s1 only; sgd: unused). */
 int ssn_optimizer_step(float *p, const float *g, float *s1, float *s2, long n, const ssn_opt_params *o, void *stream);
 
+/*
+ * One critic step of the GAN loop in ONE call (single process; the data-parallel loop keeps the separate calls because its
+ * all-reduce sits between the gradient and the optimizer step): penalty points xp = eps xd + (1 - eps) xg (cwgan.py:476-481),
+ * loss + gradient (ssn_critic_loss_grad*), optimizer step on the critic's parameters, accuracy of the UPDATED critic
+ * (cwgan.py:507), per-tensor sums of squares of the updated parameters (recorders.py:275-311), and the step's scalar record
+ * tail[4 + nseg] = {dynamics penalty, rate penalty (from pens64, device double[2] or NULL), loss, accuracy, sums of squares}.
+ * The same kernels in the same order as the separate calls: identical results.  xg, xd: device [n][nx]; cond [n][3] shared by
+ * the three inputs; eps device [n]; layer_norm / leak as above; opt_s1 / opt_s2 / opt as ssn_optimizer_step; seg_bounds, seg_ws
+ * as ssn_segment_sqnorms_f32; acc_dvals device [2 n] scratch; workspace as ssn_critic_*workspace_floats(n + n, n).
+ */
+typedef struct ssn_critic_step {
+    float *params; const int *dims; const int *layer_norm; int nlayers; float leak;
+    const float *xg, *xd, *cond, *eps;
+    int n, hide_cell_type, precision; float lmd;
+    float *xp, *grads, *stats, *dvals, *workspace;
+    float *opt_s1, *opt_s2; const ssn_opt_params *opt;
+    const long *seg_bounds; int nseg; double *seg_ws;
+    const double *pens64;
+    float *acc_dvals, *tail;
+} ssn_critic_step;
+int ssn_critic_step_run(const ssn_critic_step *a, void *stream);
+
 /* ------------------------------------------------------------------------
  * 5. Feed-forward tuning-curve generator (FF_lalazar model; BASELINE config 5): replaces the Theano
  *    graph of FF_functions/lalazar_func.py:16-45 (get_FF_output) compiled at

@@ -195,6 +195,24 @@ class OptParams(Structure):
 
 
 _ip = POINTER(c_int)
+
+
+class CriticStep(Structure):
+    """``ssn_critic_step`` of include/ssnode_mi355x.h."""
+    _fields_ = [
+        ('params', c_void_p), ('dims', _ip), ('layer_norm', _ip), ('nlayers', c_int), ('leak', c_float),
+        ('xg', c_void_p), ('xd', c_void_p), ('cond', c_void_p), ('eps', c_void_p),
+        ('n', c_int), ('hide_cell_type', c_int), ('precision', c_int), ('lmd', c_float),
+        ('xp', c_void_p), ('grads', c_void_p), ('stats', c_void_p), ('dvals', c_void_p), ('workspace', c_void_p),
+        ('opt_s1', c_void_p), ('opt_s2', c_void_p), ('opt', POINTER(OptParams)),
+        ('seg_bounds', c_void_p), ('nseg', c_int), ('seg_ws', c_void_p),
+        ('pens64', c_void_p),
+        ('acc_dvals', c_void_p), ('tail', c_void_p),
+    ]
+
+
+libssnode.ssn_critic_step_run.argtypes = [POINTER(CriticStep), c_void_p]
+libssnode.ssn_critic_step_run.restype = c_int
 libssnode.ssn_critic_num_params.argtypes = [_ip, c_int]
 libssnode.ssn_critic_num_params.restype = c_long
 libssnode.ssn_critic_workspace_floats.argtypes = [_ip, c_int, c_int, c_int]
@@ -278,7 +296,7 @@ DECLARED_SYMBOLS = (
     'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
     'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
-    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy',
+    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run',
 )
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]

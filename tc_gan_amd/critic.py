@@ -115,17 +115,21 @@ class Critic(object):
     # -- parameter statistics without a host wait (recorders.py:275-311 logs them after EVERY critic step) --------
     def param_sqnorms_device(self):
         """Sum of squares per parameter tensor (device tensor, `param_shapes` order; one launch: `ssn_segment_sqnorms_f32`)."""
+        self._ensure_segments()
+        out = torch.empty(len(self._seg_sizes), device=self.device, dtype=torch.float32)
+        clib.check(libssnode.ssn_segment_sqnorms_f32(self.params.data_ptr(), self._seg_bounds.data_ptr(), int(out.numel()),
+                                                     out.data_ptr(), self._seg_ws.data_ptr(), _stream()),
+                   'ssn_segment_sqnorms_f32')
+        return out
+
+    def _ensure_segments(self):
+        """Bounds of the parameter tensors inside the flat vector (device) and the scratch of `ssn_segment_sqnorms_f32`."""
         if getattr(self, '_seg_bounds', None) is None:
             sizes = [int(np.prod(shape)) for _, shape in self.param_shapes()]
             self._seg_sizes = np.asarray(sizes, dtype='float64')
             self._seg_bounds = torch.as_tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)).to(self.device)
             self._seg_ws = torch.empty(int(libssnode.ssn_segment_sqnorms_ws_doubles(len(sizes))), device=self.device,
                                        dtype=torch.float64)
-        out = torch.empty(len(self._seg_sizes), device=self.device, dtype=torch.float32)
-        clib.check(libssnode.ssn_segment_sqnorms_f32(self.params.data_ptr(), self._seg_bounds.data_ptr(), int(out.numel()),
-                                                     out.data_ptr(), self._seg_ws.data_ptr(), _stream()),
-                   'ssn_segment_sqnorms_f32')
-        return out
 
     def cache_param_nnorms(self, sqnorms_host):
         """Store ||p|| / size per tensor for the NEXT `param_nnorms()` call (None: no valid cache)."""
@@ -260,6 +264,37 @@ class Critic(object):
     def accuracy(self, xg, cg, xd, cd):
         return float(self.accuracy_device(xg, cg, xd, cd)[0])
 
+    def step(self, updater, xg, xd, cond, eps, lmd, pens64=None):
+        """One critic step of the GAN loop in ONE library call (`ssn_critic_step_run`): penalty points, loss + gradient,
+        `updater`'s step on the parameters, accuracy of the updated critic, per-tensor sums of squares -- the kernels of
+        `interpolate`, `loss_grad`, `Updater.__call__` (plain clip-free form), `accuracy_device`, `param_sqnorms_device` in
+        that order, so the same numbers.  Returns (xp, tail): tail = [penalties (2, from `pens64`), loss, accuracy, sums of
+        squares] on the device."""
+        xg, xd, cond = self._f32(xg), self._f32(xd), self._f32(cond)
+        eps = self._f32(eps).reshape(-1)
+        n = xg.shape[0]
+        assert xd.shape == xg.shape and cond.shape[0] == n and eps.numel() == n
+        self._ensure_segments()
+        nseg = len(self._seg_sizes)
+        ws = self._workspace(2 * n, n)
+        xp = torch.empty_like(xd)
+        tail = torch.empty(4 + nseg, device=self.device, dtype=torch.float32)
+        self._dvals = torch.empty(2 * n, device=self.device, dtype=torch.float32)
+        dv = self.__dict__.get('_acc_dvals')
+        if dv is None or dv.numel() < 2 * n:
+            dv = self._acc_dvals = torch.empty(2 * n, device=self.device, dtype=torch.float32)
+        s1, s2, opt = updater.begin_step(self.params)
+        a = clib.CriticStep(
+            params=self.params.data_ptr(), dims=self._dims_c, layer_norm=self._norm_c if self.layer_norm else None,
+            nlayers=self.nlayers, leak=float(self.leak), xg=xg.data_ptr(), xd=xd.data_ptr(), cond=cond.data_ptr(),
+            eps=eps.data_ptr(), n=n, hide_cell_type=self.hide_cell_type, precision=self.precision, lmd=float(lmd),
+            xp=xp.data_ptr(), grads=self.grads.data_ptr(), stats=self.stats.data_ptr(), dvals=self._dvals.data_ptr(),
+            workspace=ws.data_ptr(), opt_s1=s1.data_ptr(), opt_s2=s2.data_ptr(), opt=ctypes.pointer(opt),
+            seg_bounds=self._seg_bounds.data_ptr(), nseg=nseg, seg_ws=self._seg_ws.data_ptr(),
+            pens64=pens64.data_ptr() if pens64 is not None else None, acc_dvals=dv.data_ptr(), tail=tail.data_ptr())
+        clib.check(libssnode.ssn_critic_step_run(ctypes.byref(a), _stream()), 'ssn_critic_step_run')
+        return xp, tail
+
 
 class Updater(object):
     """wgan.py:111-165: 'adam-wgan' = Adam(beta1=.5, beta2=.9); any of adam / rmsprop / sgd by name;
@@ -307,6 +342,19 @@ class Updater(object):
         params.copy_(snap[0])
         self.step = snap[1]
         self._state = snap[2]
+
+    def begin_step(self, params):
+        """Bookkeeping of one clip-free update made by somebody else's launch (`Critic.step`): the state tensors and the
+        `ssn_opt_params` of this step, with the step count advanced as `__call__` would."""
+        if self._state is None or self._state[0].shape != params.shape:
+            self._state = (torch.zeros_like(params), torch.zeros_like(params))
+        self.step += 1
+        o = clib.OptParams(kind=self.kind, step=self.step, clip=0, reserved=0,
+                           learning_rate=self.learning_rate, beta1=self.cfg['beta1'], beta2=self.cfg['beta2'],
+                           epsilon=self.cfg['epsilon'], rho=self.cfg['rho'],
+                           reg_l2_penalty=self.reg[0], reg_l1_penalty=self.reg[1],
+                           reg_l2_decay=self.reg[2], reg_l1_decay=self.reg[3], clip_lo=0.0, clip_hi=0.0)
+        return self._state[0], self._state[1], o
 
     def __call__(self, params, grads, clip=None):
         """In-place update of the flat device tensor `params` from `grads`.  `clip` = (lo, hi): scalars, or arrays of the

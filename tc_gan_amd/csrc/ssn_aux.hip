@@ -418,6 +418,16 @@ __global__ void __launch_bounds__(256) mean_diff_kernel(const float* __restrict_
     }
     if (threadIdx.x == 0) out[0] = (ng ? red[0][0] / ng : 0.f) - (nd ? red[1][0] / nd : 0.f);
 }
+// head of the critic step's scalar record: tail[0..1] = the forward's two penalties (fp64 -> fp32), tail[2] = the loss
+__global__ void step_head_kernel(const double* __restrict__ pens, const float* __restrict__ stats, float* __restrict__ tail) {
+    tail[0] = pens ? (float)pens[0] : 0.f;
+    tail[1] = pens ? (float)pens[1] : 0.f;
+    tail[2] = stats[3];
+}
+hipError_t launch_step_head(const double* pens, const float* stats, float* tail, hipStream_t st) {
+    hipLaunchKernelGGL(step_head_kernel, dim3(1), dim3(1), 0, st, pens, stats, tail);
+    return hipGetLastError();
+}
 hipError_t launch_mean_diff(const float* d, int ng, int nd, float* out, hipStream_t st) {
     hipLaunchKernelGGL(mean_diff_kernel, dim3(1), dim3(256), 0, st, d, out, ng, nd);
     return hipGetLastError();

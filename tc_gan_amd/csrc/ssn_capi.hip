@@ -730,6 +730,34 @@ int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, c
     return 0;
 }
 
+int ssn_critic_step_run(const ssn_critic_step* a, void* stream) {
+    if (!a || !a->params || !a->dims || !a->xg || !a->xd || !a->cond || !a->eps || !a->xp || !a->grads || !a->stats || !a->dvals ||
+        !a->workspace || !a->opt || !a->acc_dvals || !a->tail || a->n <= 0 || a->nlayers < 0 || a->nseg < 0) {
+        g_last_error = "ssn_critic_step_run: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    bool norm = false;
+    for (int l = 0; a->layer_norm && l < a->nlayers; ++l) norm = norm || a->layer_norm[l] != 0;
+    const int n = a->n, nx = a->dims[0] - 3;
+    int rc;
+    if ((rc = ssn_interpolate_f32(a->eps, a->xd, a->xg, a->xp, n, nx, stream))) return rc;
+    if (norm) rc = ssn_critic_loss_grad_norm(a->params, a->dims, a->layer_norm, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond,
+                                             n, n, n, a->lmd, a->hide_cell_type, a->grads, a->stats, a->dvals, a->workspace, a->precision, stream);
+    else if (a->leak != 0.f) rc = ssn_critic_loss_grad_leaky(a->params, a->dims, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond,
+                                                             n, n, n, a->lmd, a->hide_cell_type, a->leak, a->grads, a->stats, a->dvals,
+                                                             a->workspace, a->precision, stream);
+    else rc = ssn_critic_loss_grad(a->params, a->dims, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond, n, n, n, a->lmd,
+                                   a->hide_cell_type, a->grads, a->stats, a->dvals, a->workspace, a->precision, stream);
+    if (rc) return rc;
+    const long nparams = ssn_critic_num_params(a->dims, a->nlayers);
+    if ((rc = ssn_optimizer_step(a->params, a->grads, a->opt_s1, a->opt_s2, nparams, a->opt, stream))) return rc;
+    if ((rc = ssn_critic_accuracy(a->params, a->dims, a->layer_norm, a->nlayers, a->leak, a->xg, a->cond, a->xd, a->cond, n, n,
+                                  a->hide_cell_type, a->tail + 3, a->acc_dvals, a->workspace, a->precision, stream))) return rc;
+    if (a->nseg > 0 && (rc = ssn_segment_sqnorms_f32(a->params, a->seg_bounds, a->nseg, a->tail + 4, a->seg_ws, stream))) return rc;
+    SSN_TRY(ssn::launch_step_head(a->pens64, a->stats, a->tail, (hipStream_t)stream));
+    return 0;
+}
+
 static ssn::FFArgs ff_args(const ssn_ff_params& p) {
     ssn::FFArgs a{};
     a.nsam = p.nsam; a.nhid = p.nhid; a.ni = p.ni; a.box = p.box;

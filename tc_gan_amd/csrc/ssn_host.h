@@ -181,6 +181,7 @@ template <typename T> hipError_t launch_probe_scatter(const T* g, const long* id
 long segment_sqnorms_ws_doubles(int n);
 hipError_t launch_segment_sqnorms(const float* x, const long* bounds, int n, float* out, double* ws, hipStream_t st);
 hipError_t launch_interpolate(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, hipStream_t st);
+hipError_t launch_step_head(const double* pens, const float* stats, float* tail, hipStream_t st);
 hipError_t launch_mean_diff(const float* d, int ng, int nd, float* out, hipStream_t st);
 template <typename T> hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, hipStream_t st);
 template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st);

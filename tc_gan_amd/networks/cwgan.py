@@ -357,28 +357,35 @@ class ConditionalBPTTWassersteinGAN(object):
         host memory with an asynchronous copy followed by an event."""
         gen_out, local = ctx.gen_out, ctx.local
         xg = gen_out.prober_tuning_curve
-        pens = ctx.pens64.to(torch.float32)          # [dynamics_penalty, rate_penalty] of this step's forward (averaged over ranks below)
         per = local.batchsize
         r0 = self.reducer.rank * per if self.reducer.on else 0
         xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
-        xp = self.disc.interpolate(eps, xd, xg)                               # cwgan.py:481
-        ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
         ctx.skipped = False
-        # cwgan.py:493-498 skips the critic update when the rate penalty of the batch exceeds `disc_rate_penalty_bound`.
-        # Waiting for that value here would stall the queue at every critic step, so the update is made
-        # speculatively and rolled back in `_read_disc` (which learns the value before the next update is queued)
-        # in the rare case that the bound was exceeded.
-        ctx.snapshot = self.disc_updater.snapshot(self.disc.params) if self.disc_rate_penalty_bound > 0 else None
-        with self.disc_train_watch:
-            stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
-            self.reducer.mean_(self.disc.grads, stats, pens)      # ONE collective: gradients, loss statistics, the two penalties
-            self.disc_updater(self.disc.params, self.disc.grads)
-        acc = self.disc.accuracy_device(xg, cd, xd, cd)
-        self.reducer.mean_(acc)
-        # the four scalars of the step [dynamics penalty, rate penalty, loss, accuracy] + the per-tensor sums of squares of
-        # the updated critic (disc_param_stats); pinned buffers and events come from a small ring (a step is read before the
+        ctx.snapshot = None
+        if not self.reducer.on and self.disc_rate_penalty_bound <= 0 and xg.dtype == torch.float32:
+            # single process, no skip rule to honour: the whole step is one library call (same kernels, same order)
+            with self.disc_train_watch:
+                xp, tail = self.disc.step(self.disc_updater, xg, xd, cd, eps, self.lipschitz_cost, pens64=ctx.pens64)
+            ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
+        else:
+            pens = ctx.pens64.to(torch.float32)      # [dynamics_penalty, rate_penalty] of this step's forward (averaged over ranks below)
+            xp = self.disc.interpolate(eps, xd, xg)                               # cwgan.py:481
+            ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
+            # cwgan.py:493-498 skips the critic update when the rate penalty of the batch exceeds `disc_rate_penalty_bound`.
+            # Waiting for that value here would stall the queue at every critic step, so the update is made
+            # speculatively and rolled back in `_read_disc` (which learns the value before the next update is queued)
+            # in the rare case that the bound was exceeded.
+            ctx.snapshot = self.disc_updater.snapshot(self.disc.params) if self.disc_rate_penalty_bound > 0 else None
+            with self.disc_train_watch:
+                stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
+                self.reducer.mean_(self.disc.grads, stats, pens)      # ONE collective: gradients, loss statistics, the two penalties
+                self.disc_updater(self.disc.params, self.disc.grads)
+            acc = self.disc.accuracy_device(xg, cd, xd, cd)
+            self.reducer.mean_(acc)
+            tail = torch.cat([pens, stats[3:4], acc, self.disc.param_sqnorms_device()])
+        # `tail`: the four scalars of the step [dynamics penalty, rate penalty, loss, accuracy] + the per-tensor sums of squares
+        # of the updated critic (disc_param_stats); pinned buffers and events come from a small ring (a step is read before the
         # ring comes round: at most two steps are in flight)
-        tail = torch.cat([pens, stats[3:4], acc, self.disc.param_sqnorms_device()])
         ring = self.__dict__.setdefault('_host_ring', [])
         if not ring or ring[0][0].numel() != tail.numel():
             ring[:] = [(torch.empty(tail.numel(), dtype=torch.float32, pin_memory=True), torch.cuda.Event()) for _ in range(4)]

@@ -80,6 +80,37 @@ def test_piecewise_linear_nonlinearities(nonlinearity, batch, nx, layers):
             Critic(nx, layers, nonlinearity=nonlinearity, normalization='layer')
 
 
+@pytest.mark.parametrize('layers,norm,nonlin,precision', [([128, 128, 128, 128], ['none', 'layer', 'layer', 'layer'], 'rectify', 'fp32'),
+                                                          ([512, 512, 512], 'none', 'rectify', 'bf16'),
+                                                          ([64, 64], 'none', 'leaky_rectify', 'fp32'), ([], 'none', 'rectify', 'fp32')])
+def test_one_call_critic_step_equals_the_separate_calls(layers, norm, nonlin, precision):
+    """`Critic.step` (`ssn_critic_step_run`: penalty points, loss + gradient, optimizer step, accuracy of the updated critic,
+    per-tensor sums of squares and the step's scalar record in one library call) launches the kernels of the separate calls in
+    the same order: parameters, optimizer state, gradients and every scalar agree bit for bit over several steps."""
+    from tc_gan_amd.critic import Critic, Updater
+    rs = np.random.RandomState(7)
+    n, nx = 96, 8
+    kw = dict(seed=3, precision=precision, normalization=norm, nonlinearity=nonlin)
+    a, b = Critic(nx, layers, **kw), Critic(nx, layers, **kw)
+    ua, ub = Updater(0.01, 'rmsprop', reg_l2_decay=1e-3), Updater(0.01, 'rmsprop', reg_l2_decay=1e-3)
+    for it in range(3):
+        xg = torch.as_tensor(rs.rand(n, nx) * 5, device='cuda', dtype=torch.float32)
+        xd = torch.as_tensor(rs.rand(n, nx) * 5, device='cuda', dtype=torch.float32)
+        cond = torch.as_tensor(np.stack([np.full(n, 20.), rs.rand(n) * 2 - 1, rs.randint(0, 2, n)], axis=1), device='cuda', dtype=torch.float32)
+        eps = torch.as_tensor(rs.rand(n, 1), device='cuda', dtype=torch.float32)
+        pens = torch.as_tensor(rs.rand(2), device='cuda', dtype=torch.float64)
+        xp_a = a.interpolate(eps, xd, xg)
+        stats = a.loss_grad(xg, cond, xd, cond, xp_a, cond, 10.0)
+        loss_a = stats[3:4].clone()
+        ua(a.params, a.grads)
+        acc_a = a.accuracy_device(xg, cond, xd, cond)
+        want = torch.cat([pens.to(torch.float32), loss_a, acc_a, a.param_sqnorms_device()])
+        xp_b, tail = b.step(ub, xg, xd, cond, eps, 10.0, pens64=pens)
+        assert torch.equal(xp_a, xp_b) and torch.equal(tail, want), (it, tail, want)
+        assert torch.equal(a.params, b.params) and torch.equal(a.grads, b.grads) and ua.step == ub.step
+        assert all(torch.equal(x, y) for x, y in zip(ua._state, ub._state))
+
+
 def test_critic_bf16_path_close_to_fp64():
     from tc_gan_amd.critic import Critic
     c, params_o, xg, xd, xp, cond = _setup(512, 8, [256, 256], seed=3)
