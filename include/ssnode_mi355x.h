@@ -494,6 +494,23 @@ int ssn_build_w_philox_f32(unsigned long long seed, unsigned long long offset, c
                            float *W, float *z, int B, int N, void *stream);
 int ssn_build_w_philox_f64(unsigned long long seed, unsigned long long offset, const double *J, const double *D, const double *S,
                            double *W, double *z, int B, int N, void *stream);
+/*
+ * Everything a device-noise generator forward reads, in ONE call (the launches of ssn_philox_amp_f32, ssn_stimulus_amp_f32 and
+ * ssn_build_w_philox_f32 in that order: the same numbers, without the host between them): zin / amp = the heterogeneous-input
+ * signs and 1 + v zin from stream elements off_zin.. (v device [M]; v NULL: none, plain stimulus), ext[B][NB][M] the (amplified)
+ * stimulus of bandwidths bw and contrasts con (device [B][NB]), W[B][M][M] from stream elements off_z.. (z device or NULL).
+ */
+typedef struct ssn_gen_inputs {
+    unsigned long long seed, off_z, off_zin;
+    const float *J, *D, *S;            /* HOST float[4] each */
+    const float *bw, *con;
+    float smoothness;
+    const float *v;
+    int bernoulli;
+    float *W, *z, *zin, *amp, *ext;
+    int B, NB, N;
+} ssn_gen_inputs;
+int ssn_gen_inputs_philox_f32(const ssn_gen_inputs *a, void *stream);
 /* The heterogeneous-input SSN's noise from the same stream, in one launch (networks/ssn.py:679-720): zin[i] = +1 / -1
  * (u < 0.5; bernoulli != 0) or 2 u - 1, and amp[i] = 1 + v[i % M] * zin[i] (v: device [M], the input variability per
  * neuron); zin, amp: device [n]. */

@@ -142,6 +142,19 @@ libssnode.ssn_build_w_philox_f32.argtypes = [ctypes.c_ulonglong, ctypes.c_ulongl
 libssnode.ssn_build_w_philox_f64.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong, POINTER(c_double), POINTER(c_double),
                                              POINTER(c_double), c_void_p, c_void_p, c_int, c_int, c_void_p]
 libssnode.ssn_build_w_philox_f32.restype = libssnode.ssn_build_w_philox_f64.restype = c_int
+class GenInputs(Structure):
+    """``ssn_gen_inputs`` of include/ssnode_mi355x.h."""
+    _fields_ = [
+        ('seed', ctypes.c_ulonglong), ('off_z', ctypes.c_ulonglong), ('off_zin', ctypes.c_ulonglong),
+        ('J', POINTER(c_float)), ('D', POINTER(c_float)), ('S', POINTER(c_float)),
+        ('bw', c_void_p), ('con', c_void_p), ('smoothness', c_float), ('v', c_void_p), ('bernoulli', c_int),
+        ('W', c_void_p), ('z', c_void_p), ('zin', c_void_p), ('amp', c_void_p), ('ext', c_void_p),
+        ('B', c_int), ('NB', c_int), ('N', c_int),
+    ]
+
+
+libssnode.ssn_gen_inputs_philox_f32.argtypes = [POINTER(GenInputs), c_void_p]
+libssnode.ssn_gen_inputs_philox_f32.restype = c_int
 libssnode.ssn_weight_grad_scaled_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_long, c_int, c_void_p, c_float, c_void_p]
 libssnode.ssn_weight_grad_scaled_f32.restype = c_int
 for _name in ('ssn_philox_uniform_f32', 'ssn_philox_uniform_f64'):
@@ -296,7 +309,7 @@ DECLARED_SYMBOLS = (
     'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
     'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
-    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run',
+    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_gen_inputs_philox_f32',
 )
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]

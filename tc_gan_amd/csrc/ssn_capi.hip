@@ -1024,6 +1024,19 @@ int ssn_build_w_philox_f64(unsigned long long seed, unsigned long long offset, c
     SSN_TRY(ssn::launch_build_w_philox<double>(seed, offset, jds, W, z, B, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_gen_inputs_philox_f32(const ssn_gen_inputs* a, void* stream) {
+    if (!a || !a->J || !a->D || !a->S || !a->bw || !a->con || !a->W || !a->ext || a->B < 0 || a->NB < 0 || a->N <= 0 ||
+        (a->v && (!a->zin || !a->amp))) {
+        g_last_error = "ssn_gen_inputs_philox: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    const int M = 2 * a->N;
+    int rc;
+    if (a->v && (rc = ssn_philox_amp_f32(a->seed, a->off_zin, a->v, a->zin, a->amp, (unsigned long long)a->B * M, M, a->bernoulli, stream)))
+        return rc;
+    if ((rc = ssn_stimulus_amp_f32(a->bw, a->con, a->smoothness, a->v ? a->amp : nullptr, a->ext, a->B, a->NB, a->N, stream))) return rc;
+    return ssn_build_w_philox_f32(a->seed, a->off_z, a->J, a->D, a->S, a->W, a->z, a->B, a->N, stream);
+}
 int ssn_stimulus_f32(const float* bw, const float* con, float smoothness, float* ext, int B, int NB, int N, void* stream) {
     SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, nullptr, ext, B, NB, N, (hipStream_t)stream));
     return 0;

@@ -89,6 +89,21 @@ class PhiloxDraw(object):
         return z, W
 
 
+class PhiloxAmp(object):
+    """The heterogeneous-input noise of a forward (z = +-1 or 2 u - 1, and 1 + v z) as a reserved slice of the stream."""
+
+    def __init__(self, seed, offset, shape, tdtype, v, bernoulli):
+        self.seed, self.offset, self.shape, self.tdtype, self.v, self.bernoulli = int(seed), int(offset), tuple(shape), tdtype, v, bernoulli
+
+    def materialize(self):
+        zin = torch.empty(self.shape, device='cuda', dtype=self.tdtype)
+        amp = torch.empty_like(zin)
+        fn = clib.libssnode.ssn_philox_amp_f32 if self.tdtype == torch.float32 else clib.libssnode.ssn_philox_amp_f64
+        clib.check(fn(self.seed, self.offset, self.v.data_ptr(), zin.data_ptr(), amp.data_ptr(), zin.numel(),
+                      int(self.shape[-1]), int(self.bernoulli), clib.stream_ptr()), 'ssn_philox_amp')
+        return zin, amp
+
+
 class DeviceNoise(object):
     """Uniform [0, 1) noise drawn on the device from ONE counter-based stream (Philox4x32-10, `ssn_philox_uniform_*`).
 
@@ -122,6 +137,11 @@ class DeviceNoise(object):
         fn = clib.libssnode.ssn_philox_uniform_f32 if tdtype == torch.float32 else clib.libssnode.ssn_philox_uniform_f64
         clib.check(fn(self.seed, self.take(n), out.data_ptr(), n, clib.stream_ptr()), 'ssn_philox_uniform')
         return out
+
+    def lazy_signs_and_amp(self, local_shape, tdtype, v, bernoulli):
+        """The next `signs_and_amp` draw of this shape, reserved but not generated (`PhiloxAmp`)."""
+        n = int(np.prod(local_shape))
+        return PhiloxAmp(self.seed, self.take(n), tuple(local_shape), tdtype, v, bool(bernoulli))
 
     def signs_and_amp(self, local_shape, tdtype, v, bernoulli):
         """The heterogeneous-input noise z (+-1 or 2 u - 1 from the next `uniform` draw of this shape) and 1 + v * z,
@@ -266,9 +286,8 @@ class TuningCurveGenerator(object):
             noise = dict(model_zs=self._zgen.lazy_uniform((num_models, M, M), self.tdtype))
             if self.heteroin:
                 vs = self._input_variability()
-                zin, amp = self._zgen.signs_and_amp((num_models, M), self.tdtype, vs, self.dist_in == 'bernoulli')
-                noise['model_zs_in'] = zin
-                self._amp_of = (zin, vs, amp)          # picked up by _device_inputs when it is handed this very draw
+                # (reserved like z: _device_inputs generates it together with the stimulus and W, `ssn_gen_inputs_philox_f32`)
+                noise['model_zs_in'] = self._zgen.lazy_signs_and_amp((num_models, M), self.tdtype, vs, self.dist_in == 'bernoulli')
             return noise
         noise = dict(model_zs=rng.rand(num_models, M, M))
         if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720
@@ -304,11 +323,37 @@ class TuningCurveGenerator(object):
             self._cached_upload('con', np.asarray(stimulator_contrasts), self.tdtype)
         amp = None
         self._zin = None
+        if (isinstance(model_zs, PhiloxDraw) and self.tdtype == torch.float32 and torch.is_tensor(bw) and torch.is_tensor(con)
+                and bw.dtype == torch.float32 and con.dtype == torch.float32 and bw.is_contiguous() and con.is_contiguous()
+                and (isinstance(model_zs_in, PhiloxAmp) if self.heteroin else model_zs_in is None)):
+            # device noise: heterogeneous-input signs, stimulus and W in ONE library call (the launches of the branches below, in
+            # their order, without the host between them)
+            import ctypes
+            B, NB = bw.shape
+            N, M = self.num_sites, self.num_neurons
+            W = torch.empty((B, M, M), device='cuda', dtype=torch.float32)
+            z = torch.empty_like(W) if save else None
+            ext = torch.empty((B, NB, M), device='cuda', dtype=torch.float32)
+            zin = amp = None
+            if self.heteroin:
+                zin = torch.empty((B, M), device='cuda', dtype=torch.float32)
+                amp = torch.empty_like(zin)
+            arrs = [(ctypes.c_float * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (self.J, self.D, self.S)]
+            a = clib.GenInputs(seed=model_zs.seed, off_z=model_zs.offset, off_zin=model_zs_in.offset if self.heteroin else 0,
+                               J=arrs[0], D=arrs[1], S=arrs[2], bw=bw.data_ptr(), con=con.data_ptr(), smoothness=float(self.smoothness),
+                               v=model_zs_in.v.data_ptr() if self.heteroin else None,
+                               bernoulli=int(model_zs_in.bernoulli) if self.heteroin else 0, W=W.data_ptr(),
+                               z=z.data_ptr() if save else None, zin=zin.data_ptr() if self.heteroin else None,
+                               amp=amp.data_ptr() if self.heteroin else None, ext=ext.data_ptr(), B=int(B), NB=int(NB), N=int(N))
+            clib.check(clib.libssnode.ssn_gen_inputs_philox_f32(ctypes.byref(a), clib.stream_ptr()), 'ssn_gen_inputs_philox_f32')
+            self._zin = zin
+            self._ext_base = (stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
+                              if self.heteroin and save else None)
+            return ext, z, W
         if self.heteroin:
             vs = self._input_variability()
-            made = self.__dict__.get('_amp_of')
-            if made is not None and made[0] is model_zs_in and made[1] is vs:
-                zin, amp = model_zs_in, made[2]                           # device noise: amp came with the draw
+            if isinstance(model_zs_in, PhiloxAmp):
+                zin, amp = model_zs_in.materialize()                      # device noise outside the one-call path (fp64)
             else:
                 zin = to_device(model_zs_in, self.tdtype)                 # (pinned staging: no wait for queued kernels)
                 amp = 1 + vs[None, :] * zin                               # ssn.py:679-684
