@@ -371,7 +371,7 @@ int ssn_optimizer_step(float *p, const float *g, float *s1, float *s2, long n, c
  * tail[4 + nseg] = {dynamics penalty, rate penalty (from pens64, device double[2] or NULL), loss, accuracy, sums of squares}.
  * The same kernels in the same order as the separate calls: identical results.  xg, xd: device [n][nx]; cond [n][3] shared by
  * the three inputs; eps device [n]; layer_norm / leak as above; opt_s1 / opt_s2 / opt as ssn_optimizer_step; seg_bounds, seg_ws
- * as ssn_segment_sqnorms_f32; acc_dvals device [2 n] scratch; workspace as ssn_critic_*workspace_floats(n + n, n).
+ * as ssn_segment_sqnorms2_f32; acc_dvals device [2 n] scratch; workspace as ssn_critic_*workspace_floats(n + n, n).
  */
 typedef struct ssn_critic_step {
     float *params; const int *dims; const int *layer_norm; int nlayers; float leak;
@@ -460,14 +460,17 @@ int ssn_penalty_means_f32(const float *dyn_row, const float *rate_row, long n, d
                           double *ws, double *out, void *stream);
 int ssn_penalty_means_f64(const double *dyn_row, const double *rate_row, long n, double scale_dyn, double scale_rate,
                           double *ws, double *out, void *stream);
-/* Per-step helpers of the GAN loop.  ssn_segment_sqnorms_f32: out[t] = sum of x[i]^2 over
+/* Per-step helpers of the GAN loop.  ssn_segment_sqnorms2_f32: out[t] = sum of x[i]^2 over
  * bounds[t] <= i < bounds[t + 1] (the per-tensor critic statistics of recorders.py:275-311; bounds: device [n + 1], out:
  * device [n]; ws: device scratch of ssn_segment_sqnorms_ws_doubles(n) doubles; every tensor is cut into chunks summed by
  * their own workgroups in fp64, the chunk sums added in chunk order: the same bits every run).
+ * ssn_segment_sqnorms_f32 keeps the signature this symbol had before the scratch argument existed (same results; the
+ * scratch comes from the stream-ordered allocator): a caller built against the older header still links AND runs right.
  * ssn_interpolate_f32: xp[r][c] = eps[r] xd[r][c] + (1 - eps[r]) xg[r][c], the
  * gradient-penalty points of cwgan.py:476-481 (all device; xd, xg, xp [rows][cols], eps [rows]). */
 long ssn_segment_sqnorms_ws_doubles(int n);
-int ssn_segment_sqnorms_f32(const float *x, const long *bounds, int n, float *out, double *ws, void *stream);
+int ssn_segment_sqnorms2_f32(const float *x, const long *bounds, int n, float *out, double *ws, void *stream);
+int ssn_segment_sqnorms_f32(const float *x, const long *bounds, int n, float *out, void *stream);
 /* Adjoint of the conditional prober's gather tuning_curve[k][s] = time_avg[ids[k]][s][probes[k]] (cwgan.py:91-98):
  * g_ta[b][s][m] = sum of g[k][s] over the samples k with ids[k] == b, probes[k] == m; the whole of g_ta is written.
  * g: device [n][NB], ids / probes: device int64 [n] (0 <= ids < B, 0 <= probes < M), g_ta: device [B][NB][M].

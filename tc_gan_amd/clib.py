@@ -118,7 +118,9 @@ for _name in ('ssn_build_w_f32', 'ssn_build_w_f64', 'ssn_stimulus_f32', 'ssn_sti
 for _name in ('ssn_probe_scatter_f32', 'ssn_probe_scatter_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     getattr(libssnode, _name).restype = c_int
-libssnode.ssn_segment_sqnorms_f32.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+libssnode.ssn_segment_sqnorms2_f32.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+libssnode.ssn_segment_sqnorms2_f32.restype = c_int
+libssnode.ssn_segment_sqnorms_f32.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p]        # (older form: no scratch)
 libssnode.ssn_segment_sqnorms_f32.restype = c_int
 libssnode.ssn_segment_sqnorms_ws_doubles.argtypes = [c_int]
 libssnode.ssn_segment_sqnorms_ws_doubles.restype = c_long
@@ -306,7 +308,7 @@ DECLARED_SYMBOLS = (
     'ssn_critic_input_grad_norm', 'ssn_philox_uniform_f32', 'ssn_philox_uniform_f64',
     'ssn_weight_grad_f32', 'ssn_weight_grad_f64', 'ssn_lu_solve_f32', 'ssn_lu_solve_f64',
     'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
-    'ssn_segment_sqnorms_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
+    'ssn_segment_sqnorms_f32', 'ssn_segment_sqnorms2_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
     'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
     'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_gen_inputs_philox_f32',

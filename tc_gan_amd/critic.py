@@ -114,16 +114,16 @@ class Critic(object):
 
     # -- parameter statistics without a host wait (recorders.py:275-311 logs them after EVERY critic step) --------
     def param_sqnorms_device(self):
-        """Sum of squares per parameter tensor (device tensor, `param_shapes` order; one launch: `ssn_segment_sqnorms_f32`)."""
+        """Sum of squares per parameter tensor (device tensor, `param_shapes` order; two launches: `ssn_segment_sqnorms2_f32`)."""
         self._ensure_segments()
         out = torch.empty(len(self._seg_sizes), device=self.device, dtype=torch.float32)
-        clib.check(libssnode.ssn_segment_sqnorms_f32(self.params.data_ptr(), self._seg_bounds.data_ptr(), int(out.numel()),
-                                                     out.data_ptr(), self._seg_ws.data_ptr(), _stream()),
-                   'ssn_segment_sqnorms_f32')
+        clib.check(libssnode.ssn_segment_sqnorms2_f32(self.params.data_ptr(), self._seg_bounds.data_ptr(), int(out.numel()),
+                                                      out.data_ptr(), self._seg_ws.data_ptr(), _stream()),
+                   'ssn_segment_sqnorms2_f32')
         return out
 
     def _ensure_segments(self):
-        """Bounds of the parameter tensors inside the flat vector (device) and the scratch of `ssn_segment_sqnorms_f32`."""
+        """Bounds of the parameter tensors inside the flat vector (device) and the scratch of `ssn_segment_sqnorms2_f32`."""
         if getattr(self, '_seg_bounds', None) is None:
             sizes = [int(np.prod(shape)) for _, shape in self.param_shapes()]
             self._seg_sizes = np.asarray(sizes, dtype='float64')
@@ -293,6 +293,7 @@ class Critic(object):
             seg_bounds=self._seg_bounds.data_ptr(), nseg=nseg, seg_ws=self._seg_ws.data_ptr(),
             pens64=pens64.data_ptr() if pens64 is not None else None, acc_dvals=dv.data_ptr(), tail=tail.data_ptr())
         clib.check(libssnode.ssn_critic_step_run(ctypes.byref(a), _stream()), 'ssn_critic_step_run')
+        updater.commit_step(opt)          # (only now: a refused launch leaves the step count, hence Adam's bias correction, alone)
         return xp, tail
 
 
@@ -345,16 +346,19 @@ class Updater(object):
 
     def begin_step(self, params):
         """Bookkeeping of one clip-free update made by somebody else's launch (`Critic.step`): the state tensors and the
-        `ssn_opt_params` of this step, with the step count advanced as `__call__` would."""
+        `ssn_opt_params` of this step, numbered step + 1.  The count itself advances in `commit_step`, which the caller
+        runs once its launch has been accepted -- a library call that returns an error leaves the updater where it was."""
         if self._state is None or self._state[0].shape != params.shape:
             self._state = (torch.zeros_like(params), torch.zeros_like(params))
-        self.step += 1
-        o = clib.OptParams(kind=self.kind, step=self.step, clip=0, reserved=0,
+        o = clib.OptParams(kind=self.kind, step=self.step + 1, clip=0, reserved=0,
                            learning_rate=self.learning_rate, beta1=self.cfg['beta1'], beta2=self.cfg['beta2'],
                            epsilon=self.cfg['epsilon'], rho=self.cfg['rho'],
                            reg_l2_penalty=self.reg[0], reg_l1_penalty=self.reg[1],
                            reg_l2_decay=self.reg[2], reg_l1_decay=self.reg[3], clip_lo=0.0, clip_hi=0.0)
         return self._state[0], self._state[1], o
+
+    def commit_step(self, opt):
+        self.step = int(opt.step)
 
     def __call__(self, params, grads, clip=None):
         """In-place update of the flat device tensor `params` from `grads`.  `clip` = (lo, hi): scalars, or arrays of the
@@ -362,7 +366,6 @@ class Updater(object):
         heteroin test pins V_I with V_min = [0, 0], V_max = [1, 0])."""
         if self._state is None or self._state[0].shape != params.shape:
             self._state = (torch.zeros_like(params), torch.zeros_like(params))
-        self.step += 1
         elementwise = None
         if clip is not None and (np.ndim(clip[0]) > 0 or np.ndim(clip[1]) > 0):
             lo = np.broadcast_to(np.asarray(clip[0], dtype='float32').ravel(), (params.numel(),))
@@ -372,7 +375,7 @@ class Updater(object):
                 self._clip_cache = (key, torch.as_tensor(np.array(lo)).to(params.device), torch.as_tensor(np.array(hi)).to(params.device))
             elementwise = self._clip_cache[1:]
             clip = (float(lo.min()), float(hi.max()))
-        o = clib.OptParams(kind=self.kind, step=self.step, clip=int(clip is not None), reserved=0,
+        o = clib.OptParams(kind=self.kind, step=self.step + 1, clip=int(clip is not None), reserved=0,
                            learning_rate=self.learning_rate, beta1=self.cfg['beta1'], beta2=self.cfg['beta2'],
                            epsilon=self.cfg['epsilon'], rho=self.cfg['rho'],
                            reg_l2_penalty=self.reg[0], reg_l1_penalty=self.reg[1],
@@ -381,5 +384,6 @@ class Updater(object):
         clib.check(libssnode.ssn_optimizer_step(params.data_ptr(), grads.data_ptr(), self._state[0].data_ptr(),
                                                 self._state[1].data_ptr(), params.numel(), ctypes.byref(o), _stream()),
                    'ssn_optimizer_step')
+        self.step += 1                    # (after the launch was accepted)
         if elementwise is not None:
             torch.minimum(torch.maximum(params, elementwise[0], out=params), elementwise[1], out=params)

@@ -753,7 +753,7 @@ int ssn_critic_step_run(const ssn_critic_step* a, void* stream) {
     if ((rc = ssn_optimizer_step(a->params, a->grads, a->opt_s1, a->opt_s2, nparams, a->opt, stream))) return rc;
     if ((rc = ssn_critic_accuracy(a->params, a->dims, a->layer_norm, a->nlayers, a->leak, a->xg, a->cond, a->xd, a->cond, n, n,
                                   a->hide_cell_type, a->tail + 3, a->acc_dvals, a->workspace, a->precision, stream))) return rc;
-    if (a->nseg > 0 && (rc = ssn_segment_sqnorms_f32(a->params, a->seg_bounds, a->nseg, a->tail + 4, a->seg_ws, stream))) return rc;
+    if (a->nseg > 0 && (rc = ssn_segment_sqnorms2_f32(a->params, a->seg_bounds, a->nseg, a->tail + 4, a->seg_ws, stream))) return rc;
     SSN_TRY(ssn::launch_step_head(a->pens64, a->stats, a->tail, (hipStream_t)stream));
     return 0;
 }
@@ -1066,9 +1066,22 @@ int ssn_probe_scatter_f64(const double* g, const long* ids, const long* probes, 
     return 0;
 }
 long ssn_segment_sqnorms_ws_doubles(int n) { return ssn::segment_sqnorms_ws_doubles(n); }
-int ssn_segment_sqnorms_f32(const float* x, const long* bounds, int n, float* out, double* ws, void* stream) {
-    if (n < 0 || (n > 0 && (!x || !bounds || !out || !ws))) { g_last_error = "ssn_segment_sqnorms: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+int ssn_segment_sqnorms2_f32(const float* x, const long* bounds, int n, float* out, double* ws, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !bounds || !out || !ws))) { g_last_error = "ssn_segment_sqnorms2: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::launch_segment_sqnorms(x, bounds, n, out, ws, (hipStream_t)stream));
+    return 0;
+}
+// The round-2 signature (no scratch argument), kept under its name so that a caller built against the older header still
+// gets what it asked for: the scratch comes from the stream-ordered allocator and goes back behind the two launches.
+int ssn_segment_sqnorms_f32(const float* x, const long* bounds, int n, float* out, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !bounds || !out))) { g_last_error = "ssn_segment_sqnorms: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    if (n == 0) return 0;
+    double* ws = nullptr;
+    SSN_TRY(hipMallocAsync((void**)&ws, sizeof(double) * (size_t)ssn::segment_sqnorms_ws_doubles(n), (hipStream_t)stream));
+    const hipError_t e = ssn::launch_segment_sqnorms(x, bounds, n, out, ws, (hipStream_t)stream);
+    const hipError_t f = hipFreeAsync(ws, (hipStream_t)stream);
+    SSN_TRY(e);
+    SSN_TRY(f);
     return 0;
 }
 int ssn_interpolate_f32(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, void* stream) {

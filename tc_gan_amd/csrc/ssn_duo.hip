@@ -1144,7 +1144,12 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         }
         if constexpr (ED) dm = fmaxf(dm, dme);
         const float rs = live ? duo_pow2(bexp) : 0.f;
-        if (!(dm * rs < 65504.f)) delta[0] = __builtin_nanf("");                   // outgrew the lagged scale: poison, do not clamp
+        if (!(dm * rs < 65504.f)) {                                                // outgrew the lagged scale: poison, do not clamp
+            delta[0] = __builtin_nanf("");
+            // ... and say so where the host can count it: the draw's hand-over word becomes NaN (as a bit pattern it is above
+            // every |delta|, so the atomic maximum keeps it)
+            if (a.dmax) atomicMax(a.dmax + b, 0x7fc00000u);
+        }
 #pragma unroll
         for (int tf = 0; tf < NTF; ++tf) {
             const int rt = RT0 + tf;

@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <type_traits>
+#include <atomic>
 #include "ssn_host.h"
 
 // Ablation builds for timing only (tools/ab_one.sh <tag> ssn_gw -DGW_ABLATE=n; results are wrong): 1 no MFMAs and no operand
@@ -353,12 +354,17 @@ template <int NT, bool F16>
 static hipError_t gw_launch_split(const float* delta, const float* traj, float* gW, int B, long K, int M, const unsigned* dmax,
                                   float xmax, hipStream_t st) {
     const size_t lds = 2 * (size_t)GwFmt<F16>::BUFB;     // 150528 (bf16 x 3) / 100352 (fp16 x 2) bytes: one workgroup per CU
-    static bool once = false;
-    if (!once) {
+    // The dynamic-LDS limit is an attribute of the function ON THE CURRENT DEVICE: one flag per device (a process that
+    // drives several cards launches this kernel on each), set after the attribute call has succeeded; two threads racing
+    // on a device both make the (idempotent) call.
+    static std::atomic<bool> done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return hipErrorInvalidDevice;
+    if (dev >= 64 || !done[dev].load(std::memory_order_acquire)) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gw_split_kernel<NT, F16>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        once = true;
+        if (dev < 64) done[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((gw_split_kernel<NT, F16>), dim3(B), dim3(512), lds, st, delta, traj, gW, K, M, dmax, xmax);
     return hipGetLastError();

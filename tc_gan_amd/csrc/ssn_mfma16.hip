@@ -844,7 +844,10 @@ __global__ void __launch_bounds__(512, 2) gen_backward_split_kernel(GenBwdArgs<f
             // step is poisoned instead: NaN into the hand-over and into the delta stream, so that the gradient is NaN like
             // the fp32 kernels' overflow and the drivers' NaN guards see it.
             const float rs = live[g] ? __builtin_bit_cast(float, (unsigned)(127 + bexp) << 23) : 0.f;
-            if (!(dm * rs < 65504.f)) delta[0] = __builtin_nanf("");
+            if (!(dm * rs < 65504.f)) {
+                delta[0] = __builtin_nanf("");
+                if (a.dmax) atomicMax(a.dmax + b, 0x7fc00000u);       // the draw's hand-over word says "poisoned" (NaN; host side counts them)
+            }
             if (b_live) split3_store(delta, (fv2){rs, rs}, (fv2){rs, rs}, (unsigned)(size_t)(LdsU2)(bbuf + g * S::BB) + b_off);
         }
         bused[g] = bexp;

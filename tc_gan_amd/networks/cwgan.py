@@ -479,6 +479,14 @@ class ConditionalBPTTWassersteinGAN(object):
                 self._gparams_host[name] = new.copy()
                 off += n
             info.gen_loss = float(host[-1])
+            if not np.isfinite(host).all():
+                # (the drivers' NaN guards end the run; say why when it was the fp16 adjoint's range and not the model)
+                bad = self.gen.poisoned_draws()
+                if bad:
+                    logger.warning('generator step %s: %d of %d draws have an adjoint that grew by more than 2^8 within one '
+                                   'Euler step -- beyond the lagged scale of the fp16-split sweep, so their gradient is NaN; '
+                                   '--gen-kernel mfma-fp32 has no such limit', getattr(info, 'gen_step', '?'), bad,
+                                   gen_out.prober_tuning_curve.shape[0] // max(self.probes_per_model, 1))
         info.gen_forward_time = self.gen_forward_watch.sum()
         info.gen_train_time = self.gen_train_watch.sum()
         info.gen_time = info.gen_train_time + info.gen_forward_time

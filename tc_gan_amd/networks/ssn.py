@@ -443,6 +443,8 @@ class TuningCurveGenerator(object):
         res = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
                                   rate_cost / fwd['n_rate'], sv['gp'], want_g_ext=self.heteroin, want_dmax=True)
         delta, g_ext, dmax = res if self.heteroin else (res[0], None, res[1])
+        # (kept for `poisoned_draws`: a draw whose adjoint outgrew the fp16 sweep's lagged scale has NaN here)
+        self.last_dmax = dmax
         # (fp16 two-part form of dL/dW where the sweep handed over max |delta| per draw and the rates are bounded)
         gW = genops.weight_grad(delta, fwd['traj'], dmax=dmax, xmax=genops.rate_bound(sv['gp']))
         gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S, as_tensor=as_tensor)
@@ -459,6 +461,13 @@ class TuningCurveGenerator(object):
                 grads['V'] = gv if self.ssn_type == 'heteroin' else np.asarray(gv.sum())
         self._saved = None
         return grads
+
+    def poisoned_draws(self):
+        """Number of draws of the last `backward` whose adjoint outgrew the lagged power-of-two scale of the fp16-split
+        sweeps (their gradient is NaN by construction, csrc/ssn_duo.hip `gen_backward_duo`); 0 for the fp32 sweeps, which
+        have no such limit.  Synchronises: for the failure path of the loop, not for every step."""
+        dmax = getattr(self, 'last_dmax', None)
+        return 0 if dmax is None else int(torch.isnan(dmax).sum())
 
     def prepare(self):
         """Nothing to compile (the reference forces Theano compilation here)."""

@@ -69,7 +69,10 @@ def add_bptt_common_options(parser):
                              'the library\'s choice -- for float32 with >= 4 bandwidths and enough models the fp16-split '
                              'matrix-core kernels (W and the state enter the products with 23 significant bits, exact '
                              'products, fp32 accumulation: within the fp32 kernels\' own distance from fp64); mfma-fp32 or '
-                             'tile: fp32 operands (the reference\'s floatX arithmetic); the others name one kernel')
+                             'tile: fp32 operands (the reference\'s floatX arithmetic); the others name one kernel.  '
+                             'The fp16-split adjoint scales each step by the previous step\'s largest |delta|; a draw whose '
+                             'adjoint grows more than 2^8 within one step makes its gradient NaN (never a clamped finite value) '
+                             'and the run logs how many draws did -- mfma-fp32 has no such limit')
     parser.add_argument('--z-device-seed', default=None, type=int,
                         help='Draw z on the device (Philox4x32-10, one stream sharded over the ranks) instead of the '
                              'host RandomState (new; fast mode, and the mode to use for multi-GPU runs)')

@@ -196,6 +196,8 @@ def gen_matlab():
         k=float(mpar['k'][0, 0]),
         n=float(mpar['n'][0, 0]),
         E_Tuning=mp['E_Tuning'],
+        # the inhibitory block of the same solve (the reference's own test reads only E_Tuning; same file, same layout)
+        I_Tuning=mp['I_Tuning'],
     )
 
 

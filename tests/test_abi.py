@@ -34,6 +34,18 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert clib.libssnode.ssn_abi_version() == 1
 
 
+def test_dynamic_symbol_table_is_exactly_the_header():
+    """A drop-in for a ctypes-loaded C library exports its header and nothing else: `nm -D --defined-only` of the product
+    library (linked under the version script csrc/gen_export_map.py writes from the header) lists the declared functions --
+    the reference's 8 (`nm -D` of a build of tc_gan/ext/ssnode.c) plus the additive batched ABI -- and no C++ launch
+    template, kernel stub or HIP registration object."""
+    import subprocess
+    so = os.path.join(ROOT, 'tc_gan_amd', 'ext', 'libssnode.so')
+    out = subprocess.check_output(['nm', '-D', '--defined-only', so]).decode()
+    exported = sorted(line.split()[-1].split('@')[0] for line in out.splitlines() if line.strip())
+    assert exported == _declared_in_header()
+
+
 def test_fast_path_table():
     from tc_gan_amd.clib import libssnode
     assert libssnode.ssn_solver_fast_path(200, 1, 4) == 2      # tile kernel

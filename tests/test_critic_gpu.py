@@ -371,7 +371,7 @@ def test_layer_by_layer_path_still_covers_small_widths():
 
 
 def test_step_helpers_segment_sqnorms_and_interpolate():
-    """`ssn_segment_sqnorms_f32` (per-tensor critic statistics, recorders.py:275-311) and `ssn_interpolate_f32`
+    """`ssn_segment_sqnorms2_f32` (per-tensor critic statistics, recorders.py:275-311) and `ssn_interpolate_f32`
     (gradient-penalty points, cwgan.py:476-481) against their numpy definitions."""
     from tc_gan_amd.critic import Critic
     crit = Critic(8, [16, 32, 8], normalization='layer', seed=3)
@@ -387,6 +387,12 @@ def test_step_helpers_segment_sqnorms_and_interpolate():
     np.testing.assert_allclose(g1, want, rtol=1e-6)
     for _ in range(3):
         np.testing.assert_array_equal(big.param_sqnorms_device().cpu().numpy(), g1)
+    # the symbol's older signature (no scratch argument; include/ssnode_mi355x.h): same bits
+    from tc_gan_amd import clib
+    old = torch.empty(len(g1), device='cuda', dtype=torch.float32)
+    clib.check(clib.libssnode.ssn_segment_sqnorms_f32(big.params.data_ptr(), big._seg_bounds.data_ptr(), len(g1), old.data_ptr(),
+                                                      clib.stream_ptr()), 'ssn_segment_sqnorms_f32')
+    np.testing.assert_array_equal(old.cpu().numpy(), g1)
     rs = np.random.RandomState(0)
     eps, xd, xg = rs.rand(37, 1).astype('float32'), rs.randn(37, 8).astype('float32'), rs.randn(37, 8).astype('float32')
     xp = crit.interpolate(torch.as_tensor(eps).cuda(), torch.as_tensor(xd).cuda(), torch.as_tensor(xg).cuda()).cpu().numpy()

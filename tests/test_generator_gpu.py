@@ -117,6 +117,85 @@ def test_bptt_gradients_vs_oracle(io_type, N, B, NB, dtype, kernel):
         np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * np.abs(want).max())
 
 
+_HORIZON_ORACLE = {}
+
+
+def _horizon_oracle(shape):
+    """fp64 autograd of oracle/gan_torch.py at a production horizon (cached per shape: seconds on the CPU)."""
+    if shape in _HORIZON_ORACLE:
+        return _HORIZON_ORACLE[shape]
+    if shape == 'c3':          # BASELINE config 3: 2N = 200, 8 stimuli, seqlen 1200 / skip 1000, tau_E = 10
+        N, B, NB, T, skip, theta, gen, v = 100, 2, 8, 1200, 1000, 5.0, dict(GEN), None
+        costs = (1.0, 0.01)
+    else:                      # the paper's run (scripts/fig4/gan/run.json): 2N = 202, tau_E = 2, 240 / 200, deg-heteroin
+        N, B, NB, T, skip, theta, gen, v = 101, 3, 8, 240, 200, 5.0, dict(GEN, tau_E=2.), 0.1
+        costs = (0.0, 100.0)
+    jds, z, bws, con = _problem(N, B, NB, 11 * N + NB, T, skip, theta)
+    rs = np.random.RandomState(17)
+    G = rs.randn(B, NB, 2 * N) * (rs.rand(B, NB, 2 * N) < 0.1)
+    zin = rs.choice(2, (B, 2 * N)) * 2.0 - 1.0
+    J, D, S = (og.t64(jds[k]).clone().requires_grad_(True) for k in 'JDS')
+    V = None if v is None else og.t64(v).clone().requires_grad_(True)
+    base = og.stimulus(bws, con, P['smoothness'], N)
+    ext_o = base if v is None else (1 + V * og.t64(zin)[:, None, :]) * base             # networks/ssn.py:679-686
+    W_o = og.make_W(og.t64(z), J, D, S, N)
+    W_o.retain_grad()
+    ta_o, dyn_o, rate_o = og.euler_ssn(W_o, ext_o, seqlen=T, skip_steps=skip, rate_penalty_threshold=theta, **gen)
+    loss = (og.t64(G) * ta_o).sum() + costs[0] * dyn_o + costs[1] * rate_o
+    loss.backward()
+    res = dict(N=N, B=B, NB=NB, T=T, skip=skip, theta=theta, gen=gen, v=v, costs=costs, jds=jds, z=z, bws=bws, con=con,
+               G=G, zin=zin, gW=W_o.grad.numpy(), gJ=J.grad.numpy(), gD=D.grad.numpy(), gS=S.grad.numpy(),
+               gV=None if v is None else float(V.grad), ta=ta_o.detach().numpy())
+    _HORIZON_ORACLE[shape] = res
+    return res
+
+
+@pytest.mark.parametrize('shape,kernel', [('c3', 2), ('c3', 6), ('c3', 8), ('c3', 4), ('paper', 5), ('paper', 2), ('paper', 8)])
+def test_bptt_gradients_vs_oracle_at_production_horizons(shape, kernel):
+    """`test_bptt_gradients_vs_oracle` stops at 50 steps; the adjoint of the fp16-split sweeps carries a LAGGED power-of-two
+    scale and hands max |delta| per draw to the fp16 form of dL/dW -- both are only exercised by a long sweep through the
+    transient (delta grows by orders of magnitude between the penalty window and the first steps).  Here: the C3 horizon
+    (2N = 200, 8 stimuli, seqlen 1200 / skip 1000) and the paper's (2N = 202, tau_E = 2, 240 / 200, deg-heteroin input), a few
+    draws, dL/dW itself AND dL/d(J, D, S[, V]) against fp64 autograd of oracle/gan_torch.py (reference semantics:
+    networks/wgan.py:236-242, networks/ssn.py:566-576, 598-633), on both dL/dW forms (three bf16 parts; two fp16 parts
+    under the handed-over bound).  Tolerances: dL/dW relative to the largest element of the draw 1e-4 (measured: see
+    DESIGN 1); parameter gradients 2e-3 of the largest (fp32 sums over 2.4e6 products)."""
+    from tc_gan_amd import genops, stimuli
+    from tc_gan_amd import weight_gen
+    o = _horizon_oracle(shape)
+    N, B, NB = o['N'], o['B'], o['NB']
+    jds = o['jds']
+    zt = torch.as_tensor(o['z']).to('cuda', torch.float32)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], zt, dtype='float32')
+    base = stimuli.stimulus_batch(o['bws'], o['con'], P['smoothness'], N, dtype='float32')
+    zin = torch.as_tensor(o['zin']).to('cuda', torch.float32)
+    ext = base if o['v'] is None else ((1 + o['v'] * zin)[:, None, :] * base).contiguous()
+    gp = genops.make_gen_params(seqlen=o['T'], skip_steps=o['skip'], rate_penalty_threshold=o['theta'], kernel=kernel, **o['gen'])
+    out = genops.gen_forward(W, ext, gp, save=True)
+    np.testing.assert_allclose(out['time_avg'].cpu().numpy(), o['ta'], rtol=1e-4, atol=1e-5)
+    Gd = torch.as_tensor(o['G']).to('cuda', torch.float32)
+    delta, g_ext, dmax = genops.gen_backward(W, out['traj'], out['df'], Gd, o['costs'][0] / out['n_dyn'],
+                                             o['costs'][1] / out['n_rate'], gp, want_g_ext=True, want_dmax=True)
+    assert (dmax is not None) == (kernel in (4, 5, 6, 8))
+    forms = [dict(kernel=2)] + ([dict(dmax=dmax, xmax=genops.rate_bound(gp))] if dmax is not None else [])
+    worst = {}
+    for form in forms:
+        gW = genops.weight_grad(delta, out['traj'], **form)
+        got = gW.cpu().numpy().astype('float64')
+        assert np.isfinite(got).all()
+        err = np.abs(got - o['gW']).reshape(B, -1).max(axis=1) / np.abs(o['gW']).reshape(B, -1).max(axis=1)
+        worst['bf16x3' if 'kernel' in form else 'fp16x2'] = err.max()
+        assert err.max() < 1e-4, (form.keys(), err)
+        gJ, gD, gS = genops.jds_grad(gW, zt, jds['J'], jds['D'], jds['S'])
+        for g, w in ((gJ, o['gJ']), (gD, o['gD']), (gS, o['gS'])):
+            np.testing.assert_allclose(g, w, rtol=2e-3, atol=2e-3 * np.abs(w).max())
+    if o['v'] is not None:
+        # ext = (1 + V z_in) base  ->  dL/dV = sum g_ext * base * z_in (networks/ssn.py:679-686, V one scalar: 'deg-heteroin')
+        gV = float((g_ext.double() * base.double() * zin.double()[:, None, :]).sum())
+        np.testing.assert_allclose(gV, o['gV'], rtol=2e-3)
+    print('horizon %s kernel %d: max |dL/dW - fp64| / max |dL/dW| = %s' % (shape, kernel, worst))
+
+
 @pytest.mark.parametrize('num_sites,batchsize,seqlen,tol', [(10, 1, 4000, 5e-4), (10, 2, 4000, 5e-4),
                                                             (100, 3, 10000, 1e-4)])
 def test_compare_with_ssnode(num_sites, batchsize, seqlen, tol):
@@ -457,6 +536,35 @@ def test_split_kernels_propagate_nan_and_terminate():
         G = torch.ones((B, NB, 2 * N), device='cuda', dtype=torch.float32)
         d = genops.gen_backward(W, out['traj'], out['df'], G, 1e-3, 1e-3, gp).cpu().numpy()
         assert np.isfinite(d[0]).all() and np.isnan(d[1]).any()
+
+
+@pytest.mark.parametrize('kernel', [4, 5, 8])
+def test_split_adjoint_marks_a_draw_that_outgrows_its_lagged_scale(kernel):
+    """The fp16-split sweeps scale step tau by max |delta| of step tau + 1; a delta that grows by more than 2^8 within ONE
+    step cannot be represented and is poisoned (NaN), never clamped.  Here f' of one draw is multiplied by 1e5 at one step:
+    that draw's delta, dL/dW and hand-over word `dmax` come out NaN (`TuningCurveGenerator.poisoned_draws` counts those
+    words), the other draw is untouched, and the fp32 sweep (kernel 2) carries the large finite value instead."""
+    from tc_gan_amd import genops, stimuli, weight_gen
+    N, B, NB, T, skip = 100, 2, 8, 60, 40
+    jds, z, bws, con = _problem(N, B, NB, 3, T, skip, 2.0)
+    W = weight_gen.generate_weight_batch(N, jds['J'], jds['D'], jds['S'], z, dtype='float32')
+    ext = stimuli.stimulus_batch(bws, con, P['smoothness'], N, dtype='float32')
+    G = torch.ones((B, NB, 2 * N), device='cuda', dtype=torch.float32)
+    res = {}
+    for kern in (2, kernel):
+        gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=kern, **GEN)
+        out = genops.gen_forward(W, ext, gp, save=True)
+        out['df'][1, :, 30, :] *= 1e5
+        d, dmax = genops.gen_backward(W, out['traj'], out['df'], G, 1e-3, 1e-3, gp, want_dmax=True)
+        gW = genops.weight_grad(d, out['traj'], **({} if dmax is None else dict(dmax=dmax, xmax=genops.rate_bound(gp))))
+        res[kern] = (d.cpu().numpy(), None if dmax is None else dmax.cpu().numpy(), gW.cpu().numpy())
+    d32, _, gW32 = res[2]
+    assert np.isfinite(d32).all() and np.isfinite(gW32).all() and np.abs(d32[1]).max() > 1e3 * np.abs(d32[0]).max()
+    d, dmax, gW = res[kernel]
+    assert np.isfinite(d[0]).all() and np.isfinite(gW[0]).all() and np.isfinite(dmax[0])
+    np.testing.assert_allclose(gW[0], gW32[0], rtol=1e-3, atol=1e-5 * np.abs(gW32[0]).max())
+    assert np.isnan(dmax[1]) and np.isnan(d[1]).any() and np.isnan(gW[1]).any()
+    assert int(np.isnan(dmax).sum()) == 1
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'float64'])

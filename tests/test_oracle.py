@@ -119,6 +119,10 @@ def test_tuning_curve_vs_matlab_known_answer(io_type):
     center, ofs = N // 2, len(ET) // 2
     actual = np.array([x[center - ofs:center + ofs + 1] for x in fps[0]]).T
     np.testing.assert_allclose(actual, ET, rtol=2e-3)
+    # the inhibitory block of the same MATLAB solve (`I_Tuning` lies beside `E_Tuning` in the reference's asset; its own
+    # test does not read it): neurons N + centre - 1 .. N + centre + 1, measured 5.9e-4
+    actual_i = np.array([x[N + center - ofs:N + center + ofs + 1] for x in fps[0]]).T
+    np.testing.assert_allclose(actual_i, g['I_Tuning'], rtol=2e-3)
 
 
 def test_oracle_matches_reference_build_live(oracle_lib, reference_lib):

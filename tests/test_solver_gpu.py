@@ -346,6 +346,9 @@ def test_tuning_curve_vs_matlab_known_answer_gpu(io_type):
         center, ofs = N // 2, len(ET) // 2
         actual = np.array([x[center - ofs:center + ofs + 1] for x in fps]).T
         np.testing.assert_allclose(actual, ET, rtol=2e-3)
+        # inhibitory block, same asset (`I_Tuning`; see tests/test_oracle.py)
+        actual_i = np.array([x[N + center - ofs:N + center + ofs + 1] for x in fps]).T
+        np.testing.assert_allclose(actual_i, g['I_Tuning'], rtol=2e-3)
 
 
 def test_find_fixed_points_rejection_semantics_vs_oracle():
