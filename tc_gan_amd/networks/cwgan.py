@@ -266,6 +266,8 @@ class ConditionalBPTTWassersteinGAN(object):
         self._predrawn = None          # host draws of the NEXT critic step, made early (see train_generator)
         self._gparams_host = {}        # host values the device copies of the generator parameters correspond to
         self._rng_before_predraw = None
+        self._acc_carry = None         # data-parallel runs: this rank's accuracy of the last critic step, waiting for a collective
+        self._arrived_with_gen = None
         self.reducer = GradientAllReducer()
         assert self.probes_per_model < gen.num_neurons
         assert num_models % self.reducer.world == 0, 'num_models must be divisible by the number of ranks'
@@ -362,6 +364,7 @@ class ConditionalBPTTWassersteinGAN(object):
         xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
         ctx.skipped = False
         ctx.snapshot = None
+        ctx.acc_deferred = False
         if not self.reducer.on and self.disc_rate_penalty_bound <= 0 and xg.dtype == torch.float32:
             # single process, no skip rule to honour: the whole step is one library call (same kernels, same order)
             with self.disc_train_watch:
@@ -376,13 +379,24 @@ class ConditionalBPTTWassersteinGAN(object):
             # speculatively and rolled back in `_read_disc` (which learns the value before the next update is queued)
             # in the rare case that the bound was exceeded.
             ctx.snapshot = self.disc_updater.snapshot(self.disc.params) if self.disc_rate_penalty_bound > 0 else None
+            # ONE collective per update: gradients, loss statistics, the two penalties -- and, riding along, the
+            # accuracy of the critic as the PREVIOUS step left it.  That number (cwgan.py:505-507) is a recorded diagnostic
+            # of the updated critic, so it only exists after this step's collective has gone; instead of its own one-float
+            # all-reduce it travels in the next flat buffer (the next critic step's, or the generator's), and the step's
+            # record is handed to the driver once it has arrived (`_single_gen_step`).
+            carry = self._acc_carry if self.reducer.on else None
             with self.disc_train_watch:
                 stats = self.disc.loss_grad(xg, cd, xd, cd, xp, cd, self.lipschitz_cost)
-                self.reducer.mean_(self.disc.grads, stats, pens)      # ONE collective: gradients, loss statistics, the two penalties
+                self.reducer.mean_(self.disc.grads, stats, pens, *([carry] if carry is not None else []))
                 self.disc_updater(self.disc.params, self.disc.grads)
             acc = self.disc.accuracy_device(xg, cd, xd, cd)
-            self.reducer.mean_(acc)
-            tail = torch.cat([pens, stats[3:4], acc, self.disc.param_sqnorms_device()])
+            if self.reducer.on:
+                self._acc_carry = acc            # this rank's share; averaged by the next collective
+                ctx.acc_deferred = True
+                arrived = carry if carry is not None else torch.full_like(acc, float('nan'))
+                tail = torch.cat([pens, stats[3:4], acc, self.disc.param_sqnorms_device(), arrived])
+            else:
+                tail = torch.cat([pens, stats[3:4], acc, self.disc.param_sqnorms_device()])
         # `tail`: the four scalars of the step [dynamics penalty, rate penalty, loss, accuracy] + the per-tensor sums of squares
         # of the updated critic (disc_param_stats); pinned buffers and events come from a small ring (a step is read before the
         # ring comes round: at most two steps are in flight)
@@ -400,6 +414,10 @@ class ConditionalBPTTWassersteinGAN(object):
         if ctx.event is not None:
             ctx.event.synchronize()
         host = ctx.host.numpy().copy()               # (the pinned buffer goes back to the ring)
+        ctx.arrived_accuracy = None
+        if ctx.acc_deferred:
+            # last word: the job-wide accuracy of the PREVIOUS critic step, which travelled in this step's collective
+            ctx.arrived_accuracy, host = float(host[-1]), host[:-1]
         if ctx.snapshot is not None and float(host[1]) > self.disc_rate_penalty_bound:
             self.disc_updater.restore(self.disc.params, ctx.snapshot)            # the skipped step of cwgan.py:493-498
             ctx.skipped = True
@@ -415,12 +433,27 @@ class ConditionalBPTTWassersteinGAN(object):
         info.gen_time = ctx.gen_time
         info.dynamics_penalty, info.rate_penalty = float(host[0]), float(host[1])
         info.disc_loss, info.accuracy = float(host[2]), float(host[3])
+        info.accuracy_pending = bool(ctx.acc_deferred and not ctx.skipped)   # (host[3] is this rank's share until the mean arrives)
         info.disc_time = np.nan if ctx.skipped else ctx.disc_time
         return info
 
+    def _flush_accuracy(self):
+        """The job-wide mean of the accuracy still waiting for a collective, through one of its own (outside the loop's
+        schedule: `train_discriminator` called by hand, the end of a run)."""
+        carry, self._acc_carry = self._acc_carry, None
+        if carry is None:
+            return None
+        self.reducer.mean_(carry)
+        return float(carry[0])
+
     def _finish_disc(self, info, ctx):
+        self._acc_carry = None
         self._launch_disc(ctx)
-        return self._read_disc(info, ctx)
+        info = self._read_disc(info, ctx)
+        if info.accuracy_pending:
+            info.accuracy, info.accuracy_pending = self._flush_accuracy(), False
+        self._acc_carry = None
+        return info
 
     def train_discriminator(self, info):
         return self._finish_disc(info, self._prepare_disc())
@@ -456,7 +489,9 @@ class ConditionalBPTTWassersteinGAN(object):
             loss = (-dmean.to(torch.float64) + self.dynamics_cost * gen_out.model_dynamics_penalty
                     + self.rate_cost * gen_out.model_rate_penalty).reshape(1).to(torch.float32)
             grads = torch.cat([gdict[name].reshape(-1) for name in self._pnames]).to(torch.float32)
-            self.reducer.mean_(grads, loss)
+            # (the accuracy of the last critic step rides in the generator's collective: see `_launch_disc`)
+            carry, self._acc_carry = (self._acc_carry if self.reducer.on else None), None
+            self.reducer.mean_(grads, loss, *([carry] if carry is not None else []))
             # Everything up to here is queued without a host wait; the device copies of the parameters are the
             # working values (re-uploaded only when somebody changed the generator's attributes from outside), and ONE
             # device-to-host copy at the end returns the new parameter values together with the loss.
@@ -469,7 +504,11 @@ class ConditionalBPTTWassersteinGAN(object):
                     p.copy_(to_device(np.ascontiguousarray(value, dtype='float32').ravel()))
                 self.gen_updaters[name](p, grads[off:off + p.numel()], clip=self.param_bounds[name])
                 off += p.numel()
-            host = torch.cat([self._gparams[name] for name in self._pnames] + [loss]).cpu().numpy()
+            host = torch.cat([self._gparams[name] for name in self._pnames] + [loss]
+                             + ([carry.to(torch.float32)] if carry is not None else [])).cpu().numpy()
+            self._arrived_with_gen = None
+            if carry is not None:
+                self._arrived_with_gen, host = float(host[-1]), host[:-1]
             off = 0
             for name in self._pnames:
                 shape = np.shape(getattr(self.gen, name))
@@ -499,6 +538,8 @@ class ConditionalBPTTWassersteinGAN(object):
         self.disc_train_watch = StopWatch()
         ctx = self._prepare_disc() if critic_iters > 0 else None
         prepared_gen = None
+        self._acc_carry = None
+        held = None            # data-parallel runs: the record of the step whose job-wide accuracy is still on its way
         for disc_step in range(critic_iters):
             last = disc_step + 1 == critic_iters
             # queue this step's critic update, THEN do the host work of the next step and queue its forward, and only
@@ -509,15 +550,29 @@ class ConditionalBPTTWassersteinGAN(object):
                 prepared_gen = self._prepare_gen(ctx.batch)    # reuses the LAST critic batch's conditions (cwgan.py:535-539)
             info = Namespace(is_discriminator=True, gen_step=gen_step, disc_step=disc_step)
             info = self._read_disc(info, ctx)
-            yield info
+            if held is not None:
+                if held.accuracy_pending:
+                    held.accuracy, held.accuracy_pending = ctx.arrived_accuracy, False
+                yield held
+                held = None
+            if info.accuracy_pending:
+                held = info        # same order of records, one collective later
+            else:
+                if ctx.acc_deferred:
+                    self._acc_carry = None      # (a skipped step has no accuracy: nothing to carry)
+                yield info
             ctx = nxt
         disc_info = info
         batch = info.batch
         info = Namespace(is_discriminator=False, gen_step=gen_step)
         info = self.train_generator(info, batch, prepared_gen)
+        if held is not None:
+            held.accuracy, held.accuracy_pending = self._arrived_with_gen, False
         logger.debug('[Loss] Acc: %-9.3g D: %-9.3g G: %-9.3g [Time] Fwd: %.3g D: %.3g G: %.3g',
                      disc_info.accuracy, disc_info.disc_loss, info.gen_loss, self.gen_forward_watch.mean(),
                      self.disc_train_watch.mean(), self.gen_train_watch.mean())
+        if held is not None:
+            yield held
         yield info
 
     def learning(self, start_step=0):

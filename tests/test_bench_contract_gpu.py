@@ -45,7 +45,7 @@ def test_default_workload_line():
     rc = ex.pop('c3paper_rccl1')                  # the paper-shape loop as the single rank of an RCCL group
     assert 'error' not in rc, rc
     assert rc['dist_backend'] == 'nccl' and rc['world_size'] == 1 and rc['ms_per_step'] > 0
-    assert rc['phases']['collectives_per_iteration'] >= 2 and rc['phases']['allreduce_ms']['max'] > 0
+    assert rc['phases']['collectives_per_iteration'] == 6 and rc['phases']['allreduce_ms']['max'] > 0    # 5 critic + 1 generator update
     assert rc['last_gen_loss'] == ex['c3paper']['last_gen_loss']            # mean over one rank = identity, bit for bit
     assert d['dist_backend'] is None and d['world_size'] == 1              # (the line itself is a plain single process)
     for name, e in ex.items():
@@ -101,7 +101,8 @@ def test_single_rank_group_runs_the_collectives_on_rccl():
     d = json.loads(out[0])
     assert d['dist_backend'] == 'nccl' and d['world_size'] == 1 and d['n_gpus'] == 1
     ph = d['phases']
-    assert ph['collectives_per_iteration'] >= 2 and ph['allreduce_ms']['max'] > 0
+    # ONE collective per update: five critic updates and one generator update per iteration
+    assert ph['collectives_per_iteration'] == 6 and ph['allreduce_ms']['max'] > 0
     plain = _bench('--workload', 'c3paper', '--steps', '3', '--warmup', '1')
     assert plain['dist_backend'] is None and 'phases' not in plain
     assert d['last_gen_loss'] == plain['last_gen_loss']

@@ -33,16 +33,21 @@ def _train(n_gen_steps=2, z_device_seed=None):
     data = np.random.RandomState(4).rand(9, 4 * 2 * 2 * 2) * 10
     gan.set_dataset(data)
     it = gan.learning()
-    losses = []
+    losses, accs, order = [], [], []
     done = 0
     while done < n_gen_steps:
         info = next(it)
         if info.is_discriminator:
             losses.append(info.disc_loss)
+            accs.append(info.accuracy)
+            order.append((info.gen_step, info.disc_step))
         else:
             losses.append(info.gen_loss)
+            order.append((info.gen_step, -1))
             done += 1
-    return np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses)
+    # [collectives issued, records in the reference's order?] then the accuracies of the critic steps
+    extra = np.array([gan.reducer.calls, float(order == sorted(order, key=lambda t: (t[0], t[1] < 0, t[1])))] + accs)
+    return np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses), extra
 
 
 def _train_moments(n_steps=3):
@@ -99,7 +104,8 @@ def _worker(rank, world, port, out, what='gan'):
 
 def test_two_ranks_follow_the_single_process_run():
     sys.path.insert(0, ROOT)
-    jds1, critic1, losses1 = _train()
+    jds1, critic1, losses1, extra1 = _train()
+    assert extra1[0] == 0 and extra1[1] == 1
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = 29700 + (os.getpid() % 1000)
@@ -116,13 +122,20 @@ def test_two_ranks_follow_the_single_process_run():
         np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
     np.testing.assert_array_equal(res[0][2], res[1][2])          # replicas stay bit-identical
     np.testing.assert_array_equal(res[0][1], res[1][1])
+    # ONE collective per update: 2 + 2 critic steps and 2 generator steps = 6 all-reduces.  The accuracy of the
+    # updated critic (cwgan.py:505-507) has no collective of its own: it rides in the next one, and every record still
+    # reaches the driver in the reference's order with the JOB-wide value (= the single process's, which sees all samples)
+    for r in range(2):
+        assert res[r][4][0] == 6 and res[r][4][1] == 1
+        np.testing.assert_allclose(res[r][4][2:], extra1[2:], atol=1e-6)
+    np.testing.assert_array_equal(res[0][4], res[1][4])
 
 
 def test_two_ranks_with_device_noise_follow_the_single_process_run():
     """`z_device_seed` (performance mode): the ranks fill disjoint rows of ONE Philox stream, so the 2-rank job trains on
     the same weight draws as the single process -- not on two copies of half of them."""
     sys.path.insert(0, ROOT)
-    jds1, critic1, losses1 = _train(z_device_seed=31)
+    jds1, critic1, losses1, _ = _train(z_device_seed=31)
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = 26700 + (os.getpid() % 1000)
