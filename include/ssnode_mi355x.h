@@ -292,6 +292,10 @@ int ssn_jds_grad_f64(const double *gW, const double *z, const double *J, const d
  *    params / grads: ONE flat fp32 device buffer [W_1 (n0 x n1) row-major, b_1, ...,
  *    W_L, b_L, w_out (n_L)] -- the order of lasagne.layers.get_all_params.
  *    dims: HOST int[L+1] = {n0 = nx+3, n1, ..., nL}.
+ *    Unconditional critic (UnConditionalDiscriminator, networks/wgan.py:66-97; CriticTrainer,
+ *    wgan.py:194-215): pass NULL for EVERY condition pointer of a call (cond; cg, cd and cp
+ *    together) -- then h0 = x and dims[0] = nx.  Conditions for some inputs of a call and not
+ *    for others are refused.
  *    precision: 0 = bf16 MFMA operands (fp32 accumulate), 1 = fp32 MFMA.
  * ------------------------------------------------------------------------ */
 long   ssn_critic_num_params(const int *dims, int nlayers);

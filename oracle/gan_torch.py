@@ -130,8 +130,11 @@ def critic_forward(params, x, cond, normalization='none', nonlinearity='rectify'
     params: list of tensors.  'none': [W1, b1, ..., WL, bL, Wout];
     'layer': [W1, b1, ...] with Dense(no bias) -> LayerNorm -> Bias -> nonlinearity.
     Input = concat(x, [contrast, |norm_probe|, cell_type]) (cwgan.py:164-170)."""
-    c = torch.stack([cond[:, 0], cond[:, 1].abs(), cond[:, 2]], dim=1)
-    h = torch.cat([x, c], dim=1)
+    if cond is None:           # UnConditionalDiscriminator (wgan.py:66-97): the tuning curve alone
+        h = x
+    else:
+        c = torch.stack([cond[:, 0], cond[:, 1].abs(), cond[:, 2]], dim=1)
+        h = torch.cat([x, c], dim=1)
     nl = len(params) // 2
     norms = normalization if isinstance(normalization, (list, tuple)) else [normalization] * nl
     # (lasagne.nonlinearities: leaky_rectify = LeakyRectify(0.01), very_leaky_rectify = LeakyRectify(1 / 3))
@@ -183,6 +186,29 @@ def generator_loss(J, D, S, z, bandwidths, contrasts, model_ids, norm_probes, ce
     cond = torch.stack([con, t64(norm_probes), t64(np.asarray(cell_types, dtype='float64'))], dim=1)
     loss = -critic_forward(critic_params, tc, cond, **critic_kw).mean() + dynamics_cost * dyn + rate_cost * rate
     return loss, dict(time_avg=ta, dynamics_penalty=dyn, rate_penalty=rate, tuning_curve=tc, conditions=cond)
+
+
+def fixed_probe(time_avg, probes):
+    """ssn.py:846-848 (`FixedProber`): time_avg[:, :, probes] flattened over (stimulus, probe) -> (batch, NB * P)."""
+    return time_avg[:, :, torch.as_tensor(np.asarray(probes), dtype=torch.long)].reshape(time_avg.shape[0], -1)
+
+
+def unconditional_generator_loss(J, D, S, z, bandwidths, contrasts, probes, critic_params, num_sites, smoothness, io_type,
+                                 k, n, tau_E, tau_I, dt, seqlen, skip_steps, rate_penalty_threshold, dynamics_cost,
+                                 rate_cost, critic_kw=None, V=None, zs_in=None):
+    """wgan.py:236-241 with the unconditional pieces of wgan.py:299-444: stimulus grid of `grid_stimulator_inputs`
+    (bandwidths, contrasts: (B, NB) arrays), fixed prober, critic without condition columns."""
+    critic_kw = critic_kw or {}
+    ext = stimulus(bandwidths, contrasts, smoothness, num_sites)
+    if V is not None:
+        vpop = V if V.dim() == 1 else torch.stack([V, V])
+        vs = torch.cat([vpop[0].expand(num_sites), vpop[1].expand(num_sites)])
+        ext = (1 + vs.reshape(1, 1, -1) * t64(zs_in)[:, None, :]) * ext
+    W = make_W(z, J, D, S, num_sites)
+    ta, dyn, rate = euler_ssn(W, ext, io_type, k, n, tau_E, tau_I, dt, seqlen, skip_steps, rate_penalty_threshold)
+    tc = fixed_probe(ta, probes)
+    loss = -critic_forward(critic_params, tc, None, **critic_kw).mean() + dynamics_cost * dyn + rate_cost * rate
+    return loss, dict(time_avg=ta, dynamics_penalty=dyn, rate_penalty=rate, tuning_curve=tc)
 
 
 # ------------------------------------------------------------------ optimizers (Lasagne defaults)

@@ -25,11 +25,21 @@ def _stream():
 LEAK = {'rectify': 0.0, 'leaky_rectify': 0.01, 'very_leaky_rectify': 1.0 / 3.0, 'linear': 1.0, 'identity': 1.0}
 
 
+class _NoCond(object):
+    """Stands for "no condition columns" in the calls of an unconditional critic (the library reads NULL that way)."""
+
+    @staticmethod
+    def data_ptr():
+        return None
+
+
 class Critic(object):
-    """MLP critic: input = [tuning curve (nx), contrast, |norm_probe|, cell_type]."""
+    """MLP critic: input = [tuning curve (nx), contrast, |norm_probe|, cell_type] (`ConditionalDiscriminator`,
+    networks/cwgan.py:123-175), or the tuning curve alone with ``conditional=False`` (`UnConditionalDiscriminator`,
+    networks/wgan.py:66-97: every `cond` argument is then None)."""
 
     def __init__(self, nx, layers, seed=0, hide_cell_type=False, precision='fp32',
-                 normalization='none', nonlinearity='rectify', device=None):
+                 normalization='none', nonlinearity='rectify', device=None, conditional=True):
         norms = list(normalization) if isinstance(normalization, (list, tuple)) else [normalization] * len(layers)
         if len(norms) != len(layers) or any(n not in ('none', 'layer') for n in norms):
             raise ValueError('normalization must be none/layer (or one per layer): {!r}'.format(normalization))
@@ -49,7 +59,8 @@ class Critic(object):
         clib.require_gpu()
         self.nx = int(nx)
         self.layers = [int(w) for w in layers]
-        self.dims = [self.nx + 3] + self.layers
+        self.conditional = bool(conditional)
+        self.dims = [self.nx + (3 if self.conditional else 0)] + self.layers
         self.nlayers = len(self.layers)
         self.hide_cell_type = int(bool(hide_cell_type))
         self.precision = PRECISION[precision]
@@ -159,6 +170,8 @@ class Critic(object):
 
     @staticmethod
     def _f32(t):
+        if t is None:
+            return _NoCond
         if torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
             return t
         return torch.as_tensor(t).to('cuda', torch.float32).contiguous()
@@ -273,7 +286,8 @@ class Critic(object):
         xg, xd, cond = self._f32(xg), self._f32(xd), self._f32(cond)
         eps = self._f32(eps).reshape(-1)
         n = xg.shape[0]
-        assert xd.shape == xg.shape and cond.shape[0] == n and eps.numel() == n
+        assert xd.shape == xg.shape and (cond is _NoCond or cond.shape[0] == n) and eps.numel() == n
+        assert (cond is _NoCond) == (not self.conditional)
         self._ensure_segments()
         nseg = len(self._seg_sizes)
         ws = self._workspace(2 * n, n)

@@ -590,7 +590,7 @@ size_t ssn_critic_workspace_floats(const int* dims, int nlayers, int batch_gd, i
 int ssn_critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
                        int hide_cell_type, float* out, float* workspace, int precision, void* stream) {
     if (batch == 0) return 0;
-    if (fused_ok(dims, nlayers, batch)) {
+    if (cond && fused_ok(dims, nlayers, batch)) {
         SSN_TRY(ssn::critic_fused_forward(params, dims, nullptr, nlayers, x, cond, batch, hide_cell_type, out, workspace, (hipStream_t)stream));
         return 0;
     }
@@ -602,7 +602,7 @@ int ssn_critic_loss_grad(const float* params, const int* dims, int nlayers, cons
                          const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
                          float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* workspace,
                          int precision, void* stream) {
-    if (fused_ok(dims, nlayers, (long)ng + nd + np)) {
+    if (cg && cd && cp && fused_ok(dims, nlayers, (long)ng + nd + np)) {
         SSN_TRY(ssn::critic_fused_loss_grad(params, dims, nullptr, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type,
                                             grads, stats, dvals, workspace, (hipStream_t)stream));
         return 0;
@@ -615,7 +615,7 @@ int ssn_critic_input_grad(const float* params, const int* dims, int nlayers, con
                           int hide_cell_type, float scale, float* gx, float* stats, float* workspace, int precision,
                           void* stream) {
     if (batch == 0) return 0;
-    if (fused_ok(dims, nlayers, batch)) {
+    if (cond && fused_ok(dims, nlayers, batch)) {
         SSN_TRY(ssn::critic_fused_input_grad(params, dims, nullptr, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
                                              workspace, (hipStream_t)stream));
         return 0;
@@ -657,7 +657,7 @@ int ssn_critic_forward_norm(const float* params, const int* dims, const int* lay
                             const float* cond, int batch, int hide_cell_type, float* out, float* workspace, int precision,
                             void* stream) {
     if (batch == 0) return 0;
-    if (fused_ok(dims, nlayers, batch)) {
+    if (cond && fused_ok(dims, nlayers, batch)) {
         SSN_TRY(ssn::critic_fused_forward(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, out, workspace, (hipStream_t)stream));
         return 0;
     }
@@ -669,7 +669,7 @@ int ssn_critic_loss_grad_norm(const float* params, const int* dims, const int* l
                               const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
                               int nd, int np, float lmd, int hide_cell_type, float* grads, float* stats, float* dvals,
                               float* workspace, int precision, void* stream) {
-    if (fused_ok(dims, nlayers, (long)ng + nd + np)) {
+    if (cg && cd && cp && fused_ok(dims, nlayers, (long)ng + nd + np)) {
         SSN_TRY(ssn::critic_fused_loss_grad(params, dims, layer_norm, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type,
                                             grads, stats, dvals, workspace, (hipStream_t)stream));
         return 0;
@@ -682,7 +682,7 @@ int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* 
                                const float* cond, int batch, int hide_cell_type, float scale, float* gx, float* stats,
                                float* workspace, int precision, void* stream) {
     if (batch == 0) return 0;
-    if (fused_ok(dims, nlayers, batch)) {
+    if (cond && fused_ok(dims, nlayers, batch)) {
         SSN_TRY(ssn::critic_fused_input_grad(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
                                              workspace, (hipStream_t)stream));
         return 0;
@@ -731,14 +731,14 @@ int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, c
 }
 
 int ssn_critic_step_run(const ssn_critic_step* a, void* stream) {
-    if (!a || !a->params || !a->dims || !a->xg || !a->xd || !a->cond || !a->eps || !a->xp || !a->grads || !a->stats || !a->dvals ||
+    if (!a || !a->params || !a->dims || !a->xg || !a->xd || !a->eps || !a->xp || !a->grads || !a->stats || !a->dvals ||
         !a->workspace || !a->opt || !a->acc_dvals || !a->tail || a->n <= 0 || a->nlayers < 0 || a->nseg < 0) {
         g_last_error = "ssn_critic_step_run: invalid argument";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
     bool norm = false;
     for (int l = 0; a->layer_norm && l < a->nlayers; ++l) norm = norm || a->layer_norm[l] != 0;
-    const int n = a->n, nx = a->dims[0] - 3;
+    const int n = a->n, nx = a->dims[0] - (a->cond ? 3 : 0);        // cond NULL: the unconditional critic (dims[0] = nx)
     int rc;
     if ((rc = ssn_interpolate_f32(a->eps, a->xd, a->xg, a->xp, n, nx, stream))) return rc;
     if (norm) rc = ssn_critic_loss_grad_norm(a->params, a->dims, a->layer_norm, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond,

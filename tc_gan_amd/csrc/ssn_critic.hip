@@ -378,10 +378,11 @@ static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
 // ---------------------------------------------------------------------------------
 // small elementwise / reduction kernels of the critic
 // ---------------------------------------------------------------------------------
-// h0[b] = [x[b][0:nx], c0, |c1|, c2]   (cwgan.py:164-170; hide_cell_type zeroes c2, 178-187)
+// h0[b] = [x[b][0:nx], c0, |c1|, c2]   (cwgan.py:164-170; hide_cell_type zeroes c2, 178-187); nc = 0: the unconditional critic
+// of networks/wgan.py:66-97, h0[b] = x[b] (cond is not read)
 __global__ void __launch_bounds__(256) critic_input_kernel(const float* __restrict__ x, const float* __restrict__ cond,
-                                                           float* __restrict__ h0, int batch, int nx, int hide_cell_type) {
-    const int n0 = nx + 3;
+                                                           float* __restrict__ h0, int batch, int nx, int hide_cell_type, int nc) {
+    const int n0 = nx + nc;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < (long)batch * n0; e += gridDim.x * 256L) {
         const int b = (int)(e / n0), j = (int)(e % n0);
         float v;
@@ -605,11 +606,11 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
                           int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st, float leak) {
     CriticNet net;
     if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
-    const int nx = dims[0] - 3;
+    const int nc = cond ? 3 : 0, nx = dims[0] - nc;          // (no condition columns: the unconditional critic)
     float* h[10];
     float* p = ws;
     for (int l = 0; l <= nlayers; ++l) { h[l] = p; p += (long)batch * dims[l]; }
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type);
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type, nc);
     return critic_forward_pass(net, h, out, batch, bf16, st);
 }
 
@@ -621,7 +622,9 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     CriticNet net;
     if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
     hipError_t e;
-    const int L = nlayers, nx = dims[0] - 3;
+    const int nc = (cg || cd || cp) ? 3 : 0;
+    if (nc && ((ng && !cg) || (nd && !cd) || (np && !cp))) return hipErrorInvalidValue;   // conditions for all inputs or for none
+    const int L = nlayers, nx = dims[0] - nc;
     const int bgd = ng + nd;
     if ((e = hipMemsetAsync(grads, 0, net.nparams * sizeof(float), st)) != hipSuccess) return e;
     float* p = ws;
@@ -638,8 +641,8 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     float* tmp = p; p += dims[L];
     critic_splitk_begin(p, critic_splitk_scratch_floats(dims, nlayers, bgd + np));     // the rest of the workspace
     struct PlanScope { ~PlanScope() { critic_splitk_begin(nullptr, 0); } } plan_scope;    // closed on every return path
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type);
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type);
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type, nc);
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type, nc);
     if ((e = critic_forward_pass(net, h, dvals, bgd, bf16, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dvals, stats, ng, nd);
     hipLaunchKernelGGL(fill_updown_kernel, dim3(blocks_for(bgd)), dim3(256), 0, st, up, ng, nd);
@@ -656,7 +659,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st)) != hipSuccess) return e;
 
     // ---------------- (2) gradient penalty on xp ------------------------------------------------
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type);
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type, nc);
     if ((e = critic_forward_pass(net, hp, dp, np, bf16, st)) != hipSuccess) return e;
     // input gradient g = dD/dh0 per sample: v_L = m_L * w_out, chain down to vp[0]
     hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, st, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L], net.leak);
@@ -702,13 +705,13 @@ hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, 
     CriticNet net;
     if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
     hipError_t e;
-    const int L = nlayers, nx = dims[0] - 3;
+    const int L = nlayers, nc = cond ? 3 : 0, nx = dims[0] - nc;
     float *h[10], *v[10];
     float* p = ws;
     for (int l = 0; l <= L; ++l) { h[l] = p; p += (long)batch * dims[l]; }
     for (int l = 0; l <= L; ++l) { v[l] = p; p += (long)batch * dims[l]; }
     float* dv = p; p += batch;
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type);
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type, nc);
     if ((e = critic_forward_pass(net, h, dv, batch, bf16, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dv, stats, batch, 0);
     hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)batch * dims[L])), dim3(256), 0, st, h[L], net.wout, (const float*)nullptr, v[L], batch, dims[L], net.leak);
@@ -733,7 +736,8 @@ hipError_t critic_colsum(const float* X, float* out, int batch, int n, float bet
 }
 hipError_t critic_make_input(const float* x, const float* cond, float* h0, int batch, int nx, int hide, hipStream_t st) {
     if (batch == 0) return hipSuccess;
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * (nx + 3))), dim3(256), 0, st, x, cond, h0, batch, nx, hide);
+    const int nc = cond ? 3 : 0;
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * (nx + nc))), dim3(256), 0, st, x, cond, h0, batch, nx, hide, nc);
     return hipGetLastError();
 }
 hipError_t critic_gp_head(const float* g, float* ghat, float* pen, int batch, int n0, int nx, hipStream_t st) {

@@ -238,7 +238,7 @@ hipError_t critic_norm_forward(const float* params, const int* dims, const int* 
     float* p = ws;
     Acts A;
     carve_acts(p, net, batch, A);
-    if ((e = critic_make_input(x, cond, A.h[0], batch, dims[0] - 3, hide, st)) != hipSuccess) return e;
+    if ((e = critic_make_input(x, cond, A.h[0], batch, dims[0] - (cond ? 3 : 0), hide, st)) != hipSuccess) return e;
     return norm_forward(net, A, out, batch, bf16, st);
 }
 
@@ -252,11 +252,11 @@ hipError_t critic_norm_input_grad(const float* params, const int* dims, const in
     Acts A;
     carve_acts(p, net, batch, A);
     float* dv = carve(p, batch);
-    if ((e = critic_make_input(x, cond, A.h[0], batch, dims[0] - 3, hide, st)) != hipSuccess) return e;
+    if ((e = critic_make_input(x, cond, A.h[0], batch, dims[0] - (cond ? 3 : 0), hide, st)) != hipSuccess) return e;
     if ((e = norm_forward(net, A, dv, batch, bf16, st)) != hipSuccess) return e;
     if ((e = critic_two_means(dv, stats, batch, 0, st)) != hipSuccess) return e;
     if ((e = norm_chain(net, A, nullptr, batch, bf16, st)) != hipSuccess) return e;
-    return critic_gather_scale(A.u[0], gx, batch, dims[0], dims[0] - 3, scale, st);
+    return critic_gather_scale(A.u[0], gx, batch, dims[0], dims[0] - (cond ? 3 : 0), scale, st);
 }
 
 hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* xg,
@@ -266,7 +266,9 @@ hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int
     NormNet net;
     if (!parse_norm_net(params, dims, norm, nlayers, net)) return hipErrorInvalidValue;
     hipError_t e;
-    const int L = nlayers, nx = dims[0] - 3, bgd = ng + nd;
+    const int nc = (cg || cd || cp) ? 3 : 0;            // (no condition columns: the unconditional critic, networks/wgan.py:66-97)
+    if (nc && ((ng && !cg) || (nd && !cd) || (np && !cp))) return hipErrorInvalidValue;
+    const int L = nlayers, nx = dims[0] - nc, bgd = ng + nd;
     if ((e = hipMemsetAsync(grads, 0, net.nparams * sizeof(float), st)) != hipSuccess) return e;
     float* p = ws;
     // The rows of the three inputs are STACKED ([xg; xd; xp]): one forward pass and one backward chain over

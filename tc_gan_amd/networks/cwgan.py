@@ -34,7 +34,7 @@ from ..gradient_expressions.utils import sample_sites_from_stim_space
 from ..utils import Namespace, StopWatch, as_randomstate, cartesian_product, to_device, to_device_packed
 from .ssn import TuningCurveGenerator
 from .utils import gridify_tc_samples
-from .wgan import DEFAULT_PARAMS as _WGAN_DEFAULTS
+from ._common import DEFAULT_PARAMS as _WGAN_DEFAULTS
 
 logger = getLogger(__name__)
 
@@ -262,6 +262,13 @@ class ConditionalBPTTWassersteinGAN(object):
         self.dynamics_cost = dynamics_cost
         self.rate_cost = rate_cost
         self.param_bounds = param_bounds          # {'J': (min, max), ...}  (wgan.py:244-251)
+        self._init_loop_state(seed)
+        assert self.probes_per_model < gen.num_neurons
+        assert num_models % self.reducer.world == 0, 'num_models must be divisible by the number of ranks'
+
+    def _init_loop_state(self, seed):
+        """What the update loop keeps between steps (shared with the unconditional GAN of networks/wgan.py)."""
+        gen = self.gen
         self.rng = as_randomstate(seed)
         self._predrawn = None          # host draws of the NEXT critic step, made early (see train_generator)
         self._gparams_host = {}        # host values the device copies of the generator parameters correspond to
@@ -269,8 +276,6 @@ class ConditionalBPTTWassersteinGAN(object):
         self._acc_carry = None         # data-parallel runs: this rank's accuracy of the last critic step, waiting for a collective
         self._arrived_with_gen = None
         self.reducer = GradientAllReducer()
-        assert self.probes_per_model < gen.num_neurons
-        assert num_models % self.reducer.world == 0, 'num_models must be divisible by the number of ranks'
         self._pnames = [name for name, _ in gen.get_all_params()]        # ['V',] 'J', 'D', 'S'
         self._gparams = {name: torch.zeros(int(np.size(value)), device='cuda', dtype=torch.float32)
                          for name, value in gen.get_all_params()}
@@ -361,7 +366,10 @@ class ConditionalBPTTWassersteinGAN(object):
         xg = gen_out.prober_tuning_curve
         per = local.batchsize
         r0 = self.reducer.rank * per if self.reducer.on else 0
-        xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
+        if local.conditions is None:              # the unconditional GAN of networks/wgan.py: no condition columns
+            (xd, eps), cd = to_device_packed([local.tuning_curves, ctx.eps_full[r0:r0 + per]], torch.float32), None
+        else:
+            xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
         ctx.skipped = False
         ctx.snapshot = None
         ctx.acc_deferred = False
@@ -481,7 +489,7 @@ class ConditionalBPTTWassersteinGAN(object):
             self._rng_before_predraw = self.rng.get_state()
             self._predrawn = self._draw_disc()
         with self.gen_train_watch:
-            cd = to_device(np.ascontiguousarray(local.conditions), torch.float32)
+            cd = None if local.conditions is None else to_device(np.ascontiguousarray(local.conditions), torch.float32)
             xg = gen_out.prober_tuning_curve.to(torch.float32)
             nb = xg.shape[0]
             gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
@@ -525,7 +533,7 @@ class ConditionalBPTTWassersteinGAN(object):
                     logger.warning('generator step %s: %d of %d draws have an adjoint that grew by more than 2^8 within one '
                                    'Euler step -- beyond the lagged scale of the fp16-split sweep, so their gradient is NaN; '
                                    '--gen-kernel mfma-fp32 has no such limit', getattr(info, 'gen_step', '?'), bad,
-                                   gen_out.prober_tuning_curve.shape[0] // max(self.probes_per_model, 1))
+                                   gen_out.prober_tuning_curve.shape[0] // max(getattr(self, 'probes_per_model', 1), 1))
         info.gen_forward_time = self.gen_forward_watch.sum()
         info.gen_train_time = self.gen_train_watch.sum()
         info.gen_time = info.gen_train_time + info.gen_forward_time

@@ -1,5 +1,10 @@
-"""Shared options / learn() of the BPTT WGAN runs (mirror of ``tc_gan/run/bptt_wgan.py`` and of the shared
-helpers of ``tc_gan/run/gan.py:1109-1254``; same option names, defaults and config keys)."""
+"""
+Run SSN-BPTT Wasserstein GAN learning on MI355X.
+
+Mirror of ``tc_gan/run/bptt_wgan.py`` (and of the shared helpers of ``tc_gan/run/gan.py:1109-1254``): same option
+names, defaults and config keys, same flow (argparse -> run_config -> preprocess -> info.json -> init_driver ->
+learn), same outputs.  ``tc_gan_amd.run.bptt_cwgan`` reuses the options and `learn` from here.
+"""
 from logging import getLogger
 
 import numpy as np
@@ -7,7 +12,8 @@ import numpy as np
 from .. import clib, execution, ssnode, utils
 from ..networks.dataset import generate_dataset
 from ..networks.fixed_time_sampler import new_JDS
-from ..networks.wgan import DEFAULT_PARAMS
+from ..drivers import BPTTWGANDriver
+from ..networks.wgan import DEFAULT_PARAMS, make_gan
 
 logger = getLogger(__name__)
 
@@ -26,6 +32,25 @@ def learn(driver, **generate_dataset_kwargs):
     data = generate_dataset_and_save(driver.datastore, gan, **generate_dataset_kwargs)
     gan.set_dataset(data)
     driver.run(gan)
+
+
+def make_parser():
+    """bptt_wgan.py:46-72."""
+    import argparse
+
+    class CustomFormatter(argparse.RawDescriptionHelpFormatter, argparse.ArgumentDefaultsHelpFormatter):
+        pass
+
+    parser = argparse.ArgumentParser(formatter_class=CustomFormatter, description=__doc__)
+    parser.add_argument('--batchsize', '--n_samples', default=15, type=eval,
+                        help='Number of samples to draw from G each step (aka NZ, minibatch size).')
+    parser.add_argument('--sample-sites', default=[0], type=utils.csv_line(float),
+                        help='Locations (offsets) of neurons to be sampled from SSN in the "bandwidth" space [-1, 1].  '
+                             '0 means the center of the network.')
+    add_bptt_common_options(parser)
+    add_learning_options(parser)
+    parser.set_defaults(datastore_template='logfiles/BPTT_WGAN_{layers_str}')
+    return parser
 
 
 def add_bptt_common_options(parser):
@@ -134,3 +159,29 @@ def do_learning(learn, run_config, script_file, init_driver, preprocess=preproce
                       init_driver='{}.{}'.format(init_driver.__module__, init_driver.__name__))
     execution.do_learning(lambda **rc: learn(**init_driver(**rc)), run_config, preprocess=preprocess,
                           extra_info=extra_info, **kwargs)
+
+
+def init_driver(datastore, iterations, quit_JDS_threshold, quiet, disc_param_save_interval, disc_param_template,
+                disc_param_save_on_error, layers, checkpoint_interval=-1, resume_from=None, **run_config):
+    """bptt_wgan.py:175-198."""
+    del layers                       # only used for the datastore name (execution.format_datastore)
+    run_config = utils.subdict_by_prefix(run_config, 'disc_')
+    run_config = utils.subdict_by_prefix(run_config, 'gen_')
+    gan, rest = make_gan(run_config)
+    driver = BPTTWGANDriver(
+        gan, datastore, iterations=iterations, quiet=quiet, disc_param_save_interval=disc_param_save_interval,
+        disc_param_template=disc_param_template, disc_param_save_on_error=disc_param_save_on_error,
+        quit_JDS_threshold=quit_JDS_threshold, checkpoint_interval=checkpoint_interval, resume_from=resume_from)
+    return dict(driver=driver, **rest)
+
+
+def main(args=None):
+    """bptt_wgan.py:224-233."""
+    parser = make_parser()
+    ns = parser.parse_args(args)
+    ns.layers = ns.disc_layers       # for the {layers_str} of the datastore name; dropped again in init_driver
+    do_learning(learn, vars(ns), init_driver=init_driver, script_file=__file__)
+
+
+if __name__ == '__main__':
+    main()

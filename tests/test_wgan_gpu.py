@@ -1,0 +1,265 @@
+"""GPU tests of the unconditional BPTT-WGAN (tc_gan_amd/networks/wgan.py, run/bptt_wgan.py): the reference's smoke tests
+(networks/tests/test_wgan.py:50-72) restated on the product, one full critic + generator update against the fp64 oracle
+with identical host RNG streams, the unconditional critic against fp64 autograd, and the CLI cases of
+run/tests/test_bptt_wgan.py:12-105."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gan_torch as og
+from oracle import ssn_numpy as on
+
+pytestmark = pytest.mark.gpu
+
+JDS = on.new_JDS()
+# networks/tests/test_wgan.py:9-35 (TEST_PARAMS), sizes cut down
+TEST_PARAMS = dict(
+    J0=np.ones((2, 2)) * 0.01, D0=np.ones((2, 2)) * 0.01, S0=np.ones((2, 2)) * 0.01,
+    gen=dict(J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10, dynamics_cost=1, rate_cost=100,
+             rate_penalty_threshold=200),
+    disc=dict(layers=[], normalization='none', nonlinearity='rectify'),
+    critic_iters_init=1, critic_iters=1, include_inhibitory_neurons=True, lipschitz_cost=10, truth_size=1,
+    num_sites=10, seqlen=12, skip_steps=8)
+
+
+def emit_gan(**kwargs):
+    from tc_gan_amd.networks import wgan
+    return wgan.make_gan(dict(TEST_PARAMS, **kwargs))
+
+
+def fake_data(gan, truth_size):
+    """networks/tests/test_wgan.py:43-47."""
+    ncols = len(gan.bandwidths) * len(gan.contrasts) * len(gan.sample_sites)
+    if gan.include_inhibitory_neurons:
+        ncols *= 2
+    return gan.rng.randn(truth_size, ncols)
+
+
+@pytest.mark.parametrize('config', [dict(), dict(ssn_type='heteroin'), dict(ssn_type='deg-heteroin')])
+def test_smoke_wgan(config):
+    """networks/tests/test_wgan.py:50-64 (+ the default SSN)."""
+    gan, rest = emit_gan(**config)
+    assert rest == {'truth_size': 1}
+    gan.set_dataset(fake_data(gan, rest['truth_size']))
+    learning_it = gan.learning()
+    info = next(learning_it)
+    assert info.is_discriminator
+    for field in ('disc_loss', 'accuracy', 'gen_time', 'disc_time', 'xd', 'xg', 'xp', 'dynamics_penalty', 'rate_penalty',
+                  'gen_out', 'gen_step', 'disc_step'):                       # wgan.py:385-422
+        assert hasattr(info, field), field
+    assert info.xg.shape == info.xd.shape == (1, 8 * 2) and np.isfinite(info.disc_loss)
+    info = next(learning_it)
+    assert not info.is_discriminator and np.isfinite(info.gen_loss)
+    for field in ('gen_loss', 'gen_forward_time', 'gen_train_time', 'gen_time', 'disc_time'):      # wgan.py:424-437
+        assert hasattr(info, field), field
+
+
+@pytest.mark.parametrize('ssn_type', ['heteroin', 'deg-heteroin'])
+def test_wgan_heteroin(ssn_type):
+    """networks/tests/test_wgan.py:67-72: the input-variability parameter and its bounds exist."""
+    gan, _rest = emit_gan(ssn_type=ssn_type)
+    assert np.shape(gan.gen.V) == ((2,) if ssn_type == 'heteroin' else ())
+    lo, hi = gan.param_bounds['V']
+    assert np.all(np.asarray(lo) == 0) and np.all(np.asarray(hi) == 1)
+    assert gan.gen.get_flat_param_names()[:2] == (('V_E', 'V_I') if ssn_type == 'heteroin' else ('V', 'J_EE'))
+    # wgan.py:340-361: what the driver and the dataset providers read
+    assert gan.loss_type == 'WD' and gan.NZ == gan.batchsize == 1 and gan.discriminator is gan.disc
+    assert gan.sample_sites == [4] and len(gan.get_gen_param()) == 3
+
+
+@pytest.mark.parametrize('layers,norm', [([], 'none'), ([16, 16], 'none'), ([16, 16], 'layer')])
+def test_unconditional_critic_vs_fp64_autograd(layers, norm):
+    """`Critic(conditional=False)` = `UnConditionalDiscriminator` + `CriticTrainer` (wgan.py:66-97, 194-215): D values, loss,
+    parameter gradients (WGAN-GP double backward) and the input gradient against oracle/gan_torch.py without condition
+    columns."""
+    from tc_gan_amd.networks.wgan import UnConditionalDiscriminator
+    rs = np.random.RandomState(3)
+    n, nx = 24, 10
+    disc = UnConditionalDiscriminator((n, nx), layers=layers, normalization=norm, seed=2)
+    assert disc.dims[0] == nx and disc.param_shapes()[0][1] == ((nx, layers[0]) if layers else (nx, 1))
+    xg, xd = rs.rand(n, nx) * 5, rs.rand(n, nx) * 5
+    eps = rs.rand(n, 1)
+    xp = eps * xd + (1 - eps) * xg
+    ps = [og.t64(p).clone().requires_grad_(True) for p in disc.get_param_values()]
+    kw = dict(normalization=norm)
+    want = og.critic_loss(ps, og.t64(xg), og.t64(xd), og.t64(xp), None, None, None, 10.0, **kw)
+    gwant = torch.autograd.grad(want, ps)
+    stats = disc.loss_grad(xg, None, xd, None, xp, None, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(want), rtol=1e-4, atol=1e-5)
+    got = disc.grads.cpu().numpy()
+    flat = np.concatenate([g.numpy().ravel() for g in gwant])
+    np.testing.assert_allclose(got, flat, rtol=2e-3, atol=2e-4 * np.abs(flat).max())
+    np.testing.assert_allclose(disc.forward(xg, None).cpu().numpy(), og.critic_forward(ps, og.t64(xg), None, **kw)[:, 0].detach().numpy(),
+                               rtol=1e-4, atol=1e-5)
+    x = og.t64(xg).clone().requires_grad_(True)
+    gx_want, = torch.autograd.grad(-og.critic_forward(ps, x, None, **kw).mean(), x)
+    gx, dmean = disc.input_grad(xg, None, scale=-1.0 / n)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_want.numpy(), rtol=1e-3, atol=1e-6)
+    acc = disc.accuracy(xg, None, xd, None)
+    np.testing.assert_allclose(acc, float(og.critic_forward(ps, og.t64(xg), None, **kw).mean()
+                                          - og.critic_forward(ps, og.t64(xd), None, **kw).mean()), rtol=1e-4, atol=1e-5)
+    # conditions for some inputs of a call and not for others are refused, not guessed
+    from tc_gan_amd import clib
+    with pytest.raises(clib.SSNLibraryError):
+        disc.loss_grad(xg, np.zeros((n, 3)), xd, None, xp, None, 10.0)
+
+
+def test_one_critic_and_generator_update_vs_oracle():
+    """Same seed -> same minibatch shuffle, eps, zs (RandomState order of wgan.py:385-437); critic loss, updated critic,
+    accuracy, generator loss and updated (J, D, S) against the fp64 restatement."""
+    from tc_gan_amd.networks import wgan
+    N, B = 10, 4
+    cfg = dict(TEST_PARAMS, J0=JDS['J'], D0=JDS['D'], S0=JDS['S'], batchsize=B, sample_sites=[0, 0.5], seqlen=40,
+               skip_steps=30, bandwidths=[0.0625, 0.125, 0.25, 0.75], contrasts=[5., 20.],
+               gen=dict(TEST_PARAMS['gen'], learning_rate=0.01, update_name='sgd', rate_cost=0.01, rate_penalty_threshold=5.0),
+               disc=dict(layers=[16, 16], normalization='none', nonlinearity='rectify', learning_rate=0.01, update_name='sgd'))
+    gan, _ = wgan.make_gan(cfg)
+    data = np.random.RandomState(4).rand(8, 8 * 2 * 2) * 10
+    gan.set_dataset(data)
+    p0 = [og.t64(p) for p in gan.disc.get_param_values()]
+    it = gan.learning()
+    dinfo, ginfo = next(it), next(it)
+    # ---- replay: numpy's own shuffle, then eps, then zs -- nothing of the product but the seed ---------------------
+    rng = np.random.RandomState(0)
+    idx = np.arange(len(data)); rng.shuffle(idx)                                 # utils/numerics.py:57-82
+    xd = og.t64(data[idx[:B]])
+    eps = og.t64(rng.rand(B).reshape(-1, 1))
+    zs = og.t64(rng.rand(B, 2 * N, 2 * N))
+    con, bw = wgan.grid_stimulator_inputs(cfg['contrasts'], cfg['bandwidths'], B)
+    probes = wgan.probes_from_stim_space([0, 0.5], N, True)
+    assert probes == [4, 6, 14, 16]
+    common = dict(num_sites=N, smoothness=on.DEFAULT_PARAMS['smoothness'], io_type='asym_tanh', k=0.01, n=2.2, tau_E=10.,
+                  tau_I=1., dt=0.1, seqlen=40, skip_steps=30, rate_penalty_threshold=5.0, dynamics_cost=1.0, rate_cost=0.01)
+    J, D, S = (og.t64(JDS[k]) for k in 'JDS')
+    _, aux = og.unconditional_generator_loss(J, D, S, zs, bw, con, probes, p0, **common)
+    xg = aux['tuning_curve'].detach()
+    np.testing.assert_allclose(dinfo.xg.cpu().numpy(), xg.numpy(), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(dinfo.xd.cpu().numpy(), xd.numpy(), rtol=1e-6)
+    xp = eps * xd + (1 - eps) * xg
+    ps = [p.clone().requires_grad_(True) for p in p0]
+    dloss = og.critic_loss(ps, xg, xd, xp, None, None, None, 10.0)
+    dgr = torch.autograd.grad(dloss, ps)
+    np.testing.assert_allclose(dinfo.disc_loss, float(dloss.detach()), rtol=1e-3, atol=1e-4)
+    p1 = [p - 0.01 * g for p, g in zip(p0, dgr)]
+    for a, b in zip(gan.disc.get_param_values(), p1):
+        np.testing.assert_allclose(a, b.numpy(), rtol=2e-3, atol=2e-5)
+    acc = og.critic_forward(p1, xg, None).mean() - og.critic_forward(p1, xd, None).mean()
+    np.testing.assert_allclose(dinfo.accuracy, float(acc), rtol=1e-3, atol=1e-4)
+    zs2 = og.t64(rng.rand(B, 2 * N, 2 * N))
+    Jg, Dg, Sg = (og.t64(JDS[k]).clone().requires_grad_(True) for k in 'JDS')
+    gloss, _ = og.unconditional_generator_loss(Jg, Dg, Sg, zs2, bw, con, probes, p1, **common)
+    gJ, gD, gS = torch.autograd.grad(gloss, [Jg, Dg, Sg])
+    np.testing.assert_allclose(ginfo.gen_loss, float(gloss.detach()), rtol=1e-3, atol=1e-4)
+    for name, g in (('J', gJ), ('D', gD), ('S', gS)):
+        want = np.clip(JDS[name] - 0.01 * g.numpy(), 1e-3, 10)
+        got = getattr(gan.gen, name)
+        np.testing.assert_allclose(got - JDS[name], want - JDS[name], rtol=5e-3, atol=5e-3 * np.abs(want - JDS[name]).max())
+
+
+# ------------------------------------------------------------------ CLI: run/tests/test_bptt_wgan.py
+def _load_tables(directory):
+    names = [n[:-4] for n in os.listdir(directory) if n.endswith('.csv') and n[:-4] in
+             ('learning', 'disc_learning', 'generator', 'disc_param_stats')]
+    path_h5 = os.path.join(directory, 'store.hdf5')
+    if os.path.exists(path_h5):
+        import h5py
+        with h5py.File(path_h5, 'r') as f:
+            return {k: f[k][...] for k in f}
+    return {n: np.genfromtxt(os.path.join(directory, n + '.csv'), delimiter=',', names=True, dtype=None, ndmin=1)
+            for n in names}
+
+
+def single_g_step(args):
+    """run/tests/test_bptt_wgan.py:12-21."""
+    from tc_gan_amd.run import bptt_wgan
+    bptt_wgan.main(['--iterations', '1', '--truth_size', '1', '--n_samples', '1', '--n_bandwidths', '1',
+                    '--WGAN_n_critic0', '1', '--seqlen', '4', '--skip-steps', '2', '--quiet'] + args)
+
+
+def test_single_g_step_logfiles(tmp_path, monkeypatch):
+    """run/tests/test_bptt_wgan.py:24-26: without --datastore the run lands under logfiles/ (BPTT_WGAN_<layers>)."""
+    monkeypatch.chdir(tmp_path)
+    single_g_step([])
+    assert (tmp_path / 'logfiles').is_dir()
+    assert any(name.startswith('BPTT_WGAN_') for name in os.listdir(tmp_path / 'logfiles'))
+
+
+_JDS_NAMES = ('J_EE', 'J_EI', 'J_IE', 'J_II', 'D_EE', 'D_EI', 'D_IE', 'D_II', 'S_EE', 'S_EI', 'S_IE', 'S_II')
+
+
+def _check_run(out, script_file, ssn_type='default'):
+    info = json.load(open(out / 'info.json'))
+    assert info['extra_info']['script_file'] == script_file
+    assert 'PATH' in info['meta_info']['environ']
+    assert info['run_config'].get('ssn_type', 'default') == ssn_type
+    assert json.load(open(out / 'exit.json')) == dict(reason='end_of_iteration', good=True)
+    tables = _load_tables(str(out))
+    # recorders.LearningRecorder.dtype.names (the loader's 'epoch' etc. are derived columns)
+    assert tables['learning'].dtype.names == ('gen_step', 'Gloss', 'Dloss', 'Daccuracy', 'gen_forward_time',
+                                              'gen_train_time', 'disc_time', 'rate_penalty', 'dynamics_penalty')
+    assert len(tables['learning']) == 1 and np.isfinite(tables['learning']['Gloss']).all()
+    vnames = {'heteroin': ('V_E', 'V_I'), 'deg-heteroin': ('V',)}.get(ssn_type, ())
+    assert tables['generator'].dtype.names == ('gen_step',) + vnames + _JDS_NAMES and len(tables['generator']) == 1
+    assert len(tables['disc_learning']) == 1
+    npz = np.load(out / 'disc_param' / 'last.npz')
+    assert list(npz['param_names']) == ['W']                     # --disc-layers [] : the linear output layer alone
+    return info, tables
+
+
+@pytest.mark.parametrize('args', [[], ['--sample-sites', '0, 0.5'], ['--include-inhibitory-neurons']])
+def test_single_g_step(args, tmp_path, monkeypatch):
+    """run/tests/test_bptt_wgan.py:29-77."""
+    from tc_gan_amd.run import bptt_wgan
+    monkeypatch.chdir(tmp_path)
+    single_g_step(args + ['--datastore', 'results'])
+    info, tables = _check_run(tmp_path / 'results', bptt_wgan.__file__)
+    sites = 2 if '--sample-sites' in args else 1
+    cols = sites * (2 if '--include-inhibitory-neurons' in args else 1)
+    assert np.load(tmp_path / 'results' / 'truth.npy').shape == (1, cols)
+    assert np.shape(np.loadtxt(tmp_path / 'results' / 'TC_mean.csv', delimiter=',', ndmin=2)) == (1, 2 * cols)
+
+
+@pytest.mark.parametrize('args, config', [
+    ([], dict(ssn_type='heteroin')),
+    (['--include-inhibitory-neurons'], dict(ssn_type='heteroin')),
+    (['--include-inhibitory-neurons'], dict(ssn_type='heteroin', V=[0.3, 0])),
+    (['--include-inhibitory-neurons'], dict(ssn_type='heteroin', gen_V_min=[0, 0], gen_V_max=[1, 0])),
+    ([], dict(ssn_type='deg-heteroin')),
+    (['--include-inhibitory-neurons'], dict(ssn_type='deg-heteroin', V=0.5)),
+])
+def test_single_g_step_with_load_config(args, config, tmp_path, monkeypatch):
+    """run/tests/test_bptt_wgan.py:80-105."""
+    from tc_gan_amd.run import bptt_wgan
+    monkeypatch.chdir(tmp_path)
+    config = dict(config, dataset_provider='fixedtime')         # ('ssnode' does not do heterogeneous input: dataset.py:163-166)
+    with open(tmp_path / 'run.json', 'w') as fp:
+        json.dump(config, fp)
+    single_g_step(args + ['--datastore', 'results', '--load-config', str(tmp_path / 'run.json')])
+    info, tables = _check_run(tmp_path / 'results', bptt_wgan.__file__, config['ssn_type'])
+    for key, value in config.items():
+        assert info['run_config'][key] == value
+    if 'gen_V_max' in config:
+        assert tables['generator']['V_I'][0] == 0.0
+
+
+def test_ssnode_truth_with_heterogeneous_input_is_refused(tmp_path, monkeypatch):
+    """dataset.py:163-166 through this entry point."""
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(NotImplementedError):
+        single_g_step(['--datastore', 'results', '--ssn-type', 'heteroin'])
+
+
+def test_run_script_dispatches_bptt_wgan(tmp_path, monkeypatch):
+    """`./run tc_gan.run.bptt_wgan -- ...` (the reference's module name) reaches this module."""
+    import run as run_script
+    monkeypatch.chdir(tmp_path)
+    code = run_script.main(['tc_gan.run.bptt_wgan', '--', '--iterations', '2', '--truth_size', '4', '--n_samples', '2',
+                            '--n_bandwidths', '4', '--WGAN_n_critic0', '2', '--WGAN_n_critic', '1', '--seqlen', '12',
+                            '--skip-steps', '8', '--disc-layers', '[8]', '--datastore', 'results', '--quiet',
+                            '--dataset-provider', 'fixedtime', '--J0', '0.1', '--D0', '0.05', '--S0', '0.1'])
+    assert code == 0
+    tables = _load_tables(str(tmp_path / 'results'))
+    assert list(tables['learning']['gen_step']) == [0, 1] and len(tables['disc_learning']) == 3
