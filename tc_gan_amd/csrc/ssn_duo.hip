@@ -47,10 +47,17 @@
                                 // from the partner wave's chain what they save the own one)
 #endif
 #ifndef SSN_DUO_EARLY_SOLVE
-#define SSN_DUO_EARLY_SOLVE 1   // solver: the candidate state of a wave's last row tile behind its own chain (0 = all in the serial phase)
+#define SSN_DUO_EARLY_SOLVE 2   // solver: the candidate state of a wave's last row tile behind its own chain: 2 = the four-tile wave only
+                                // (27.4 ms at C2 with 8 stimuli against 28.3 with 1 = every wave and 29.1 with 0 = none, same box)
 #endif
 #ifndef SSN_DUO_EARLY_BWD
 #define SSN_DUO_EARLY_BWD 1     // adjoint sweep: the last row tile of a step after the window behind the previous step's chain (0 = off)
+#endif
+#ifndef SSN_DUO_SOLVE_NL
+#define SSN_DUO_SOLVE_NL 4      // solver, 2N > 152: units of every wave whose low part W_m lives in LDS instead of registers
+#endif
+#ifndef SSN_DUO_BPF
+#define SSN_DUO_BPF 1           // chains: the B operand of k tile kk + 1 is requested before the MFMAs of tile kk (0 = compiler's order)
 #endif
 #ifndef SSN_DUO_ABLATE
 #define SSN_DUO_ABLATE 0        // diagnostic builds (timing only, wrong results): 1 = no nonlinearity, 2 = one FMA per MFMA,
@@ -102,6 +109,7 @@ struct Duo16 {
     // plain forward 3.38 ms with NL = 0 against 3.67 with 4 (the extra reads sit on the chain's critical path, and it did not
     // spill); forward with stores 6.1 -> 5.6 ms, solver 40.2 -> 34.3 ms with NL = 4.
     static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? 4 : 0; }
+    static constexpr int nl_solve() { return MK > 152 ? SSN_DUO_SOLVE_NL : 0; }
     // adjoint sweep: 10 state values per row and stimulus -- by the number of row tiles a wave finishes (6 or 8 values per lane)
     // (window steps / the steps after the window: the window keeps four trajectory rows per value in registers)
     // (wave 0 of the window loop is the one short of registers: it takes three units from its two three-tile neighbours)
@@ -291,10 +299,25 @@ struct DuoOperands {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = (mf4){0.f, 0.f, 0.f, 0.f};
         }
+        // B operands one k tile AHEAD of the MFMAs that take them (SSN_DUO_BPF): left to itself the compiler issues a tile's
+        // ds_read_b128 right in front of its first MFMA and waits (seen in the assembly: read, s_waitcnt lgkmcnt(0), six MFMAs,
+        // seven times per chain in the register-bound kernels) -- ~100 cycles of LDS latency per k tile with the matrix pipe idle.
+        // The scheduling fence keeps the prefetch in front of the tile's MFMAs; the wait it needs is a counted one, one tile later.
+        hv8 bnext = hv8{};
+        if constexpr (SSN_DUO_BPF && KA < KB) {
+            if (!(PRE && ROT && own_kt() >= 0 && KA == 0)) bnext = read_b(rd, (K0 + KA) % S::NKT);
+        }
 #pragma unroll
         for (int kk = KA; kk < KB; ++kk) {
             const int kt = (K0 + kk) % S::NKT;
-            const hv8 b1 = (PRE && ROT && own_kt() >= 0 && kk == 0) ? bpre : read_b(rd, kt);
+            hv8 b1;
+            if constexpr (SSN_DUO_BPF) {
+                b1 = (PRE && ROT && own_kt() >= 0 && kk == 0) ? bpre : bnext;
+                if (kk + 1 < KB) bnext = read_b(rd, (K0 + kk + 1) % S::NKT);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                b1 = (PRE && ROT && own_kt() >= 0 && kk == 0) ? bpre : read_b(rd, kt);
+            }
 #pragma unroll
             for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -715,16 +738,18 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     const int li = lane & 15, lg = lane >> 4, hi = li >> 3, st = li & 7;
     using LdsW = __attribute__((address_space(3))) unsigned*;
     using LdsI = __attribute__((address_space(3))) int*;
-    using LdsS = __attribute__((address_space(3))) short*;
     const LdsW wmax = (LdsW)wlds + 2 * d;                                        // [0] max |W|, [1] max |r0| of this draw
     const LdsW done = (LdsW)wlds + 4;                                           // [phase parity][draw]
-    const LdsI flags = (LdsI)(dlds + S::SYNC);                                  // [3][8] of this draw
+    // stop flags of this draw: three rotating words, one per step (bits 0-7: stimulus st has a row that is not converged,
+    // bits 8-15: ... a row at the rate bound).  A wave folds its lanes' verdicts with one ballot and ORs ONE word in (round 3
+    // had every lane store its own 16-bit flag: up to 8 lanes per address and instruction, 2.2e7 bank-conflict cycles per launch)
+    const LdsI flags = (LdsI)(dlds + S::SYNC);
     // previous state of this lane's values (r_prev output): kept in LDS, 32 B per lane, rewritten with every applied step
     using LdsF4s = __attribute__((address_space(3))) mf4*;
     const LdsF4s rp_slot = (LdsF4s)(plds + (size_t)WV * 2048 + (size_t)lane * 16);     // second half 1 KB further: conflict-free 16-byte stores
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
-    using Ops = DuoOperands<MK, WV, S::nl(true)>;
+    using Ops = DuoOperands<MK, WV, S::nl_solve()>;
     __hip_atomic_fetch_max(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
     // ---- the values this lane finishes
@@ -732,14 +757,12 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     const int s = s0 + st;
     const bool live = valid && s < a.NB;
     float rc[NE], ex[NE], eps[NE];
-    bool rowok[NE];
     float r0max = 0.f;
     {
         const size_t vec = ((size_t)b * a.NB + (s < a.NB ? s : 0)) * M;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
-            rowok[i] = row < M;
             const bool ok = s < a.NB && row < M;
             rc[i] = ok ? a.r[vec + row] : 0.f;
             ex[i] = ok ? a.ext[(a.ext_per_draw ? vec : (size_t)s * M) + row] : 0.f;
@@ -783,17 +806,21 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     };
     store_state();                                       // the initial state as the first B operand
 
+    int slot = 0;                                        // step % 3: the flag word of the step being finished
     mf4 acc[NT];
     auto chain = [&]() {
         ops.chain(b_rd, acc);
         if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
     };
     // bookkeeping identical in the four waves of the draw: lane s < 8 holds the verdict of stimulus s0 + s
+    // (a form with the stopped set as one scalar and the per-stimulus code / step count touched only when a stimulus stops
+    // was built and measured: the register allocation of the 2N = 208 kernel tipped into 87 spills, 4 of them inside the
+    // serial part -- 31.9 ms against 27.4; the segment it would shorten is short anyway, see the stamps in DESIGN 3.13c)
     int my_code = 1, my_steps = max_iter;
     bool my_frozen = lane >= 8 || !valid || s0 + lane >= a.NB;
     unsigned frozen = (unsigned)__builtin_amdgcn_ballot_w64(my_frozen) & 0xffu;
-    auto verdict = [&](int it, int f) {            // f: flag word of step it for stimulus `lane`
-        const bool fnc = (f & 0xffff) != 0, fhb = (f >> 16) != 0;
+    auto verdict = [&](int it, int f) {            // f: flag word of step it (lanes 0-7 judge stimulus `lane`)
+        const bool fnc = ((f >> (lane & 7)) & 1) != 0, fhb = ((f >> (8 + (lane & 7))) & 1) != 0;
         const bool stop = lane < 8 && !my_frozen && (!fnc || fhb);
         my_code = stop ? (fnc ? 2 : 0) : my_code;
         my_steps = stop ? it + 1 : my_steps;
@@ -834,48 +861,102 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
 #pragma unroll
         for (int tf = 0; tf < NS / 2; ++tf) tile_u(tf, tf == 0, uu[2 * tf], uu[2 * tf + 1]);
         duo_eval<false, NS>(io, uu, ff, dfn);
-        float r1[NE], dmax = -1.f, rmax = -__builtin_inff();
+        // Rows that do not exist (the padding of the last row tile) stay at their zero state: rows of zeros in W and no input
+        // give u = 0, f(0) = 0 and a step of exactly 0 (or NaN beside a NaN in the state, which fmaxf ignores), so their
+        // |r1 - r0| never exceeds that of a real row and needs no select; the state itself keeps its select below.
+        float r1[NE], dmax = 0.f;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             r1[i] = i < NS ? rc[i] + (-rc[i] + ff[i % NS]) * eps[i] : r1e[(i - NS) & 1];          // ssnode.c:64-67
-            dmax = fmaxf(dmax, rowok[i] ? fabsf(r1[i] - rc[i]) : -1.f);
-            rmax = fmaxf(rmax, rowok[i] ? r1[i] : -__builtin_inff());
+            dmax = fmaxf(dmax, fabsf(r1[i] - rc[i]));
         }
-        if (WV == 0 && lane < 8) flags[((it + 1) % 3) * 8 + lane] = 0;
-        if (live && !((frozen >> st) & 1u)) {
-            const LdsS fw = (LdsS)(flags + (it % 3) * 8 + st);
-            if (dmax >= a.st.atol) fw[0] = 1;                                    // ssnode.c:84-90 (a NaN difference does not count)
-            if (a.st.check_hard && rmax >= a.st.hard_stop) fw[1] = 1;
-            store_prev();
+        const bool take = live && !((frozen >> st) & 1u);
+        const bool ncv = dmax >= a.st.atol;                                      // ssnode.c:84-90 (a NaN difference does not count)
+        unsigned long long votes = __builtin_amdgcn_ballot_w64(take && ncv);
+        unsigned bits;
+        if (a.st.check_hard) {                                                   // (uniform; never with the saturating I/O function)
+            float rmax = -__builtin_inff();
 #pragma unroll
-            for (int i = 0; i < NE; ++i) rc[i] = rowok[i] ? r1[i] : rc[i];
+            for (int i = 0; i < NE; ++i) rmax = fmaxf(rmax, r1[i]);          // (rows that do not exist are at 0 <= any bound)
+            unsigned long long hb = __builtin_amdgcn_ballot_w64(take && rmax >= a.st.hard_stop);     // ssnode.c:98-102
+            hb |= hb >> 32; hb |= hb >> 16; hb |= hb >> 8;
+            bits = ((unsigned)hb & 0xffu) << 8;
+        } else {
+            bits = 0u;
+        }
+        votes |= votes >> 32; votes |= votes >> 16; votes |= votes >> 8;         // lane = 16 lg + 8 hi + st: bit st of the low byte
+        bits |= (unsigned)votes & 0xffu;
+        // (slot = it % 3 kept incrementally: three integer divisions by 3 per step are 20 scalar instructions of an in-order
+        // wave; the OR as a bare ds_or_b32 of one lane -- the builtin brings the atomic optimiser's lane census with it)
+        const unsigned fbase = (unsigned)(size_t)flags;
+        if (WV == 0 && lane == 0) *(LdsW)(size_t)(fbase + 4u * (unsigned)(slot == 2 ? 0 : slot + 1)) = 0u;
+        if (lane == 0 && bits) asm volatile("ds_or_b32 %0, %1" : : "v"(fbase + 4u * (unsigned)slot), "v"(bits) : "memory");
+        if (take) {
+            // r_prev = the state before the LAST applied step.  The last applied step of a stimulus is the one at which all of
+            // its rows pass the convergence test (or step max_iter - 1), so a lane whose own rows do not pass it knows that this
+            // step is not the last and need not save -- unless a rate-bound test (any row of any lane) can end the solve too.
+            if (!ncv || it >= max_iter - 1 || a.st.check_hard) store_prev();
+#pragma unroll
+            for (int i = 0; i < NE; ++i) rc[i] = r1[i];         // (a row that does not exist steps from 0 to 0: see above)
             store_state();
         }
     };
     __syncthreads();                                                          // (B)
     bool finished = !valid;
     int it = 0;
+#if SSN_DUO_STAMP
+    unsigned long long st_c = 0, st_v = 0, st_b1 = 0, st_s = 0, st_b2 = 0; int st_n = 0;
+#define SSN_SOLVE_NOW() ({ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); (unsigned long long)__builtin_amdgcn_s_memtime(); })
+#endif
     for (int p = 0;; ++p) {
-        // flags of my draw's last finished step (lanes 0-7) and both `done` words of the previous phase (lanes 8, 9)
+        // flag word of my draw's last finished step (lanes 0-7) and both `done` words of the previous phase (lanes 8, 9): the
+        // read is issued here and first used BEHIND the chain -- nothing in front of the chain waits for LDS
         const bool chain_phase = ((p + d) & 1) == 0;
         int word = 0;
         {
-            const LdsI src = lane < 8 ? flags + ((it + 2) % 3) * 8 + lane : (LdsI)(done + ((p + 1) & 1) * 2 + (lane & 1));
+            const LdsI src = lane < 8 ? flags + (slot == 0 ? 2 : slot - 1) : (LdsI)(done + ((p + 1) & 1) * 2 + (lane & 1));
             if (lane < 10) word = *src;
         }
+#if SSN_DUO_STAMP
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        unsigned long long t1 = t0;
+#endif
         if (chain_phase && p >= d) {
+            // The chain of step `it` runs before the verdict on step it - 1 is known: it reads the state that step published
+            // whatever the verdict says, and if the verdict ends the solve its sums are simply not used.
+            const bool run = !finished && it < max_iter;
+            if (run) { chain(); early(); }
+#if SSN_DUO_STAMP
+            t1 = SSN_SOLVE_NOW();
+#endif
             if (!finished && it >= 1) verdict(it - 1, word);
             if (frozen == 0xffu || it >= max_iter) finished = true;
-            if (!finished) { chain(); early(); }
         } else if (p >= d) {
             if (!finished) serial(it);
             ++it;
+            slot = slot == 2 ? 0 : slot + 1;
         }
         if (WV == 0 && lane == 0) done[(p & 1) * 2 + d] = finished ? 1u : 0u;
         const bool both = p >= 1 && __builtin_amdgcn_readlane(word, 8) != 0 && __builtin_amdgcn_readlane(word, 9) != 0;
-        __syncthreads();
+#if SSN_DUO_STAMP
+        const unsigned long long t2 = SSN_SOLVE_NOW();
+        duo_phase_barrier();
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        if (p >= d && !finished) {
+            if (chain_phase) { st_c += t1 - t0; st_v += t2 - t1; st_b1 += t3 - t2; ++st_n; }
+            else { st_s += t2 - t0; st_b2 += t3 - t2; }
+        }
+#else
+        duo_phase_barrier();
+#endif
         if (both) break;
     }
+#if SSN_DUO_STAMP
+    if (blockIdx.x == 0 && lane == 0) {             // every wave of workgroup 0: [8 w + 0 .. 4] segment sums, [8 w + 5] steps
+        unsigned long long* o = duo_stamps_fine + 8 * (4 * d + WV);
+        o[0] = st_c; o[1] = st_v; o[2] = st_b1; o[3] = st_s; o[4] = st_b2; o[5] = (unsigned long long)st_n;
+    }
+#endif
     if (valid && s < a.NB) {
         const size_t unit = (size_t)b * a.NB + s;
 #pragma unroll
@@ -898,7 +979,7 @@ __global__ void __launch_bounds__(512, 2) solve_duo_kernel(SolveArgs<float> a) {
     using S = Duo16<MK>;
     // per draw: images, slots, [3][8] flags, previous states of its 4 waves (32 B per lane); then max words, done words
     constexpr int PER_DRAW = S::DRAW + 128 + 4 * 64 * 32;
-    constexpr int WL = S::nl(true) * 1024;
+    constexpr int WL = S::nl_solve() * 1024;
     __shared__ __align__(16) char lds[2 * PER_DRAW + 64 + 8 * WL];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));

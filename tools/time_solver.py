@@ -36,7 +36,15 @@ def main():
             ref = res.x
         print('variant %d: %.2f ms  %.3e SSN-steps/s   max |x - first variant| %.3e (max %.3e)' % (
             v, ms, M * B * NB * T / (ms * 1e-3), float((res.x - ref).abs().max()), float(ref.abs().max())), flush=True)
-
+        from tc_gan_amd import clib
+        if v == 8 and hasattr(clib.libssnode, 'ssn_debug_duo_stamps_fine'):          # diagnostic build (-DSSN_DUO_STAMP=1)
+            import ctypes
+            buf = (ctypes.c_ulonglong * 64)()
+            clib.libssnode.ssn_debug_duo_stamps_fine(buf)
+            for w in range(8):
+                n = max(int(buf[8 * w + 5]), 1)
+                print('  workgroup 0, draw %d, wave %d, cycles per step: chain + early %.0f, verdict %.0f, barrier %.0f, serial %.0f, '
+                      'barrier %.0f  (%d steps)' % ((w // 4, w % 4) + tuple(buf[8 * w + i] / n for i in range(5)) + (n,)), flush=True)
 
 if __name__ == '__main__':
     main()
