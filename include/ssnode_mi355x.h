@@ -388,6 +388,39 @@ typedef struct ssn_critic_step {
     float *acc_dvals, *tail;
 } ssn_critic_step;
 int ssn_critic_step_run(const ssn_critic_step *a, void *stream);
+/* The same with the rule of cwgan.py:493-498 decided on the device: the optimizer step (parameters AND optimizer state) is
+ * skipped when the batch's rate penalty pens64[1] exceeds rate_penalty_bound (> 0; pens64 required).  Everything else runs and
+ * is written as in ssn_critic_step_run -- the caller reads tail[1], sees the bound exceeded and reports the step as skipped
+ * (loss and accuracy NaN in the reference's record); no host round trip, no snapshot to roll back to. */
+int ssn_critic_step_gated_run(const ssn_critic_step *a, double rate_penalty_bound, void *stream);
+
+/*
+ * End of a generator step (GeneratorTrainer, networks/wgan.py:218-260) in two calls, with the job's all-reduce (if any)
+ * between them.  ssn_gen_grads_f32, ONE launch: out[nv + 12 + 1] = {dL/dV (nv = 0: none; 1: 'deg-heteroin', one V for both
+ * populations; 2: 'heteroin', V_E, V_I), dL/dJ[4], dL/dD[4], dL/dS[4], loss} from jds_part (device [B][4][3], the output of
+ * ssn_jds_grad_*), the input-variability pieces g_ext, ext_base (device [B][NB][M]) and zin (device [B][M]) --
+ * dL/dV_pop = sum over draws, stimuli and the population's neurons of g_ext ext_base zin (networks/ssn.py:679-686) --
+ * and loss = -dmean[0] + dynamics_cost pens64[0] + rate_cost pens64[1] (wgan.py:236-241; dmean: mean D(G(z)), stats[0] of
+ * ssn_critic_input_grad*; pens64 may be NULL = 0).  Sums in fp64, fixed order.  ws: device scratch of
+ * ssn_gen_grads_ws_doubles() doubles whose LAST 8 bytes are zero before the first call (the kernel leaves them zero).
+ * ssn_gen_apply_f32, ONE launch: the update of ssn_optimizer_step on all n parameters at once with per-element clip bounds
+ * clip_lo / clip_hi (device [n]; both NULL = opt's scalar rule) -- the reference clips with numpy broadcasting,
+ * wgan.py:244-251 -- and record[n + 1] (device, or NULL) = the new values followed by grads[n] (the loss riding behind the
+ * gradient vector).
+ */
+typedef struct ssn_gen_grads {
+    const double *jds_part; int B;
+    int nv;
+    const float *g_ext, *ext_base, *zin; int NB, M;
+    const float *dmean; const double *pens64;
+    double dynamics_cost, rate_cost;
+    double *ws;
+    float *out;
+} ssn_gen_grads;
+long ssn_gen_grads_ws_doubles(void);
+int ssn_gen_grads_f32(const ssn_gen_grads *a, void *stream);
+int ssn_gen_apply_f32(float *params, const float *grads, float *s1, float *s2, int n, const ssn_opt_params *opt,
+                      const float *clip_lo, const float *clip_hi, float *record, void *stream);
 
 /* ------------------------------------------------------------------------
  * 5. Feed-forward tuning-curve generator (FF_lalazar model; BASELINE config 5): replaces the Theano
@@ -464,6 +497,15 @@ int ssn_penalty_means_f32(const float *dyn_row, const float *rate_row, long n, d
                           double *ws, double *out, void *stream);
 int ssn_penalty_means_f64(const double *dyn_row, const double *rate_row, long n, double scale_dyn, double scale_rate,
                           double *ws, double *out, void *stream);
+/* The same launch with the conditional prober's gather riding along (cwgan.py:91-98; one launch instead of two):
+ * tc[k][s] = time_avg[ids[k]][s][probes[k]] for k < nsamp, s < NB (time_avg: device [B][NB][M]; ids, probes: device int64
+ * [nsamp], 0 <= ids < B, 0 <= probes < M; tc: device [nsamp][NB]).  nsamp = 0: exactly ssn_penalty_means_*. */
+int ssn_penalty_means_probe_f32(const float *dyn_row, const float *rate_row, long n, double scale_dyn, double scale_rate,
+                                double *ws, double *out, const float *time_avg, const long *ids, const long *probes,
+                                float *tc, int nsamp, int NB, int M, void *stream);
+int ssn_penalty_means_probe_f64(const double *dyn_row, const double *rate_row, long n, double scale_dyn, double scale_rate,
+                                double *ws, double *out, const double *time_avg, const long *ids, const long *probes,
+                                double *tc, int nsamp, int NB, int M, void *stream);
 /* Per-step helpers of the GAN loop.  ssn_segment_sqnorms2_f32: out[t] = sum of x[i]^2 over
  * bounds[t] <= i < bounds[t + 1] (the per-tensor critic statistics of recorders.py:275-311; bounds: device [n + 1], out:
  * device [n]; ws: device scratch of ssn_segment_sqnorms_ws_doubles(n) doubles; every tensor is cut into chunks summed by

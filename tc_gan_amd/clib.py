@@ -133,6 +133,10 @@ for _name in ('ssn_philox_amp_f32', 'ssn_philox_amp_f64'):
 for _name in ('ssn_penalty_means_f32', 'ssn_penalty_means_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_long, c_double, c_double, c_void_p, c_void_p, c_void_p]
     getattr(libssnode, _name).restype = c_int
+for _name in ('ssn_penalty_means_probe_f32', 'ssn_penalty_means_probe_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_long, c_double, c_double, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+    getattr(libssnode, _name).restype = c_int
 for _name in ('ssn_lu_solve_f32', 'ssn_lu_solve_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
     getattr(libssnode, _name).restype = c_int
@@ -228,6 +232,27 @@ class CriticStep(Structure):
 
 libssnode.ssn_critic_step_run.argtypes = [POINTER(CriticStep), c_void_p]
 libssnode.ssn_critic_step_run.restype = c_int
+libssnode.ssn_critic_step_gated_run.argtypes = [POINTER(CriticStep), c_double, c_void_p]
+libssnode.ssn_critic_step_gated_run.restype = c_int
+
+
+class GenGrads(Structure):
+    """``ssn_gen_grads`` of include/ssnode_mi355x.h."""
+    _fields_ = [
+        ('jds_part', c_void_p), ('B', c_int), ('nv', c_int),
+        ('g_ext', c_void_p), ('ext_base', c_void_p), ('zin', c_void_p), ('NB', c_int), ('M', c_int),
+        ('dmean', c_void_p), ('pens64', c_void_p), ('dynamics_cost', c_double), ('rate_cost', c_double),
+        ('ws', c_void_p), ('out', c_void_p),
+    ]
+
+
+libssnode.ssn_gen_grads_ws_doubles.argtypes = []
+libssnode.ssn_gen_grads_ws_doubles.restype = c_long
+libssnode.ssn_gen_grads_f32.argtypes = [POINTER(GenGrads), c_void_p]
+libssnode.ssn_gen_grads_f32.restype = c_int
+libssnode.ssn_gen_apply_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(OptParams), c_void_p, c_void_p,
+                                        c_void_p, c_void_p]
+libssnode.ssn_gen_apply_f32.restype = c_int
 libssnode.ssn_critic_num_params.argtypes = [_ip, c_int]
 libssnode.ssn_critic_num_params.restype = c_long
 libssnode.ssn_critic_workspace_floats.argtypes = [_ip, c_int, c_int, c_int]
@@ -307,11 +332,12 @@ DECLARED_SYMBOLS = (
     'ssn_critic_norm_workspace_floats', 'ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm',
     'ssn_critic_input_grad_norm', 'ssn_philox_uniform_f32', 'ssn_philox_uniform_f64',
     'ssn_weight_grad_f32', 'ssn_weight_grad_f64', 'ssn_lu_solve_f32', 'ssn_lu_solve_f64',
-    'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
+    'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_penalty_means_probe_f32', 'ssn_penalty_means_probe_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
     'ssn_segment_sqnorms_f32', 'ssn_segment_sqnorms2_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
     'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
-    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_gen_inputs_philox_f32',
+    'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_critic_step_gated_run', 'ssn_gen_grads_ws_doubles', 'ssn_gen_grads_f32', 'ssn_gen_apply_f32',
+    'ssn_gen_inputs_philox_f32',
 )
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]

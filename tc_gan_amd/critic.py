@@ -277,7 +277,7 @@ class Critic(object):
     def accuracy(self, xg, cg, xd, cd):
         return float(self.accuracy_device(xg, cg, xd, cd)[0])
 
-    def step(self, updater, xg, xd, cond, eps, lmd, pens64=None):
+    def step(self, updater, xg, xd, cond, eps, lmd, pens64=None, rate_penalty_bound=None):
         """One critic step of the GAN loop in ONE library call (`ssn_critic_step_run`): penalty points, loss + gradient,
         `updater`'s step on the parameters, accuracy of the updated critic, per-tensor sums of squares -- the kernels of
         `interpolate`, `loss_grad`, `Updater.__call__` (plain clip-free form), `accuracy_device`, `param_sqnorms_device` in
@@ -306,7 +306,13 @@ class Critic(object):
             workspace=ws.data_ptr(), opt_s1=s1.data_ptr(), opt_s2=s2.data_ptr(), opt=ctypes.pointer(opt),
             seg_bounds=self._seg_bounds.data_ptr(), nseg=nseg, seg_ws=self._seg_ws.data_ptr(),
             pens64=pens64.data_ptr() if pens64 is not None else None, acc_dvals=dv.data_ptr(), tail=tail.data_ptr())
-        clib.check(libssnode.ssn_critic_step_run(ctypes.byref(a), _stream()), 'ssn_critic_step_run')
+        if rate_penalty_bound is not None and rate_penalty_bound > 0:
+            # cwgan.py:493-498 on the device: no update (parameters, optimizer state) when the batch's rate penalty exceeds the
+            # bound; the caller learns it from tail[1] and takes the step count back (`Updater.uncommit_step`)
+            clib.check(libssnode.ssn_critic_step_gated_run(ctypes.byref(a), float(rate_penalty_bound), _stream()),
+                       'ssn_critic_step_gated_run')
+        else:
+            clib.check(libssnode.ssn_critic_step_run(ctypes.byref(a), _stream()), 'ssn_critic_step_run')
         updater.commit_step(opt)          # (only now: a refused launch leaves the step count, hence Adam's bias correction, alone)
         return xp, tail
 
@@ -373,6 +379,10 @@ class Updater(object):
 
     def commit_step(self, opt):
         self.step = int(opt.step)
+
+    def uncommit_step(self):
+        """The last committed update turned out not to have been made (the device-side gate of `Critic.step`)."""
+        self.step -= 1
 
     def __call__(self, params, grads, clip=None):
         """In-place update of the flat device tensor `params` from `grads`.  `clip` = (lo, hi): scalars, or arrays of the

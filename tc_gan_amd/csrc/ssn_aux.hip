@@ -10,9 +10,6 @@ namespace ssn {
 // W[b][pN+i][qN+j] = exp(-(x_i-x_j)^2/(2 S_pq^2)) * sign_q * (J_pq + D_pq z[b][pN+i][qN+j])
 // (gradient_expressions/make_w_batch.py:8-34; weight_gen.py:13-26).  8 B/element of HBM
 // traffic; one thread per 4 consecutive columns when M % 4 == 0 (16-B accesses).
-template <typename T>
-struct JDS { T J[4], D[4], inv2s2[4]; };
-
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) build_w_kernel(const T* __restrict__ z, T* __restrict__ W, JDS<T> p,
                                                       int N, long total_vec) {
@@ -74,12 +71,12 @@ template hipError_t launch_build_w<double>(const double*, const double*, double*
 
 // ext[b][s][pN+i] = c * sig((x_i + bw/2)/l) * sig((bw/2 - x_i)/l)   (stimuli.py:3-10)
 template <typename T>
-__global__ void __launch_bounds__(256) stimulus_kernel(const T* __restrict__ bw, const T* __restrict__ con, T inv_l,
-                                                       const T* __restrict__ amp, int NB,
-                                                       T* __restrict__ ext, int N, long total) {
+__device__ __forceinline__ void stimulus_body(const T* __restrict__ bw, const T* __restrict__ con, T inv_l,
+                                              const T* __restrict__ amp, int NB, T* __restrict__ ext, int N, long total,
+                                              long blk, long nblk) {
     const int M = 2 * N;
     const T step = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    for (long e = blk * 256L + threadIdx.x; e < total; e += nblk * 256L) {
         const int m = (int)(e % M);
         const long bs = e / M;
         const int i = m >= N ? m - N : m;
@@ -91,6 +88,12 @@ __global__ void __launch_bounds__(256) stimulus_kernel(const T* __restrict__ bw,
         const T gain = amp ? amp[(bs / NB) * M + m] : (T)1;
         ext[e] = gain * con[bs] * s1 * s2;
     }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) stimulus_kernel(const T* __restrict__ bw, const T* __restrict__ con, T inv_l,
+                                                       const T* __restrict__ amp, int NB,
+                                                       T* __restrict__ ext, int N, long total) {
+    stimulus_body<T>(bw, con, inv_l, amp, NB, ext, N, total, blockIdx.x, gridDim.x);
 }
 template <typename T>
 hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st) {
@@ -263,12 +266,12 @@ hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long off
 // the caller keeps it (the generator step's chain rule needs it, the five critic-phase forwards of a GAN iteration do not):
 // 4 instead of 12 bytes of HBM traffic per element and one launch instead of two.  One thread per 4 consecutive columns.
 template <typename T>
-__global__ void __launch_bounds__(256) build_w_philox_kernel(unsigned long long seed, unsigned long long offset, T* __restrict__ W,
-                                                             T* __restrict__ zout, JDS<T> p, int N, long total_vec) {
+__device__ __forceinline__ void build_w_philox_body(unsigned long long seed, unsigned long long offset, T* __restrict__ W,
+                                                    T* __restrict__ zout, const JDS<T>& p, int N, long total_vec, long blk0, long nblk) {
     const int M = 2 * N;
     const T inv_nm1 = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
     const unsigned mis = (unsigned)(offset & 3ull);           // (uniform) the 4 elements straddle two Philox blocks when != 0
-    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total_vec; v += (long)gridDim.x * blockDim.x) {
+    for (long v = blk0 * 256L + threadIdx.x; v < total_vec; v += nblk * 256L) {
         const long e0 = v * 4;
         const unsigned long long g0 = offset + (unsigned long long)e0, blk = g0 >> 2;
         unsigned w[8];
@@ -297,6 +300,11 @@ __global__ void __launch_bounds__(256) build_w_philox_kernel(unsigned long long 
             *reinterpret_cast<V4*>(zout + e0) = zq;
         }
     }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) build_w_philox_kernel(unsigned long long seed, unsigned long long offset, T* __restrict__ W,
+                                                             T* __restrict__ zout, JDS<T> p, int N, long total_vec) {
+    build_w_philox_body<T>(seed, offset, W, zout, p, N, total_vec, blockIdx.x, gridDim.x);
 }
 // M even and 16-byte aligned outputs (the caller checks; other shapes take the two-kernel path)
 template <typename T>
@@ -356,6 +364,79 @@ hipError_t launch_philox_amp(unsigned long long seed, unsigned long long offset,
 template hipError_t launch_philox_amp<float>(unsigned long long, unsigned long long, const float*, float*, float*, unsigned long long, int, int, hipStream_t);
 template hipError_t launch_philox_amp<double>(unsigned long long, unsigned long long, const double*, double*, double*, unsigned long long, int, int, hipStream_t);
 
+// The inputs of a device-noise forward in ONE launch (ssn_gen_inputs_philox_f32; three launches until round 4): the grid is
+// cut in three ranges of workgroups that run the bodies of philox_amp_kernel (heterogeneous-input noise z and 1 + v z),
+// stimulus_kernel and build_w_philox_kernel.  The stimulus needs 1 + v z of its own (draw, neuron): it forms the number
+// again from the same stream element (ten Philox rounds per element, on a kernel of a few microseconds) instead of waiting
+// for the first range -- same expression, same bits as the stored `amp`.
+__global__ void __launch_bounds__(256) gen_inputs_kernel(GenInputsArgs a) {
+    const long blk = blockIdx.x;
+    const int M = 2 * a.N;
+    if (blk < a.nb_w) {
+        build_w_philox_body<float>(a.seed, a.off_z, a.W, a.z, a.p, a.N, a.total_vec, blk, a.nb_w);
+    } else if (blk < a.nb_w + a.nb_s) {
+        const long b0 = blk - a.nb_w;
+        if (!a.v) { stimulus_body<float>(a.bw, a.con, a.inv_l, nullptr, a.NB, a.ext, a.N, a.total_s, b0, a.nb_s); return; }
+        const float step = (a.N > 1) ? 1.f / (float)(a.N - 1) : 0.f;
+        for (long e = b0 * 256L + threadIdx.x; e < a.total_s; e += a.nb_s * 256L) {
+            const int m = (int)(e % M);
+            const long bs = e / M;
+            const int i = m >= a.N ? m - a.N : m;
+            const float x = -0.5f + step * (float)i;
+            const float hb = a.bw[bs] * 0.5f;
+            const float s1 = 1.f / (1.f + exp(-(x + hb) * a.inv_l));
+            const float s2 = 1.f / (1.f + exp(-(hb - x) * a.inv_l));
+            const unsigned long long g = a.off_zin + (unsigned long long)((bs / a.NB) * M + m);
+            unsigned w[4];
+            philox4x32_10((unsigned)(g >> 2), (unsigned)(g >> 34), 0u, 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), w);
+            const float u = (float)(w[g & 3ull] >> 8) * (1.0f / 16777216.0f);
+            const float z = a.bernoulli ? (u < 0.5f ? 1.f : -1.f) : u * 2.f - 1.f;
+            const float gain = 1.f + a.v[m] * z;
+            a.ext[e] = gain * a.con[bs] * s1 * s2;
+        }
+    } else {
+        const long b0 = blk - a.nb_w - a.nb_s, nblk = (long)gridDim.x - a.nb_w - a.nb_s;
+        const unsigned long long n = (unsigned long long)a.B * M, first_blk = a.off_zin >> 2, last_blk = (a.off_zin + n + 3) >> 2;
+        for (unsigned long long pb = first_blk + (unsigned long long)b0 * 256ull + threadIdx.x; pb < last_blk; pb += (unsigned long long)nblk * 256ull) {
+            unsigned w[4];
+            philox4x32_10((unsigned)pb, (unsigned)(pb >> 32), 0u, 0u, (unsigned)a.seed, (unsigned)(a.seed >> 32), w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long g = 4 * pb + j;
+                if (g >= a.off_zin && g < a.off_zin + n) {
+                    const unsigned long long i = g - a.off_zin;
+                    const float u = (float)(w[j] >> 8) * (1.0f / 16777216.0f);
+                    const float z = a.bernoulli ? (u < 0.5f ? 1.f : -1.f) : u * 2.f - 1.f;
+                    a.zin[i] = z;
+                    a.amp[i] = 1.f + a.v[i % (unsigned long long)M] * z;
+                }
+            }
+        }
+    }
+}
+hipError_t launch_gen_inputs(GenInputsArgs a, const float* jds12, hipStream_t st) {
+    for (int q = 0; q < 4; ++q) {
+        a.p.J[q] = jds12[q];
+        a.p.D[q] = jds12[4 + q];
+        a.p.inv2s2[q] = 1.f / (2.f * jds12[8 + q] * jds12[8 + q]);
+    }
+    const int M = 2 * a.N;
+    const long total = (long)a.B * M * M;
+    if (total == 0) return hipSuccess;
+    if ((((uintptr_t)a.W | (uintptr_t)a.z) % 16) != 0) return hipErrorInvalidValue;
+    a.total_vec = total / 4;
+    a.total_s = (long)a.B * a.NB * M;
+    a.nb_w = (a.total_vec + 255) / 256 < 256 * 16 ? (a.total_vec + 255) / 256 : 256 * 16;       // (the grids of the three launches)
+    a.nb_s = a.total_s ? ((a.total_s + 255) / 256 < 2048 ? (a.total_s + 255) / 256 : 2048) : 0;
+    long nb_a = 0;
+    if (a.v) {
+        nb_a = (long)((((unsigned long long)a.B * M + 3) / 4 + 1 + 255) / 256);
+        if (nb_a > 8192) nb_a = 8192;
+    }
+    hipLaunchKernelGGL(gen_inputs_kernel, dim3((unsigned)(a.nb_w + a.nb_s + nb_a)), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
 template hipError_t launch_philox_uniform<float>(unsigned long long, unsigned long long, float*, unsigned long long, hipStream_t);
 template hipError_t launch_philox_uniform<double>(unsigned long long, unsigned long long, double*, unsigned long long, hipStream_t);
 
@@ -367,12 +448,21 @@ template hipError_t launch_philox_uniform<double>(unsigned long long, unsigned l
 // first launch).
 // ---------------------------------------------------------------------------------
 constexpr int PEN_BLOCKS = 256;
+// (optional rider, round 4: the conditional prober's gather tc[k][s] = time_avg[ids[k]][s][probes[k]] (cwgan.py:91-98) of the
+// same forward, which used to be a launch of its own between this one and the critic -- plain copies, spread over the grid)
+template <typename T>
+struct ProbeGather { const T* time_avg; const long* ids; const long* probes; T* tc; long count; int NB, M; };
 template <typename T>
 __global__ void __launch_bounds__(256) penalty_means_kernel(const T* __restrict__ dyn, const T* __restrict__ rate, long n,
                                                             double scale_dyn, double scale_rate, double* __restrict__ ws,
-                                                            double* __restrict__ out) {
+                                                            double* __restrict__ out, ProbeGather<T> pg) {
     __shared__ double red[2][256];
     __shared__ int last;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < pg.count; e += (long)gridDim.x * 256L) {
+        const long k = e / pg.NB;
+        const int sidx = (int)(e % pg.NB);
+        pg.tc[e] = pg.time_avg[((size_t)pg.ids[k] * pg.NB + sidx) * pg.M + pg.probes[k]];
+    }
     double s0 = 0.0, s1 = 0.0;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += (long)gridDim.x * 256L) { s0 += (double)dyn[e]; s1 += (double)rate[e]; }
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
@@ -435,15 +525,19 @@ hipError_t launch_mean_diff(const float* d, int ng, int nd, float* out, hipStrea
 
 template <typename T>
 hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws,
-                                double* out, hipStream_t st) {
+                                double* out, hipStream_t st, const T* time_avg, const long* ids, const long* probes, T* tc,
+                                int nsamp, int NB, int M) {
     long blocks = (n + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > PEN_BLOCKS) blocks = PEN_BLOCKS;
-    hipLaunchKernelGGL((penalty_means_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, dyn, rate, n, scale_dyn, scale_rate, ws, out);
+    ProbeGather<T> pg{time_avg, ids, probes, tc, tc ? (long)nsamp * NB : 0L, NB, M};
+    hipLaunchKernelGGL((penalty_means_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, st, dyn, rate, n, scale_dyn, scale_rate, ws, out, pg);
     return hipGetLastError();
 }
-template hipError_t launch_penalty_means<float>(const float*, const float*, long, double, double, double*, double*, hipStream_t);
-template hipError_t launch_penalty_means<double>(const double*, const double*, long, double, double, double*, double*, hipStream_t);
+template hipError_t launch_penalty_means<float>(const float*, const float*, long, double, double, double*, double*, hipStream_t,
+                                                const float*, const long*, const long*, float*, int, int, int);
+template hipError_t launch_penalty_means<double>(const double*, const double*, long, double, double, double*, double*, hipStream_t,
+                                                 const double*, const long*, const long*, double*, int, int, int);
 
 // ---------------------------------------------------------------------------------
 // Small per-step helpers of the GAN loop (one launch each instead of three to five element-wise ones).
@@ -478,6 +572,41 @@ __global__ void __launch_bounds__(64) segment_sqnorms_finish_kernel(const double
     double s = 0.0;
     for (int c = 0; c < SQ_CHUNKS; ++c) s += ws[(size_t)t * SQ_CHUNKS + c];
     out[t] = (float)s;
+}
+// The end of a one-call critic step in ONE launch (three until round 4: mean_diff_kernel, segment_sqnorms_finish_kernel,
+// step_head_kernel): tail[0..1] = the forward's penalties, tail[2] = the loss, tail[3] = mean D(xg) - mean D(xd) of the
+// updated critic (fixed order, as mean_diff_kernel), tail[4 + t] = sum of squares of parameter tensor t (chunks in chunk
+// order, as segment_sqnorms_finish_kernel): the same bits as the three launches.
+__global__ void __launch_bounds__(256) step_finish_kernel(const float* __restrict__ d, int ng, int nd, const double* __restrict__ pens,
+                                                          const float* __restrict__ stats, const double* __restrict__ ws, int nseg,
+                                                          float* __restrict__ tail) {
+    __shared__ float red[2][256];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < ng; i += 256) a += d[i];
+    for (int i = threadIdx.x; i < nd; i += 256) b += d[ng + i];
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) { red[0][threadIdx.x] += red[0][threadIdx.x + off]; red[1][threadIdx.x] += red[1][threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tail[0] = pens ? (float)pens[0] : 0.f;
+        tail[1] = pens ? (float)pens[1] : 0.f;
+        tail[2] = stats[3];
+        tail[3] = (ng ? red[0][0] / ng : 0.f) - (nd ? red[1][0] / nd : 0.f);
+    }
+    for (int t = threadIdx.x; t < nseg; t += 256) {
+        double s = 0.0;
+        for (int c = 0; c < SQ_CHUNKS; ++c) s += ws[(size_t)t * SQ_CHUNKS + c];
+        tail[4 + t] = (float)s;
+    }
+}
+hipError_t launch_step_finish(const float* params, const long* bounds, int nseg, double* ws, const float* dvals, int ng, int nd,
+                              const double* pens, const float* stats, float* tail, hipStream_t st) {
+    if (nseg > 0) hipLaunchKernelGGL(segment_sqnorms_kernel, dim3(SQ_CHUNKS, nseg), dim3(256), 0, st, params, bounds, ws);
+    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(256), 0, st, dvals, ng, nd, pens, stats, ws, nseg, tail);
+    return hipGetLastError();
 }
 long segment_sqnorms_ws_doubles(int n) { return (long)(n > 0 ? n : 0) * SQ_CHUNKS; }
 hipError_t launch_segment_sqnorms(const float* x, const long* bounds, int n, float* out, double* ws, hipStream_t st) {

@@ -693,9 +693,20 @@ int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* 
 }
 // mean D(xg) - mean D(xd) in one call (two critic forwards into `dvals`, one reduction in a fixed order): layer_norm NULL or all
 // zero = plain layers, leak as in the _leaky entry points.
+static int critic_accuracy_forwards(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
+                                    const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type,
+                                    float* dvals, float* workspace, int precision, void* stream);
 int ssn_critic_accuracy(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
                         const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type, float* acc,
                         float* dvals, float* workspace, int precision, void* stream) {
+    if (int rc = critic_accuracy_forwards(params, dims, layer_norm, nlayers, leak, xg, cg, xd, cd, ng, nd, hide_cell_type, dvals,
+                                          workspace, precision, stream)) return rc;
+    SSN_TRY(ssn::launch_mean_diff(dvals, ng, nd, acc, (hipStream_t)stream));
+    return 0;
+}
+static int critic_accuracy_forwards(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
+                                    const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type,
+                                    float* dvals, float* workspace, int precision, void* stream) {
     bool norm = false;
     for (int l = 0; layer_norm && l < nlayers; ++l) norm = norm || layer_norm[l] != 0;
     const struct { const float* x; const float* c; int n; float* out; } part[2] = {{xg, cg, ng, dvals}, {xd, cd, nd, dvals + ng}};
@@ -709,15 +720,30 @@ int ssn_critic_accuracy(const float* params, const int* dims, const int* layer_n
                                      workspace, precision, stream);
         if (rc) return rc;
     }
-    SSN_TRY(ssn::launch_mean_diff(dvals, ng, nd, acc, (hipStream_t)stream));
     return 0;
 }
+static int optimizer_step_full(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, const double* gate,
+                               double gate_bound, const float* clip_lo_v, const float* clip_hi_v, float* record, const float* record_tail,
+                               void* stream);
+static int optimizer_step_gated(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, const double* gate,
+                                double gate_bound, void* stream);
 int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, void* stream) {
+    return optimizer_step_gated(p, g, s1, s2, n, o, nullptr, 0.0, stream);
+}
+static int optimizer_step_gated(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, const double* gate,
+                                double gate_bound, void* stream) {
+    return optimizer_step_full(p, g, s1, s2, n, o, gate, gate_bound, nullptr, nullptr, nullptr, nullptr, stream);
+}
+static int optimizer_step_full(float* p, const float* g, float* s1, float* s2, long n, const ssn_opt_params* o, const double* gate,
+                               double gate_bound, const float* clip_lo_v, const float* clip_hi_v, float* record, const float* record_tail,
+                               void* stream) {
     if (!o || n < 0 || o->kind < 0 || o->kind > 2) {
         g_last_error = "ssn_optimizer_step: invalid argument";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
     ssn::OptArgs a;
+    a.gate = gate; a.gate_bound = gate_bound;
+    a.clip_lo_v = clip_lo_v; a.clip_hi_v = clip_hi_v; a.record = record; a.record_tail = record_tail;
     a.p = p; a.g = g; a.s1 = s1; a.s2 = s2; a.n = n; a.kind = o->kind;
     a.lr = (float)o->learning_rate; a.beta1 = (float)o->beta1; a.beta2 = (float)o->beta2; a.eps = (float)o->epsilon;
     a.rho = (float)o->rho;
@@ -730,7 +756,38 @@ int ssn_optimizer_step(float* p, const float* g, float* s1, float* s2, long n, c
     return 0;
 }
 
-int ssn_critic_step_run(const ssn_critic_step* a, void* stream) {
+long ssn_gen_grads_ws_doubles(void) { return 2 * 128 + 1; }
+int ssn_gen_grads_f32(const ssn_gen_grads* a, void* stream) {
+    if (!a || !a->jds_part || a->B < 0 || a->nv < 0 || a->nv > 2 || !a->dmean || !a->ws || !a->out ||
+        (a->nv > 0 && (!a->g_ext || !a->ext_base || !a->zin || a->NB <= 0 || a->M <= 0 || (a->M & 1)))) {
+        g_last_error = "ssn_gen_grads: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::GenGradsArgs g{};
+    g.part = a->jds_part; g.B = a->B; g.nv = a->nv; g.g_ext = a->g_ext; g.ext_base = a->ext_base; g.zin = a->zin;
+    g.NB = a->NB; g.M = a->M; g.dmean = a->dmean; g.pens = a->pens64; g.dynamics_cost = a->dynamics_cost; g.rate_cost = a->rate_cost;
+    g.ws = a->ws; g.out = a->out;
+    SSN_TRY(ssn::launch_gen_grads(g, (hipStream_t)stream));
+    return 0;
+}
+int ssn_gen_apply_f32(float* params, const float* grads, float* s1, float* s2, int n, const ssn_opt_params* opt, const float* clip_lo,
+                      const float* clip_hi, float* record, void* stream) {
+    if (!params || !grads || n <= 0 || (clip_lo == nullptr) != (clip_hi == nullptr)) {
+        g_last_error = "ssn_gen_apply: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    return optimizer_step_full(params, grads, s1, s2, n, opt, nullptr, 0.0, clip_lo, clip_hi, record, record ? grads + n : nullptr, stream);
+}
+static int critic_step_impl(const ssn_critic_step* a, const double* gate, double gate_bound, void* stream);
+int ssn_critic_step_run(const ssn_critic_step* a, void* stream) { return critic_step_impl(a, nullptr, 0.0, stream); }
+int ssn_critic_step_gated_run(const ssn_critic_step* a, double rate_penalty_bound, void* stream) {
+    if (!a || !a->pens64 || !(rate_penalty_bound > 0.0)) {
+        g_last_error = "ssn_critic_step_gated_run: needs pens64 and a positive bound";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    return critic_step_impl(a, a->pens64 + 1, rate_penalty_bound, stream);
+}
+static int critic_step_impl(const ssn_critic_step* a, const double* gate, double gate_bound, void* stream) {
     if (!a || !a->params || !a->dims || !a->xg || !a->xd || !a->eps || !a->xp || !a->grads || !a->stats || !a->dvals ||
         !a->workspace || !a->opt || !a->acc_dvals || !a->tail || a->n <= 0 || a->nlayers < 0 || a->nseg < 0) {
         g_last_error = "ssn_critic_step_run: invalid argument";
@@ -750,11 +807,14 @@ int ssn_critic_step_run(const ssn_critic_step* a, void* stream) {
                                    a->hide_cell_type, a->grads, a->stats, a->dvals, a->workspace, a->precision, stream);
     if (rc) return rc;
     const long nparams = ssn_critic_num_params(a->dims, a->nlayers);
-    if ((rc = ssn_optimizer_step(a->params, a->grads, a->opt_s1, a->opt_s2, nparams, a->opt, stream))) return rc;
-    if ((rc = ssn_critic_accuracy(a->params, a->dims, a->layer_norm, a->nlayers, a->leak, a->xg, a->cond, a->xd, a->cond, n, n,
-                                  a->hide_cell_type, a->tail + 3, a->acc_dvals, a->workspace, a->precision, stream))) return rc;
-    if (a->nseg > 0 && (rc = ssn_segment_sqnorms2_f32(a->params, a->seg_bounds, a->nseg, a->tail + 4, a->seg_ws, stream))) return rc;
-    SSN_TRY(ssn::launch_step_head(a->pens64, a->stats, a->tail, (hipStream_t)stream));
+    if ((rc = optimizer_step_gated(a->params, a->grads, a->opt_s1, a->opt_s2, nparams, a->opt, gate, gate_bound, stream))) return rc;
+    if ((rc = critic_accuracy_forwards(a->params, a->dims, a->layer_norm, a->nlayers, a->leak, a->xg, a->cond, a->xd, a->cond, n, n,
+                                       a->hide_cell_type, a->acc_dvals, a->workspace, a->precision, stream))) return rc;
+    if (a->nseg > 0 && (!a->seg_bounds || !a->seg_ws)) { g_last_error = "ssn_critic_step_run: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    // accuracy, sums of squares and the head of the record: the chunk sums, then ONE finishing launch (same bits as
+    // ssn_critic_accuracy + ssn_segment_sqnorms2_f32 + the head kernel)
+    SSN_TRY(ssn::launch_step_finish(a->params, a->seg_bounds, a->nseg, a->seg_ws, a->acc_dvals, n, n, a->pens64, a->stats, a->tail,
+                                    (hipStream_t)stream));
     return 0;
 }
 
@@ -1030,12 +1090,16 @@ int ssn_gen_inputs_philox_f32(const ssn_gen_inputs* a, void* stream) {
         g_last_error = "ssn_gen_inputs_philox: invalid argument";
         return SSN_ERR_BASE + (int)hipErrorInvalidValue;
     }
-    const int M = 2 * a->N;
-    int rc;
-    if (a->v && (rc = ssn_philox_amp_f32(a->seed, a->off_zin, a->v, a->zin, a->amp, (unsigned long long)a->B * M, M, a->bernoulli, stream)))
-        return rc;
-    if ((rc = ssn_stimulus_amp_f32(a->bw, a->con, a->smoothness, a->v ? a->amp : nullptr, a->ext, a->B, a->NB, a->N, stream))) return rc;
-    return ssn_build_w_philox_f32(a->seed, a->off_z, a->J, a->D, a->S, a->W, a->z, a->B, a->N, stream);
+    // one launch (ssn_aux.hip: gen_inputs_kernel): the numbers of ssn_philox_amp_f32, ssn_stimulus_amp_f32 and
+    // ssn_build_w_philox_f32 called in that order
+    ssn::GenInputsArgs g{};
+    g.seed = a->seed; g.off_z = a->off_z; g.off_zin = a->off_zin;
+    g.bw = a->bw; g.con = a->con; g.v = a->v; g.inv_l = 1.f / a->smoothness; g.bernoulli = a->bernoulli;
+    g.W = a->W; g.z = a->z; g.zin = a->zin; g.amp = a->amp; g.ext = a->ext;
+    g.B = a->B; g.NB = a->NB; g.N = a->N;
+    const float jds12[12] = {a->J[0], a->J[1], a->J[2], a->J[3], a->D[0], a->D[1], a->D[2], a->D[3], a->S[0], a->S[1], a->S[2], a->S[3]};
+    SSN_TRY(ssn::launch_gen_inputs(g, jds12, (hipStream_t)stream));
+    return 0;
 }
 int ssn_stimulus_f32(const float* bw, const float* con, float smoothness, float* ext, int B, int NB, int N, void* stream) {
     SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, nullptr, ext, B, NB, N, (hipStream_t)stream));
@@ -1097,6 +1161,24 @@ int ssn_penalty_means_f32(const float* dyn, const float* rate, long n, double sc
 int ssn_penalty_means_f64(const double* dyn, const double* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, void* stream) {
     if (n < 0 || !ws || !out || (n > 0 && (!dyn || !rate))) { g_last_error = "ssn_penalty_means: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::launch_penalty_means<double>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream));
+    return 0;
+}
+int ssn_penalty_means_probe_f32(const float* dyn, const float* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out,
+                                const float* time_avg, const long* ids, const long* probes, float* tc, int nsamp, int NB, int M, void* stream) {
+    if (n < 0 || !ws || !out || (n > 0 && (!dyn || !rate)) || nsamp < 0 || NB < 0 || M < 0 || (nsamp > 0 && (!time_avg || !ids || !probes || !tc))) {
+        g_last_error = "ssn_penalty_means_probe: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_penalty_means<float>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream, time_avg, ids, probes,
+                                             nsamp > 0 ? tc : nullptr, nsamp, NB, M));
+    return 0;
+}
+int ssn_penalty_means_probe_f64(const double* dyn, const double* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out,
+                                const double* time_avg, const long* ids, const long* probes, double* tc, int nsamp, int NB, int M, void* stream) {
+    if (n < 0 || !ws || !out || (n > 0 && (!dyn || !rate)) || nsamp < 0 || NB < 0 || M < 0 || (nsamp > 0 && (!time_avg || !ids || !probes || !tc))) {
+        g_last_error = "ssn_penalty_means_probe: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_penalty_means<double>(dyn, rate, n, scale_dyn, scale_rate, ws, out, (hipStream_t)stream, time_avg, ids, probes,
+                                              nsamp > 0 ? tc : nullptr, nsamp, NB, M));
     return 0;
 }
 int ssn_philox_amp_f32(unsigned long long seed, unsigned long long offset, const float* v, float* zin, float* amp, unsigned long long n, int M, int bernoulli, void* stream) {

@@ -761,6 +761,9 @@ hipError_t critic_gather_scale(const float* v0, float* gx, int batch, int n0, in
 // optimizers (wgan.py:111-165 on top of lasagne.updates.{adam,rmsprop,sgd})
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) optimizer_kernel(OptArgs o) {
+    // (compared in fp32, the precision in which the caller reads the penalty back: host and device take the same decision;
+    // NaN compares false: the update is made, as cwgan.py:494 does)
+    if (o.gate && (float)*o.gate > (float)o.gate_bound) return;
     for (long e = blockIdx.x * 256L + threadIdx.x; e < o.n; e += gridDim.x * 256L) {
         const float p0 = o.p[e];
         float g = o.g[e];
@@ -781,8 +784,13 @@ __global__ void __launch_bounds__(256) optimizer_kernel(OptArgs o) {
         }
         // decoupled decay on the OLD value (wgan.py:158-163, apply_l2_decay / apply_l1_decay)
         pn -= o.lr * o.l2_decay * p0 + o.lr * o.l1_decay * ((p0 > 0.f) - (p0 < 0.f));
-        if (o.clip) pn = fminf(fmaxf(pn, o.clip_lo), o.clip_hi);       // wgan.py:244-251
+        if (o.clip_lo_v) pn = fminf(fmaxf(pn, o.clip_lo_v[e]), o.clip_hi_v[e]);      // (bounds per element: the reference's numpy clip broadcasts)
+        else if (o.clip) pn = fminf(fmaxf(pn, o.clip_lo), o.clip_hi);       // wgan.py:244-251
         o.p[e] = pn;
+        if (o.record) {
+            o.record[e] = pn;
+            if (e == 0 && o.record_tail) o.record[o.n] = *o.record_tail;
+        }
     }
 }
 hipError_t optimizer_step(const OptArgs& o, hipStream_t st) {

@@ -54,6 +54,27 @@ struct GenBwdArgs {
 };
 template <typename T>
 struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };
+template <typename T>
+struct JDS { T J[4], D[4], inv2s2[4]; };
+// inputs of a device-noise forward in one launch (ssn_aux.hip: gen_inputs_kernel)
+struct GenInputsArgs {
+    unsigned long long seed, off_z, off_zin;
+    const float *bw, *con, *v; float inv_l; int bernoulli;
+    float *W, *z, *zin, *amp, *ext;
+    int B, NB, N;
+    JDS<float> p; long total_vec, total_s, nb_w, nb_s;
+};
+hipError_t launch_gen_inputs(GenInputsArgs a, const float* jds12, hipStream_t st);
+// gradient vector and loss of a generator step in one launch (ssn_gen_tail.hip)
+struct GenGradsArgs {
+    const double* part; int B;           // [B][4][3] from jds_grad_kernel
+    int nv;                              // 0 no V, 1 one V for both populations, 2 (V_E, V_I)
+    const float *g_ext, *ext_base, *zin; int NB, M;
+    const float* dmean; const double* pens; double dynamics_cost, rate_cost;
+    double* ws;                          // 2 * 128 + 1 doubles, the last 8 bytes zero before the first call
+    float* out;                          // [nv + 12 + 1]
+};
+hipError_t launch_gen_grads(const GenGradsArgs& a, hipStream_t st);
 
 // ssn_solver.hip
 template <typename T> bool regw_supported(int M, int NB);
@@ -112,6 +133,13 @@ struct OptArgs {
     float l2_penalty, l1_penalty, l2_decay, l1_decay;
     float clip_lo, clip_hi; int clip;
     int kind;    // 0 sgd, 1 adam, 2 rmsprop
+    // the whole update is skipped when *gate > gate_bound (device value, read by every thread; nullptr = always update):
+    // the critic step that cwgan.py:493-498 drops when the batch's rate penalty exceeds its bound, decided on the device
+    const double* gate = nullptr; double gate_bound = 0.0;
+    // per-element clip bounds (instead of clip_lo / clip_hi when given), and the record of a generator step: record[e] = the
+    // new value, record[n] = *record_tail (the step's loss), written by the thread of element 0
+    const float* clip_lo_v = nullptr; const float* clip_hi_v = nullptr;
+    float* record = nullptr; const float* record_tail = nullptr;
 };
 size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);
 hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
@@ -182,8 +210,12 @@ long segment_sqnorms_ws_doubles(int n);
 hipError_t launch_segment_sqnorms(const float* x, const long* bounds, int n, float* out, double* ws, hipStream_t st);
 hipError_t launch_interpolate(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, hipStream_t st);
 hipError_t launch_step_head(const double* pens, const float* stats, float* tail, hipStream_t st);
+hipError_t launch_step_finish(const float* params, const long* bounds, int nseg, double* ws, const float* dvals, int ng, int nd,
+                              const double* pens, const float* stats, float* tail, hipStream_t st);
 hipError_t launch_mean_diff(const float* d, int ng, int nd, float* out, hipStream_t st);
-template <typename T> hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, hipStream_t st);
+template <typename T> hipError_t launch_penalty_means(const T* dyn, const T* rate, long n, double scale_dyn, double scale_rate, double* ws, double* out, hipStream_t st,
+                                                      const T* time_avg = nullptr, const long* ids = nullptr, const long* probes = nullptr, T* tc = nullptr,
+                                                      int nsamp = 0, int NB = 0, int M = 0);
 template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st);
 
 }  // namespace ssn

@@ -55,10 +55,13 @@ def forward_variant(B, NB, M, gp, save=False):
     return int(libssnode.ssn_gen_forward_variant(int(B), int(NB), int(M), int(gp.seqlen), int(bool(save)), ctypes.byref(gp)))
 
 
-def gen_forward(W, ext, gp, save=False):
+def gen_forward(W, ext, gp, save=False, probe=None):
     """W (B, M, M), ext (B, NB, M) CUDA tensors -> dict(time_avg, dynamics_penalty, rate_penalty[, traj, df]).
 
-    dynamics_penalty / rate_penalty are the means of networks/ssn.py:626,632 (0-dim tensors)."""
+    dynamics_penalty / rate_penalty are the means of networks/ssn.py:626,632 (0-dim tensors).
+    ``probe`` = (ids, probes), int64 CUDA tensors of one length: the conditional prober's gather
+    ``tuning_curve[k] = time_avg[ids[k], :, probes[k]]`` (cwgan.py:91-98) rides in the launch that forms the penalty means
+    and comes back as ``out['tuning_curve']``."""
     clib.require_gpu()
     assert W.is_cuda and ext.is_cuda and W.dtype == ext.dtype and W.dtype in _DT
     W = W.contiguous(); ext = ext.contiguous()
@@ -88,11 +91,24 @@ def gen_forward(W, ext, gp, save=False):
     n_rate = B * (T - skip) * NB * M
     # both penalty means in one launch (fp64 sums in a fixed order), instead of two reductions and two scalings
     pens = torch.empty(2, device=W.device, dtype=torch.float64)
-    rc = getattr(libssnode, 'ssn_penalty_means_' + suffix)(
-        dyn.data_ptr(), rate.data_ptr(), dyn.numel(), (1.0 / n_dyn) if n_dyn > 0 else float('nan'), 1.0 / n_rate,
-        _penalty_scratch(W.device).data_ptr(), pens.data_ptr(), _stream())
-    clib.check(rc, 'ssn_penalty_means_' + suffix)
+    tc = None
+    if probe is not None:
+        ids, pr = probe
+        assert ids.dtype == pr.dtype == torch.int64 and ids.is_cuda and pr.is_cuda and ids.numel() == pr.numel()
+        tc = torch.empty((ids.numel(), NB), device=W.device, dtype=W.dtype)
+        rc = getattr(libssnode, 'ssn_penalty_means_probe_' + suffix)(
+            dyn.data_ptr(), rate.data_ptr(), dyn.numel(), (1.0 / n_dyn) if n_dyn > 0 else float('nan'), 1.0 / n_rate,
+            _penalty_scratch(W.device).data_ptr(), pens.data_ptr(), ta.data_ptr(), ids.contiguous().data_ptr(),
+            pr.contiguous().data_ptr(), tc.data_ptr(), int(ids.numel()), int(NB), int(M), _stream())
+        clib.check(rc, 'ssn_penalty_means_probe_' + suffix)
+    else:
+        rc = getattr(libssnode, 'ssn_penalty_means_' + suffix)(
+            dyn.data_ptr(), rate.data_ptr(), dyn.numel(), (1.0 / n_dyn) if n_dyn > 0 else float('nan'), 1.0 / n_rate,
+            _penalty_scratch(W.device).data_ptr(), pens.data_ptr(), _stream())
+        clib.check(rc, 'ssn_penalty_means_' + suffix)
     out = dict(time_avg=ta, dynamics_penalty=pens[0], rate_penalty=pens[1], penalties=pens, n_dyn=n_dyn, n_rate=n_rate)
+    if tc is not None:
+        out['tuning_curve'] = tc
     if save:
         out.update(traj=traj, df=df)
     return out
@@ -162,6 +178,46 @@ def weight_grad(delta, traj, kernel=0, dmax=None, xmax=None):
                                                          int(kernel), _stream())
     clib.check(rc, 'ssn_weight_grad_' + suffix)
     return gW
+
+
+def jds_grad_parts(gW, z, J, D, S):
+    """Chain rule through make_W_with_x per draw: the (B, 4, 3) float64 CUDA tensor of ``ssn_jds_grad_*``
+    ([:, pq, 0 / 1 / 2] = this draw's share of dL/dJ_pq, dL/dD_pq, dL/dS_pq); `jds_grad` or `ssn_gen_grads_f32` add the draws."""
+    clib.require_gpu()
+    B, M, _ = gW.shape
+    suffix, ct = _DT[gW.dtype]
+    arrs = [(ct * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (J, D, S)]
+    out = torch.empty((B, 4, 3), device=gW.device, dtype=torch.float64)
+    rc = getattr(libssnode, 'ssn_jds_grad_' + suffix)(gW.contiguous().data_ptr(), z.contiguous().data_ptr(),
+                                                      arrs[0], arrs[1], arrs[2], out.data_ptr(), B, M // 2, _stream())
+    clib.check(rc, 'ssn_jds_grad_' + suffix)
+    return out
+
+
+_GRADS_WS = {}
+
+
+def gen_grads(parts, dmean, pens64, dynamics_cost, rate_cost, nv=0, g_ext=None, ext_base=None, zin=None):
+    """``ssn_gen_grads_f32``: the flat gradient vector [dL/dV (nv), dL/dJ (4), dL/dD (4), dL/dS (4)] followed by the step's loss
+    -- (nv + 13,) float32 on the device, one launch, fp64 sums in a fixed order."""
+    clib.require_gpu()
+    B = parts.shape[0]
+    assert parts.shape == (B, 4, 3) and parts.dtype == torch.float64 and parts.is_contiguous()
+    key = (parts.device.index, clib.stream_ptr().value)
+    ws = _GRADS_WS.get(key)
+    if ws is None:
+        ws = _GRADS_WS[key] = torch.zeros(int(libssnode.ssn_gen_grads_ws_doubles()), device=parts.device, dtype=torch.float64)
+    out = torch.empty(nv + 13, device=parts.device, dtype=torch.float32)
+    a = clib.GenGrads(jds_part=parts.data_ptr(), B=int(B), nv=int(nv), dmean=dmean.data_ptr(),
+                      pens64=pens64.data_ptr() if pens64 is not None else None, dynamics_cost=float(dynamics_cost),
+                      rate_cost=float(rate_cost), ws=ws.data_ptr(), out=out.data_ptr())
+    if nv:
+        assert g_ext.dtype == ext_base.dtype == zin.dtype == torch.float32 and g_ext.shape == ext_base.shape
+        g_ext, ext_base, zin = g_ext.contiguous(), ext_base.contiguous(), zin.contiguous()
+        a.g_ext, a.ext_base, a.zin = g_ext.data_ptr(), ext_base.data_ptr(), zin.data_ptr()
+        a.NB, a.M = int(g_ext.shape[1]), int(g_ext.shape[2])
+    clib.check(libssnode.ssn_gen_grads_f32(ctypes.byref(a), _stream()), 'ssn_gen_grads_f32')
+    return out
 
 
 def jds_grad(gW, z, J, D, S, as_tensor=False):

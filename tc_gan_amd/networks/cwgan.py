@@ -372,11 +372,15 @@ class ConditionalBPTTWassersteinGAN(object):
             xd, cd, eps = to_device_packed([local.tuning_curves, local.conditions, ctx.eps_full[r0:r0 + per]], torch.float32)
         ctx.skipped = False
         ctx.snapshot = None
+        ctx.gated = False
         ctx.acc_deferred = False
-        if not self.reducer.on and self.disc_rate_penalty_bound <= 0 and xg.dtype == torch.float32:
-            # single process, no skip rule to honour: the whole step is one library call (same kernels, same order)
+        if not self.reducer.on and xg.dtype == torch.float32:
+            # single process: the whole step is one library call (same kernels, same order); the skip rule of cwgan.py:493-498
+            # is honoured by the optimizer kernel itself, which reads the rate penalty where the forward left it
+            ctx.gated = self.disc_rate_penalty_bound > 0
             with self.disc_train_watch:
-                xp, tail = self.disc.step(self.disc_updater, xg, xd, cd, eps, self.lipschitz_cost, pens64=ctx.pens64)
+                xp, tail = self.disc.step(self.disc_updater, xg, xd, cd, eps, self.lipschitz_cost, pens64=ctx.pens64,
+                                          rate_penalty_bound=self.disc_rate_penalty_bound if ctx.gated else None)
             ctx.xd, ctx.xg, ctx.xp, ctx.cd = xd, xg, xp, cd
         else:
             pens = ctx.pens64.to(torch.float32)      # [dynamics_penalty, rate_penalty] of this step's forward (averaged over ranks below)
@@ -426,8 +430,11 @@ class ConditionalBPTTWassersteinGAN(object):
         if ctx.acc_deferred:
             # last word: the job-wide accuracy of the PREVIOUS critic step, which travelled in this step's collective
             ctx.arrived_accuracy, host = float(host[-1]), host[:-1]
-        if ctx.snapshot is not None and float(host[1]) > self.disc_rate_penalty_bound:
-            self.disc_updater.restore(self.disc.params, ctx.snapshot)            # the skipped step of cwgan.py:493-498
+        if (ctx.snapshot is not None or ctx.gated) and np.float32(host[1]) > np.float32(self.disc_rate_penalty_bound):
+            if ctx.gated:
+                self.disc_updater.uncommit_step()                                # (the kernel made no update: same test, same value)
+            else:
+                self.disc_updater.restore(self.disc.params, ctx.snapshot)        # the skipped step of cwgan.py:493-498
             ctx.skipped = True
             host = np.array([host[0], host[1], np.nan, np.nan], dtype='float32')
             self.disc.cache_param_nnorms(None)
@@ -488,11 +495,24 @@ class ConditionalBPTTWassersteinGAN(object):
         if self.critic_iters > 0 and self._predrawn is None:
             self._rng_before_predraw = self.rng.get_state()
             self._predrawn = self._draw_disc()
+        fused = self._gen_tail_fused()
         with self.gen_train_watch:
             cd = None if local.conditions is None else to_device(np.ascontiguousarray(local.conditions), torch.float32)
             xg = gen_out.prober_tuning_curve.to(torch.float32)
             nb = xg.shape[0]
             gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
+            if fused is not None:
+                host = self._train_generator_tail(fused, gx, dmean)
+                info.gen_loss = float(host[-1])
+                if not np.isfinite(host).all():
+                    self._report_poisoned(info, gen_out)
+        if fused is not None:
+            info.gen_forward_time = self.gen_forward_watch.sum()
+            info.gen_train_time = self.gen_train_watch.sum()
+            info.gen_time = info.gen_train_time + info.gen_forward_time
+            info.disc_time = self.disc_train_watch.sum()
+            return info
+        with self.gen_train_watch:
             gdict = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, as_tensor=True)
             loss = (-dmean.to(torch.float64) + self.dynamics_cost * gen_out.model_dynamics_penalty
                     + self.rate_cost * gen_out.model_rate_penalty).reshape(1).to(torch.float32)
@@ -527,18 +547,94 @@ class ConditionalBPTTWassersteinGAN(object):
                 off += n
             info.gen_loss = float(host[-1])
             if not np.isfinite(host).all():
-                # (the drivers' NaN guards end the run; say why when it was the fp16 adjoint's range and not the model)
-                bad = self.gen.poisoned_draws()
-                if bad:
-                    logger.warning('generator step %s: %d of %d draws have an adjoint that grew by more than 2^8 within one '
-                                   'Euler step -- beyond the lagged scale of the fp16-split sweep, so their gradient is NaN; '
-                                   '--gen-kernel mfma-fp32 has no such limit', getattr(info, 'gen_step', '?'), bad,
-                                   gen_out.prober_tuning_curve.shape[0] // max(getattr(self, 'probes_per_model', 1), 1))
+                self._report_poisoned(info, gen_out)
         info.gen_forward_time = self.gen_forward_watch.sum()
         info.gen_train_time = self.gen_train_watch.sum()
         info.gen_time = info.gen_train_time + info.gen_forward_time
         info.disc_time = self.disc_train_watch.sum()
         return info
+
+    def _report_poisoned(self, info, gen_out):
+        """(the drivers' NaN guards end the run; say why when it was the fp16 adjoint's range and not the model)"""
+        bad = self.gen.poisoned_draws()
+        if bad:
+            logger.warning('generator step %s: %d of %d draws have an adjoint that grew by more than 2^8 within one '
+                           'Euler step -- beyond the lagged scale of the fp16-split sweep, so their gradient is NaN; '
+                           '--gen-kernel mfma-fp32 has no such limit', getattr(info, 'gen_step', '?'), bad,
+                           gen_out.prober_tuning_curve.shape[0] // max(getattr(self, 'probes_per_model', 1), 1))
+
+    # -- the end of a generator step in two library calls (`ssn_gen_grads_f32`, `ssn_gen_apply_f32`) --------------------------
+    def _gen_tail_fused(self):
+        """The flat device state of the generator's update (parameters, optimizer moments, clip bounds in `_pnames` order), or
+        None when the step has to go parameter by parameter: a generator in float64, or updaters that are not in step with
+        each other (same rule, hyper-parameters and step count: `make_gan` builds them that way)."""
+        ups = [self.gen_updaters[name] for name in self._pnames]
+        sig = {(u.kind, u.learning_rate, tuple(sorted(u.cfg.items())), tuple(u.reg), u.step) for u in ups}
+        if len(sig) != 1 or self.gen.dtype != 'float32':
+            return None
+        st = self.__dict__.get('_gflat')
+        if st is None:
+            sizes = [int(self._gparams[name].numel()) for name in self._pnames]
+            offs = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+            n = int(offs[-1])
+            flat = torch.cat([self._gparams[name] for name in self._pnames])
+            lo = np.concatenate([np.broadcast_to(np.asarray(self.param_bounds[name][0], dtype='float32').ravel(), (k,))
+                                 for name, k in zip(self._pnames, sizes)])
+            hi = np.concatenate([np.broadcast_to(np.asarray(self.param_bounds[name][1], dtype='float32').ravel(), (k,))
+                                 for name, k in zip(self._pnames, sizes)])
+            st = self._gflat = dict(n=n, offs=offs, flat=flat, m=torch.zeros_like(flat), v=torch.zeros_like(flat),
+                                    lo=to_device(lo), hi=to_device(hi), record=torch.empty(n + 1, device='cuda', dtype=torch.float32))
+            for i, name in enumerate(self._pnames):          # the per-name device copies become views of the flat vector
+                self._gparams[name] = flat[offs[i]:offs[i + 1]]
+        for i, name in enumerate(self._pnames):               # ... and so do the updaters' moments (checkpoints read them there)
+            u, a, b = self.gen_updaters[name], st['offs'][i], st['offs'][i + 1]
+            mine = (st['m'][a:b], st['v'][a:b])
+            if u._state is None:
+                mine[0].zero_(); mine[1].zero_()
+                u._state = mine
+            elif u._state[0].data_ptr() != mine[0].data_ptr():           # (restored from a checkpoint: take the values over)
+                mine[0].copy_(u._state[0].reshape(-1)); mine[1].copy_(u._state[1].reshape(-1))
+                u._state = mine
+        return st
+
+    def _train_generator_tail(self, st, gx, dmean):
+        """Adjoint sweep, dL/dW, chain rule; then gradient vector + loss in one launch, the job's all-reduce, and the update of
+        all parameters with their bounds + the record in one more.  Returns the record on the host: new values, loss."""
+        import ctypes
+        pieces = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, raw=True)
+        from .. import genops
+        gl = genops.gen_grads(pieces['parts'], dmean, self.gen.last_penalties, self.dynamics_cost, self.rate_cost,
+                              nv=pieces['nv'], g_ext=pieces.get('g_ext'), ext_base=pieces.get('ext_base'), zin=pieces.get('zin'))
+        # (the accuracy of the last critic step rides in the generator's collective: see `_launch_disc`)
+        carry, self._acc_carry = (self._acc_carry if self.reducer.on else None), None
+        self.reducer.mean_(gl, *([carry] if carry is not None else []))
+        for name in self._pnames:                                                # wgan.py:218-260
+            value = np.asarray(getattr(self.gen, name))
+            cached = self._gparams_host.get(name)
+            if cached is None or cached.shape != value.shape or not np.array_equal(cached, value):
+                self._gparams[name].copy_(to_device(np.ascontiguousarray(value, dtype='float32').ravel()))
+        u0 = self.gen_updaters[self._pnames[0]]
+        _, _, opt = u0.begin_step(st['flat'][:self._gparams[self._pnames[0]].numel()])
+        opt.clip = 0
+        clib.check(clib.libssnode.ssn_gen_apply_f32(st['flat'].data_ptr(), gl.data_ptr(), st['m'].data_ptr(), st['v'].data_ptr(),
+                                                    st['n'], ctypes.byref(opt), st['lo'].data_ptr(), st['hi'].data_ptr(),
+                                                    st['record'].data_ptr(), clib.stream_ptr()), 'ssn_gen_apply_f32')
+        for name in self._pnames:
+            self.gen_updaters[name].commit_step(opt)
+        tail = [st['record']] + ([carry.to(torch.float32)] if carry is not None else [])
+        host = (torch.cat(tail) if len(tail) > 1 else tail[0]).cpu().numpy()
+        self._arrived_with_gen = None
+        if carry is not None:
+            self._arrived_with_gen, host = float(host[-1]), host[:-1]
+        off = 0
+        for name in self._pnames:
+            shape = np.shape(getattr(self.gen, name))
+            n = int(np.prod(shape, dtype=int))
+            new = host[off:off + n].astype('float64').reshape(shape)
+            setattr(self.gen, name, new)
+            self._gparams_host[name] = new.copy()
+            off += n
+        return host
 
     def _single_gen_step(self, gen_step, critic_iters):
         self.gen_forward_watch = StopWatch()

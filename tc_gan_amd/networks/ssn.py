@@ -372,18 +372,22 @@ class TuningCurveGenerator(object):
         W = generate_weight_batch(self.num_sites, self.J, self.D, self.S, z, dtype=self.dtype)
         return ext, z, W
 
+    def _probe_indices(self, prober_norm_probes=None, prober_model_ids=None, prober_cell_types=None):
+        """(ids, probes) of the conditional prober as int64 device tensors (cwgan.py:91-93), cached while the probe set stays."""
+        key = (np.asarray(prober_norm_probes, dtype='float64').tobytes(), np.asarray(prober_cell_types).tobytes(),
+               np.asarray(prober_model_ids).tobytes())
+        hit = self.__dict__.get('_probe_cache')
+        if hit is None or hit[0] != key:
+            probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
+                                                       self.num_sites, type='uint16').astype(np.int64) \
+                + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
+            hit = self._probe_cache = (key, to_device(np.asarray(prober_model_ids).astype(np.int64)), to_device(probes))
+        return hit[1], hit[2]
+
     def _probe(self, time_avg, prober_norm_probes=None, prober_model_ids=None, prober_cell_types=None):
         if self.conditional:
             # (the probe set of a run rarely changes from step to step: index arithmetic and uploads only when it does)
-            key = (np.asarray(prober_norm_probes, dtype='float64').tobytes(), np.asarray(prober_cell_types).tobytes(),
-                   np.asarray(prober_model_ids).tobytes())
-            hit = self.__dict__.get('_probe_cache')
-            if hit is None or hit[0] != key:
-                probes = sample_sites_from_stim_space_impl(np.asarray(prober_norm_probes, dtype='float64'),
-                                                           self.num_sites, type='uint16').astype(np.int64) \
-                    + np.asarray(prober_cell_types).astype(np.int64) * self.num_sites     # cwgan.py:91-93
-                hit = self._probe_cache = (key, to_device(np.asarray(prober_model_ids).astype(np.int64)), to_device(probes))
-            ids, pr = hit[1], hit[2]
+            ids, pr = self._probe_indices(prober_norm_probes, prober_model_ids, prober_cell_types)
             return time_avg[ids, :, pr], ids, pr                                       # cwgan.py:98
         if getattr(self, '_probes_dev', None) is None or self._probes_dev[0] is not self.probes:
             self._probes_dev = (self.probes, to_device(np.asarray(self.probes)))
@@ -404,8 +408,14 @@ class TuningCurveGenerator(object):
         probe_kw = {k: kwargs.pop(k) for k in list(kwargs) if k.startswith('prober_')}
         assert not kwargs, 'unknown inputs: {}'.format(sorted(kwargs))
         gp = self.gen_params(theta)
-        fwd = genops.gen_forward(W, ext, gp, save=save)
-        tc, ids, pr = self._probe(fwd['time_avg'], **probe_kw)
+        if self.conditional:
+            # (the probe gather rides in the forward's reduction launch: `ssn_penalty_means_probe_*`)
+            ids, pr = self._probe_indices(**probe_kw)
+            fwd = genops.gen_forward(W, ext, gp, save=save, probe=(ids, pr))
+            tc = fwd['tuning_curve']
+        else:
+            fwd = genops.gen_forward(W, ext, gp, save=save)
+            tc, ids, pr = self._probe(fwd['time_avg'], **probe_kw)
         self.last_penalties = fwd['penalties']        # fp64 [dynamics_penalty, rate_penalty] of this call, one device tensor
         vals = [fwd['dynamics_penalty']]
         if self.include_rate_penalty:
@@ -418,11 +428,13 @@ class TuningCurveGenerator(object):
             self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr, zin=self._zin, ext_base=self._ext_base)
         return out
 
-    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False):
+    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False, raw=False):
         """BPTT: gradient of  sum(g_tuning_curve * tuning_curve) + dynamics_cost * dynamics_penalty
         + rate_cost * rate_penalty  w.r.t. the generator parameters (dict: J, D, S[, V]), for the last
         ``forward(save=True)`` call.  float64 numpy arrays by default; with ``as_tensor=True`` float64 CUDA tensors
-        and no host synchronisation anywhere in the call (the GAN loop keeps queuing work behind it)."""
+        and no host synchronisation anywhere in the call (the GAN loop keeps queuing work behind it).
+        ``raw=True``: the pieces `genops.gen_grads` turns into the flat gradient vector in one launch -- dict(parts (B, 4, 3)
+        float64, nv[, g_ext, ext_base, zin]) -- instead of the sums."""
         sv = self._saved
         fwd = sv['fwd']
         g = g_tuning_curve.to(fwd['time_avg'].dtype)
@@ -447,6 +459,12 @@ class TuningCurveGenerator(object):
         self.last_dmax = dmax
         # (fp16 two-part form of dL/dW where the sweep handed over max |delta| per draw and the rates are bounded)
         gW = genops.weight_grad(delta, fwd['traj'], dmax=dmax, xmax=genops.rate_bound(sv['gp']))
+        if raw:
+            pieces = dict(parts=genops.jds_grad_parts(gW, sv['z'], self.J, self.D, self.S), nv=0)
+            if self.heteroin:
+                pieces.update(nv=2 if self.ssn_type == 'heteroin' else 1, g_ext=g_ext, ext_base=sv['ext_base'], zin=sv['zin'])
+            self._saved = None
+            return pieces
         gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S, as_tensor=as_tensor)
         grads = dict(J=gJ, D=gD, S=gS)
         if self.heteroin:

@@ -143,6 +143,50 @@ def test_device_noise_mode_runs_and_rate_bound_skips_critic():
     assert st is None or float(st[0].abs().max()) == 0.0
 
 
+def test_rate_bound_skips_exactly_the_steps_over_the_bound():
+    """cwgan.py:493-498 decided on the device (`ssn_critic_step_gated_run`): with a bound between the smallest and the largest
+    rate penalty of a run, exactly the steps over the bound are reported skipped (NaN loss and accuracy), they leave the
+    critic and its Adam state as they found them -- the step count too, so the bias correction of the next update is the one
+    of an uninterrupted sequence -- and the other steps are the steps of a run that was never offered those batches."""
+    from tc_gan_amd.networks.cwgan import make_gan
+
+    def run(bound, steps=8):
+        cfg = dict(TEST_PARAMS, critic_iters_init=steps, z_device_seed=5)
+        cfg['gen'] = dict(cfg['gen'], rate_penalty_threshold=0.5)
+        cfg['disc'] = dict(cfg['disc'], update_name='adam-wgan', rate_penalty_bound=bound)
+        gan, _ = make_gan(cfg)
+        gan.set_dataset(_fake_data(gan, 9, np.random.RandomState(2)))
+        it = gan.learning()
+        rows = []
+        for _ in range(steps):
+            before = gan.disc.get_flat().copy()
+            info = next(it)
+            rows.append((info.rate_penalty, info.disc_loss, info.accuracy, before, gan.disc.get_flat().copy(), gan.disc_updater.step))
+        return rows
+
+    free = run(-1.0)
+    pens = np.array([r[0] for r in free])
+    assert pens.min() < pens.max()
+    bound = float(np.sort(pens)[len(pens) // 2 - 1] + np.sort(pens)[len(pens) // 2]) / 2
+    gated = run(bound)
+    np.testing.assert_array_equal([r[0] for r in gated], pens)            # the forwards do not depend on the critic
+    applied = 0
+    for (pen, loss, acc, before, after, count) in gated:
+        if np.float32(pen) > np.float32(bound):
+            assert np.isnan(loss) and np.isnan(acc)
+            np.testing.assert_array_equal(after, before)
+        else:
+            applied += 1
+            assert np.isfinite(loss) and np.isfinite(acc) and not np.array_equal(after, before)
+        assert count == applied
+    assert 0 < applied < len(gated)
+    # until the first skipped step the two runs are the same run
+    first = next(i for i, r in enumerate(gated) if np.isnan(r[1]))
+    for a, b in zip(free[:first], gated[:first]):
+        assert a[1] == b[1] and a[2] == b[2]
+        np.testing.assert_array_equal(a[4], b[4])
+
+
 @pytest.mark.parametrize('ssn_type,V0', [('heteroin', [0.3, 0.1]), ('deg-heteroin', 0.4)])
 def test_heteroin_generator_update_vs_oracle(ssn_type, V0):
     """Heterogeneous-input SSNs (networks/ssn.py:645-772): parameter order [V, J, D, S], noise order
