@@ -322,29 +322,39 @@ def run_c3(args, rank, world, local_rank, paper=False):
 def run_c5(args, rank, world, local_rank):
     """BASELINE config 5: the FF_lalazar feed-forward generator (get_FF_output), box_width 40 (64000 grid
     points), 27 stimuli, 1 hidden unit, 16384 samples per GPU; synthetic inputs as generate_samples draws them
-    (uniform widths / strengths, 1 % connectivity).  One step = one forward over the batch.  HBM-bound:
-    12 B per (sample, grid point)."""
+    (uniform widths / strengths, box^3 / 100 = 640 connections per unit drawn with replacement).  One step = one forward
+    over the batch through the connection-list entry point (`ssn_ff_forward_sparse_f32`: 4 B per (sample, grid point) +
+    8 B per connection); the dense entry point (12 B per point, what round 3 timed) is timed beside it on the same inputs."""
     import torch
     import torch.distributed as dist
     from tc_gan_amd import ff_model
     nsam, box, nhid = 16384, 40, 1
     G = box ** 3
+    nff = G // 100
     gen = torch.Generator(device='cuda'); gen.manual_seed(99 + rank)
     wid = torch.rand((nsam, G), device='cuda', generator=gen)
-    con = (torch.rand((nsam, nhid, G), device='cuda', generator=gen) < 0.01).float()
+    # FF_lalazar_model.py:154-167: nff draws with replacement per unit; an index drawn twice counts once
+    idx = torch.randint(0, G, (nsam, nhid, nff), device='cuda', generator=gen).sort(dim=2).values
+    idx[:, :, 1:][idx[:, :, 1:] == idx[:, :, :-1]] = -1
+    idx = idx.to(torch.int32).contiguous()
     strn = torch.rand((nsam, nhid, G), device='cuda', generator=gen)
+    val = torch.gather(strn, 2, idx.clamp(min=0).long()).contiguous()
     ths = torch.rand((nsam, nhid), device='cuda', generator=gen) * 2 - 1
     stim = ff_model.default_stimuli()
+
+    def fwd():
+        return ff_model.ff_forward_sparse(ff_model.START_PARAMS, wid, idx, val, ths, stim, box)
+
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for _ in range(args.warmup):
-        out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
+        out = fwd()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        out = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
+        out = fwd()
         ev[k][1].record()
     torch.cuda.synchronize()
     if dist.is_initialized():
@@ -357,16 +367,37 @@ def run_c5(args, rank, world, local_rank):
         elapsed = float(t.item())
     assert bool(torch.isfinite(out).all())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    bytes_alg = float(nsam) * nhid * G * 12
-    achieved = bytes_alg / (kernel_ms * 1e-3) * 1e-9
+    # the dense entry point on the same inputs (FF_con / FF_str as arrays): same outputs, three per-point streams
+    con = torch.zeros((nsam, nhid, G), device='cuda')
+    rows = torch.arange(nsam * nhid, device='cuda').reshape(nsam, nhid, 1).expand_as(idx)
+    ok = idx >= 0
+    con.view(nsam * nhid, G)[rows[ok], idx[ok].long()] = 1.0
+    dense = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        dense = ff_model.ff_forward(ff_model.START_PARAMS, wid, con, strn, ths, stim, box)
+    e1.record()
+    torch.cuda.synchronize()
+    dense_ms = e0.elapsed_time(e1) / 3
+    assert float((dense - out).abs().max()) <= 1e-4 * max(float(dense.abs().max()), 1.0)
+    del con, dense
+    # The pass over the widths is bound by the vector unit, not by HBM: per (sample, point) 27 FMAs (the 3 x 3 x 3 sums of
+    # exp products) + 18 multiplies + 9 exponentials + ~6 = 87 flop against 4 bytes
+    flops_alg = float(nsam) * G * 87.0
+    bytes_alg = float(nsam) * (G * 4 + nhid * nff * 8)
+    achieved = flops_alg / (kernel_ms * 1e-3) * 1e-12
     res = {'metric': 'FF tuning curves/sec', 'value': nsam * args.steps * world / elapsed, 'unit': 'samples (27-point curves)/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
            'config': {'workload': 'C5: FF_lalazar get_FF_output, box_width 40 (64000 points), 27 stimuli, 1 hidden unit, '
-                                  '16384 samples per GPU', 'parallelism': 'samples sharded over %d GPU(s)' % world},
-           'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                        'traffic': _traffic('c5'), 'kernel': 'ff_forward_lattice_kernel', 'kernel_ms': kernel_ms,
-                        'algorithmic_hbm_bytes': bytes_alg}}
+                                  '16384 samples per GPU, connections as lists (640 slots per unit)',
+                      'parallelism': 'samples sharded over %d GPU(s)' % world},
+           'roofline': {'bound': 'valu_fp32', 'achieved': achieved, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': achieved / 157.3,
+                        'traffic': _traffic('c5'), 'kernel': 'ff_forward_sparse_lattice_kernel', 'kernel_ms': kernel_ms,
+                        'flops_per_unit': 87, 'algorithmic_hbm_bytes': bytes_alg,
+                        'hbm_GBps': bytes_alg / (kernel_ms * 1e-3) * 1e-9, 'hbm_frac': bytes_alg / (kernel_ms * 1e-3) * 1e-9 / 8000.0,
+                        'dense_entry_ms': dense_ms, 'dense_entry_hbm_bytes': float(nsam) * nhid * G * 12}}
     res['world_size'] = world
     return res
 

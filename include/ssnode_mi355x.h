@@ -436,6 +436,13 @@ typedef struct ssn_ff_params {
  * pre-threshold drive and sum_g e, kept for the backward. */
 int ssn_ff_forward_f32(const float *RF_w, const float *FF_con, const float *FF_str, const float *TH_sam,
                        const float *stim, float *out, float *q, float *den, const ssn_ff_params *p, void *stream);
+/* The same outputs from the model's own data structure: a unit has box^3 / 100 connections (FF_lalazar_model.py:154-167), so
+ * instead of the dense FF_con / FF_str streams (99 % zeros, 8 of the 12 bytes per point) the connections come as lists:
+ * conn_idx[nsam][nhid][ncon] (device int32, grid index z fastest, each index at most once per unit; < 0 = empty slot) and
+ * conn_str[nsam][nhid][ncon] (the strengths FF_str at those indices).  sum_g e runs over all points of RF_w (4 B per point,
+ * shared by the sample's hidden units), sum_g e w over the list. */
+int ssn_ff_forward_sparse_f32(const float *RF_w, const int *conn_idx, const float *conn_str, int ncon, const float *TH_sam,
+                              const float *stim, float *out, float *q, float *den, const ssn_ff_params *p, void *stream);
 /* dsig[nsam][nhid][2] = per-sample partial derivatives of L w.r.t. RF_l and RF_d, given gq[nsam][ni][nhid] =
  * dL/d(drive) (upstream gradient times [out > 0]) and the forward's q, den. */
 int ssn_ff_backward_f32(const float *RF_w, const float *FF_con, const float *FF_str, const float *stim,

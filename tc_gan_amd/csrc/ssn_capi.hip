@@ -825,6 +825,32 @@ static ssn::FFArgs ff_args(const ssn_ff_params& p) {
     a.J = (float)p.J; a.a = (float)p.a;
     return a;
 }
+// Is the stimulus set a 3 x 3 x 3 product lattice in the model script's order?  (27 x 3 floats: read back once per call.)
+static bool ff_lattice(const float* stim, int ni, ssn::FFLattice& lat, void* stream) {
+    if (ni != 27) return false;
+    float hs[27][3];
+    if (hipMemcpyAsync(hs, stim, sizeof(hs), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return false;
+    for (int k = 0; k < 3; ++k) { lat.x[k] = hs[9 * k][0]; lat.y[k] = hs[3 * k][1]; lat.z[k] = hs[k][2]; }
+    bool lattice = true;
+    for (int i = 0; i < 27 && lattice; ++i)
+        lattice = hs[i][0] == lat.x[i / 9] && hs[i][1] == lat.y[(i / 3) % 3] && hs[i][2] == lat.z[i % 3];
+    return lattice;
+}
+int ssn_ff_forward_sparse_f32(const float* RF_w, const int* conn_idx, const float* conn_str, int ncon, const float* TH_sam,
+                              const float* stim, float* out, float* q, float* den, const ssn_ff_params* p, void* stream) {
+    if (!p || p->nsam < 0 || p->nhid < 1 || p->ni < 1 || p->ni > 32 || p->box < 1 || ncon < 0 || (q == nullptr) != (den == nullptr) ||
+        (p->nsam > 0 && (!RF_w || !TH_sam || !stim || !out || (ncon > 0 && (!conn_idx || !conn_str))))) {
+        g_last_error = "ssn_ff_forward_sparse: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::FFArgs a = ff_args(*p);
+    a.RF_w = RF_w; a.TH_sam = TH_sam; a.stim = stim; a.out = out; a.q = q; a.den = den;
+    ssn::FFLattice lat;
+    const bool lattice = ff_lattice(stim, p->ni, lat, stream);
+    SSN_TRY(ssn::launch_ff_forward_sparse(a, lattice ? &lat : nullptr, conn_idx, conn_str, ncon, (hipStream_t)stream));
+    return 0;
+}
 int ssn_ff_forward_f32(const float* RF_w, const float* FF_con, const float* FF_str, const float* TH_sam,
                        const float* stim, float* out, float* q, float* den, const ssn_ff_params* p, void* stream) {
     if (!p || p->nsam < 0 || p->nhid < 1 || p->ni < 1 || p->ni > 32 || p->box < 1 || (q == nullptr) != (den == nullptr)) {
@@ -833,19 +859,8 @@ int ssn_ff_forward_f32(const float* RF_w, const float* FF_con, const float* FF_s
     }
     ssn::FFArgs a = ff_args(*p);
     a.RF_w = RF_w; a.FF_con = FF_con; a.FF_str = FF_str; a.TH_sam = TH_sam; a.stim = stim; a.out = out; a.q = q; a.den = den;
-    // Is the stimulus set a 3 x 3 x 3 product lattice in the model script's order?  (27 x 3 floats: read back once.)
     ssn::FFLattice lat;
-    bool lattice = false;
-    if (p->ni == 27) {
-        float hs[27][3];
-        if (hipMemcpyAsync(hs, stim, sizeof(hs), hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess &&
-            hipStreamSynchronize((hipStream_t)stream) == hipSuccess) {
-            for (int k = 0; k < 3; ++k) { lat.x[k] = hs[9 * k][0]; lat.y[k] = hs[3 * k][1]; lat.z[k] = hs[k][2]; }
-            lattice = true;
-            for (int i = 0; i < 27 && lattice; ++i)
-                lattice = hs[i][0] == lat.x[i / 9] && hs[i][1] == lat.y[(i / 3) % 3] && hs[i][2] == lat.z[i % 3];
-        }
-    }
+    const bool lattice = ff_lattice(stim, p->ni, lat, stream);
     SSN_TRY(ssn::launch_ff_forward(a, lattice ? &lat : nullptr, (hipStream_t)stream));
     return 0;
 }

@@ -68,6 +68,49 @@ def ff_forward(params, RF_w, FF_con, FF_str, TH_sam, stim, box_width, keep=False
     return out
 
 
+def sparsify(FF_con, FF_str):
+    """The connection lists of `ff_forward_sparse` from the dense arrays the model script draws (FF_lalazar_model.py:154-167:
+    FF_con has box^3 / 100 ones per unit, set by index, so an index drawn twice counts once): (conn_idx int32, conn_str float32),
+    both (nsam, nhid, ncon) CUDA tensors, ncon = the largest connection count of a unit, shorter lists padded with index -1."""
+    con = torch.as_tensor(FF_con).to('cuda')
+    strn = _f32(FF_str)
+    nsam, nhid, G = con.shape
+    mask = con != 0
+    counts = mask.sum(dim=2)
+    ncon = int(counts.max()) if counts.numel() else 0
+    # stable sort puts the connected grid points first, in index order
+    order = torch.sort((~mask).to(torch.uint8), dim=2, stable=True).indices[:, :, :ncon]
+    valid = torch.arange(ncon, device='cuda')[None, None, :] < counts[:, :, None]
+    idx = torch.where(valid, order, torch.full_like(order, -1)).to(torch.int32).contiguous()
+    val = torch.where(valid, torch.gather(strn, 2, order), torch.zeros((), device='cuda')).contiguous()
+    return idx, val
+
+
+def ff_forward_sparse(params, RF_w, conn_idx, conn_str, TH_sam, stim, box_width, keep=False):
+    """`ff_forward` from connection lists (`sparsify`; `ssn_ff_forward_sparse_f32`): the same hidden activations without the
+    two dense per-point streams FF_con, FF_str."""
+    clib.require_gpu()
+    RF_w, TH_sam, stim = (_f32(t) for t in (RF_w, TH_sam, stim))
+    conn_idx = torch.as_tensor(conn_idx).to('cuda', torch.int32).contiguous()
+    conn_str = _f32(conn_str)
+    nsam, nhid = TH_sam.shape
+    ni = stim.shape[0]
+    RF_w = RF_w.reshape(nsam, -1)
+    ncon = conn_idx.shape[2] if conn_idx.dim() == 3 else 0
+    assert RF_w.shape[1] == box_width ** 3 and tuple(conn_idx.shape) == (nsam, nhid, ncon) == tuple(conn_str.shape)
+    out = torch.empty((nsam, ni, nhid), device='cuda', dtype=torch.float32)
+    q = torch.empty_like(out) if keep else None
+    den = torch.empty_like(out) if keep else None
+    fp = _params(params, nsam, nhid, ni, box_width)
+    clib.check(libssnode.ssn_ff_forward_sparse_f32(RF_w.data_ptr(), conn_idx.data_ptr(), conn_str.data_ptr(), int(ncon),
+                                                   TH_sam.data_ptr(), stim.data_ptr(), out.data_ptr(),
+                                                   q.data_ptr() if keep else None, den.data_ptr() if keep else None,
+                                                   ctypes.byref(fp), clib.stream_ptr()), 'ssn_ff_forward_sparse_f32')
+    if keep:
+        return out, dict(q=q, den=den, RF_w=RF_w, conn_idx=conn_idx, conn_str=conn_str, TH_sam=TH_sam, stim=stim, fp=fp)
+    return out
+
+
 def ff_backward(params, saved, out, g_out):
     """Gradient of  sum(g_out * out)  w.r.t. the five trainable (log-space) parameters, as a dict."""
     gq = (g_out.to(torch.float32) * (out > 0)).contiguous()

@@ -40,6 +40,44 @@ def test_ff_forward_and_gradient_vs_oracle(box, nsam, nhid, lattice):
         np.testing.assert_allclose(got[name], float(w), rtol=2e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize('lattice', [True, False])
+@pytest.mark.parametrize('box,nsam,nhid', [(8, 3, 1), (12, 4, 2), (13, 2, 1), (40, 2, 1)])
+def test_ff_sparse_forward_vs_dense_and_oracle(box, nsam, nhid, lattice):
+    """`ssn_ff_forward_sparse_f32` (connection lists instead of the dense FF_con / FF_str streams): the same hidden activations,
+    pre-threshold drive and denominators as the dense entry point and as oracle/ff_torch.py -- lattice fast path (box % 4 == 0,
+    the model script's 27 stimuli) and generic path (any box, any stimuli), several hidden units sharing one denominator pass,
+    lists of different lengths (padding slots), an index that the script's `np.random.choice` drew twice (counts once)."""
+    from tc_gan_amd import ff_model
+    rs = np.random.RandomState(box + nhid)
+    con, strn, wid, ths = ff_model.generate_samples(rs, nsam, box, nhid)
+    if box < 40:            # denser than box^3 / 100 so that small grids produce a drive; unit (0, 0) stays as the script drew it
+        dense = (rs.rand(*con.shape) < 0.2).astype(float)
+        dense[0, 0] = con[0, 0]
+        con = dense
+    stim = ff_model.default_stimuli()
+    if not lattice:
+        stim = (stim + rs.randn(*stim.shape).astype('float32') * 0.1)[:20]
+    params = dict(ff_model.START_PARAMS, Js=np.log(3.0 if box < 40 else 1000.0), THR=0.1)
+    out, saved = ff_model.ff_forward(params, wid, con, strn, ths, stim, box, keep=True)
+    idx, val = ff_model.sparsify(con, strn)
+    counts = (con != 0).sum(axis=2)
+    assert idx.shape[2] == counts.max() and int((idx >= 0).sum()) == int(counts.sum())
+    assert counts.min() < counts.max() or nsam * nhid == 1           # padding slots exist
+    got, keep = ff_model.ff_forward_sparse(params, wid, idx, val, ths, stim, box, keep=True)
+    np.testing.assert_allclose(keep['den'].cpu().numpy(), saved['den'].cpu().numpy(), rtol=2e-5)
+    np.testing.assert_allclose(keep['q'].cpu().numpy(), saved['q'].cpu().numpy(), rtol=5e-5, atol=1e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), out.cpu().numpy(), rtol=5e-5, atol=1e-6)
+    pt = {k: torch.tensor(float(v), dtype=torch.float64) for k, v in params.items()}
+    want = of.ff_output(pos=of.grid_positions(box), stim=torch.as_tensor(stim, dtype=torch.float64),
+                        RF_w=torch.as_tensor(wid), FF_con=torch.as_tensor(con), FF_str=torch.as_tensor(strn),
+                        TH_sam=torch.as_tensor(ths), **_oracle_params(pt))
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
+    # an empty list is a unit without input: drive 0
+    none = ff_model.ff_forward_sparse(params, wid, torch.full_like(idx, -1), val, ths, stim, box)
+    thr = params['THR'] + np.sign(ths) * np.abs(ths) ** np.exp(params['As']) * np.exp(params['THR_del'])
+    np.testing.assert_allclose(none.cpu().numpy(), np.broadcast_to(np.maximum(-thr, 0)[:, None, :], none.shape), rtol=1e-6, atol=1e-7)
+
+
 def test_ff_sparse_connectivity_shape_of_the_model_script():
     """box^3/100 connections per unit drawn with replacement (FF_lalazar_model.py:154-167)."""
     from tc_gan_amd import ff_model

@@ -21,3 +21,14 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
 print('ff_forward %.3f ms  %.2f TB/s algorithmic (12 B per sample-point)' % (ms, nsam * G * 12 / ms * 1e-9))
+idx, val = ff_model.sparsify(con, strn)
+outs = ff_model.ff_forward_sparse(ff_model.START_PARAMS, wid, idx, val, ths, stim, box)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(n):
+    outs = ff_model.ff_forward_sparse(ff_model.START_PARAMS, wid, idx, val, ths, stim, box)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / n
+nb = nsam * (G * 4 + idx.shape[2] * 8)
+print('ff_forward_sparse %.3f ms  %.2f TB/s algorithmic (4 B per sample-point + 8 B per connection, %d slots per unit)   max |sparse - dense| %.3e (max %.3e)'
+      % (ms, nb / ms * 1e-9, idx.shape[2], float((outs - out).abs().max()), float(out.abs().max())))
