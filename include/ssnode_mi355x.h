@@ -443,6 +443,10 @@ int ssn_ff_forward_f32(const float *RF_w, const float *FF_con, const float *FF_s
  * shared by the sample's hidden units), sum_g e w over the list. */
 int ssn_ff_forward_sparse_f32(const float *RF_w, const int *conn_idx, const float *conn_str, int ncon, const float *TH_sam,
                               const float *stim, float *out, float *q, float *den, const ssn_ff_params *p, void *stream);
+/* ssn_ff_backward_f32 (below) from the same lists: dsig as there. */
+int ssn_ff_backward_sparse_f32(const float *RF_w, const int *conn_idx, const float *conn_str, int ncon, const float *stim,
+                               const float *q, const float *den, const float *gq, float *dsig, const ssn_ff_params *p,
+                               void *stream);
 /* dsig[nsam][nhid][2] = per-sample partial derivatives of L w.r.t. RF_l and RF_d, given gq[nsam][ni][nhid] =
  * dL/d(drive) (upstream gradient times [out > 0]) and the forward's q, den. */
 int ssn_ff_backward_f32(const float *RF_w, const float *FF_con, const float *FF_str, const float *stim,

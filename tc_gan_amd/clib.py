@@ -299,6 +299,8 @@ libssnode.ssn_ff_forward_f32.argtypes = [c_void_p] * 8 + [POINTER(FFParams), c_v
 libssnode.ssn_ff_forward_f32.restype = c_int
 libssnode.ssn_ff_forward_sparse_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5 + [POINTER(FFParams), c_void_p]
 libssnode.ssn_ff_forward_sparse_f32.restype = c_int
+libssnode.ssn_ff_backward_sparse_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5 + [POINTER(FFParams), c_void_p]
+libssnode.ssn_ff_backward_sparse_f32.restype = c_int
 libssnode.ssn_ff_backward_f32.argtypes = [c_void_p] * 8 + [POINTER(FFParams), c_void_p]
 libssnode.ssn_ff_backward_f32.restype = c_int
 for _name, _ct in (('ssn_build_dw_f32', c_float), ('ssn_build_dw_f64', c_double)):
@@ -328,7 +330,7 @@ DECLARED_SYMBOLS = (
     'ssn_gen_backward_f32', 'ssn_gen_backward_f64', 'ssn_jds_grad_f32', 'ssn_jds_grad_f64',
     'ssn_critic_num_params', 'ssn_critic_workspace_floats', 'ssn_critic_forward', 'ssn_critic_loss_grad',
     'ssn_critic_input_grad', 'ssn_optimizer_step',
-    'ssn_ff_forward_sparse_f32', 'ssn_ff_forward_f32', 'ssn_ff_backward_f32', 'ssn_moment_sums_f32', 'ssn_moment_loss_grad_f32',
+    'ssn_ff_forward_sparse_f32', 'ssn_ff_backward_sparse_f32', 'ssn_ff_forward_f32', 'ssn_ff_backward_f32', 'ssn_moment_sums_f32', 'ssn_moment_loss_grad_f32',
     'ssn_build_dw_f32', 'ssn_build_dw_f64', 'ssn_ss_grad_system_f32', 'ssn_ss_grad_system_f64',
     'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
     'ssn_critic_norm_workspace_floats', 'ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm',

@@ -851,6 +851,18 @@ int ssn_ff_forward_sparse_f32(const float* RF_w, const int* conn_idx, const floa
     SSN_TRY(ssn::launch_ff_forward_sparse(a, lattice ? &lat : nullptr, conn_idx, conn_str, ncon, (hipStream_t)stream));
     return 0;
 }
+int ssn_ff_backward_sparse_f32(const float* RF_w, const int* conn_idx, const float* conn_str, int ncon, const float* stim, const float* q,
+                               const float* den, const float* gq, float* dsig, const ssn_ff_params* p, void* stream) {
+    if (!p || p->nsam < 0 || p->nhid < 1 || p->ni < 1 || p->ni > 32 || p->box < 1 || ncon < 0 || !q || !den || !gq || !dsig ||
+        (p->nsam > 0 && (!RF_w || !stim || (ncon > 0 && (!conn_idx || !conn_str))))) {
+        g_last_error = "ssn_ff_backward_sparse: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::FFArgs a = ff_args(*p);
+    a.RF_w = RF_w; a.stim = stim; a.q = const_cast<float*>(q); a.den = const_cast<float*>(den);
+    SSN_TRY(ssn::launch_ff_backward_sparse(a, conn_idx, conn_str, ncon, gq, dsig, (hipStream_t)stream));
+    return 0;
+}
 int ssn_ff_forward_f32(const float* RF_w, const float* FF_con, const float* FF_str, const float* TH_sam,
                        const float* stim, float* out, float* q, float* den, const ssn_ff_params* p, void* stream) {
     if (!p || p->nsam < 0 || p->nhid < 1 || p->ni < 1 || p->ni > 32 || p->box < 1 || (q == nullptr) != (den == nullptr)) {

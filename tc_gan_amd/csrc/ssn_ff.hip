@@ -514,6 +514,67 @@ __global__ void __launch_bounds__(256) ff_forward_sparse_kernel(FFArgs a, FFSpar
     }
 }
 
+// Second pass of the connection-list form: dsig[s][h] = sum_{i,g} gq e d^2 / sig^3 (w_g - q) / den (and the same weighted by
+// RF_w) with w_g = J str on the unit's list and 0 elsewhere: the -q part runs over all grid points (RF_w only), the w part
+// over the list.  One workgroup per (sample, hidden unit), one exponential per (stimulus, point), as ff_backward_kernel.
+template <int NI_T>
+__global__ void __launch_bounds__(256) ff_backward_sparse_kernel(FFArgs a, FFSparse sp, const float* __restrict__ gq, float* __restrict__ dsig) {
+    __shared__ float stim[NI_T][3];
+    __shared__ float coef[NI_T], cq[NI_T];
+    __shared__ float red[4][2 * NI_T];
+    const int s = blockIdx.x / a.nhid, h = blockIdx.x % a.nhid;
+    const int G = a.box * a.box * a.box;
+    if (threadIdx.x < a.ni * 3) (&stim[0][0])[threadIdx.x] = a.stim[threadIdx.x];
+    if (threadIdx.x < a.ni) {
+        const size_t o = ((size_t)s * a.ni + threadIdx.x) * a.nhid + h;
+        coef[threadIdx.x] = gq[o] / a.den[o];
+        cq[threadIdx.x] = coef[threadIdx.x] * a.q[o];
+    }
+    __syncthreads();
+    const float* rfw = a.RF_w + (size_t)s * G;
+    const float step = (a.box > 1) ? 6.f / (float)(a.box - 1) : 0.f;
+    float acc[2 * NI_T];
+#pragma unroll
+    for (int k = 0; k < 2 * NI_T; ++k) acc[k] = 0.f;
+    auto point = [&](int g, float rw, const float* cf, float sgn) {
+        const int iz = g % a.box, iy = (g / a.box) % a.box, ix = g / (a.box * a.box);
+        const float px = -3.f + step * ix, py = -3.f + step * iy, pz = -3.f + step * iz;
+        const float sig = rw * a.RF_d + a.RF_l;
+        const float inv2s2 = 0.5f * __builtin_amdgcn_rcpf(sig * sig), inv_s3 = __builtin_amdgcn_rcpf(sig * sig * sig);
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI_T; ++i) {
+            if (i < a.ni) {
+                const float dx = px - stim[i][0], dy = py - stim[i][1], dz = pz - stim[i][2];
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                t += cf[i] * __expf(-d2 * inv2s2) * d2;
+            }
+        }
+        acc[0] += sgn * t * inv_s3;
+        acc[1] += sgn * t * inv_s3 * rw;
+    };
+    for (int g = threadIdx.x; g < G; g += 256) point(g, rfw[g], cq, -1.f);
+    const int* idx = sp.idx + ((size_t)s * a.nhid + h) * sp.ncon;
+    const float* str = sp.str + ((size_t)s * a.nhid + h) * sp.ncon;
+    for (int c = threadIdx.x; c < sp.ncon; c += 256) {
+        const int g = idx[c];
+        if (g >= 0 && g < G) point(g, rfw[g], coef, a.J * str[c]);
+    }
+    ff_block_reduce<NI_T>(acc, &red[0][0], 2);
+    if (threadIdx.x < 2) {
+        float v = 0.f;
+        for (int wv = 0; wv < 4; ++wv) v += red[wv][threadIdx.x];
+        dsig[((size_t)s * a.nhid + h) * 2 + threadIdx.x] = v;
+    }
+}
+hipError_t launch_ff_backward_sparse(const FFArgs& a, const int* idx, const float* str, int ncon, const float* gq, float* dsig, hipStream_t st) {
+    if (a.nsam == 0) return hipSuccess;
+    if (a.ni > FF_MAX_NI || a.ni < 1 || !a.q || !a.den || ncon < 0 || (ncon > 0 && (!idx || !str))) return hipErrorInvalidValue;
+    const FFSparse sp{idx, str, ncon};
+    hipLaunchKernelGGL((ff_backward_sparse_kernel<FF_MAX_NI>), dim3(a.nsam * a.nhid), dim3(256), 0, st, a, sp, gq, dsig);
+    return hipGetLastError();
+}
+
 hipError_t launch_ff_forward_sparse(const FFArgs& a, const FFLattice* lat, const int* idx, const float* str, int ncon, hipStream_t st) {
     if (a.nsam == 0) return hipSuccess;
     if (a.ni > FF_MAX_NI || a.ni < 1 || ncon < 0 || (ncon > 0 && (!idx || !str))) return hipErrorInvalidValue;

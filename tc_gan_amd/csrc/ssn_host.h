@@ -195,6 +195,7 @@ struct FFLattice { float x[3], y[3], z[3]; };      // stimuli = {x} x {y} x {z},
 hipError_t launch_ff_forward(const FFArgs& a, const FFLattice* lat, hipStream_t st);
 hipError_t launch_ff_backward(const FFArgs& a, const float* gq, float* dsig, hipStream_t st);
 hipError_t launch_ff_forward_sparse(const FFArgs& a, const FFLattice* lat, const int* idx, const float* str, int ncon, hipStream_t st);
+hipError_t launch_ff_backward_sparse(const FFArgs& a, const int* idx, const float* str, int ncon, const float* gq, float* dsig, hipStream_t st);
 
 // ssn_aux.hip
 hipError_t launch_moment_sums(const float* x, int B, int D, double* sums, hipStream_t st);

@@ -117,10 +117,17 @@ def ff_backward(params, saved, out, g_out):
     nsam, ni, nhid = out.shape
     dsig = torch.empty((nsam, nhid, 2), device='cuda', dtype=torch.float32)
     st = clib.stream_ptr()
-    clib.check(libssnode.ssn_ff_backward_f32(saved['RF_w'].data_ptr(), saved['FF_con'].data_ptr(),
-                                             saved['FF_str'].data_ptr(), saved['stim'].data_ptr(),
-                                             saved['q'].data_ptr(), saved['den'].data_ptr(), gq.data_ptr(),
-                                             dsig.data_ptr(), ctypes.byref(saved['fp']), st), 'ssn_ff_backward_f32')
+    if 'conn_idx' in saved:            # forward was `ff_forward_sparse`: the same second pass from the connection lists
+        clib.check(libssnode.ssn_ff_backward_sparse_f32(saved['RF_w'].data_ptr(), saved['conn_idx'].data_ptr(),
+                                                        saved['conn_str'].data_ptr(), int(saved['conn_idx'].shape[2]),
+                                                        saved['stim'].data_ptr(), saved['q'].data_ptr(), saved['den'].data_ptr(),
+                                                        gq.data_ptr(), dsig.data_ptr(), ctypes.byref(saved['fp']), st),
+                   'ssn_ff_backward_sparse_f32')
+    else:
+        clib.check(libssnode.ssn_ff_backward_f32(saved['RF_w'].data_ptr(), saved['FF_con'].data_ptr(),
+                                                 saved['FF_str'].data_ptr(), saved['stim'].data_ptr(),
+                                                 saved['q'].data_ptr(), saved['den'].data_ptr(), gq.data_ptr(),
+                                                 dsig.data_ptr(), ctypes.byref(saved['fp']), st), 'ssn_ff_backward_f32')
     fp = saved['fp']
     d = dsig.sum(dim=(0, 1), dtype=torch.float64)
     gq64 = gq.to(torch.float64)

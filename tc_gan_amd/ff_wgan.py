@@ -55,7 +55,10 @@ class FFWGAN(object):
 
     def generate(self, sample, keep=False):
         con, strn, wid, ths = sample
-        res = ff_model.ff_forward(self.params, wid, con, strn, ths, self.stim, self.box_width, keep=keep)
+        # (the draw is the script's -- dense arrays, its RNG consumption -- the kernels take the unit's box^3 / 100 connections
+        # as lists: `ssn_ff_forward_sparse_f32`, a third of the dense entry point's bytes)
+        idx, val = ff_model.sparsify(con, strn)
+        res = ff_model.ff_forward_sparse(self.params, wid, idx, val, ths, self.stim, self.box_width, keep=keep)
         out, saved = res if keep else (res, None)
         return out[:, :, self.observed], out, saved          # (nsam, ni) observed responses
 

@@ -72,6 +72,18 @@ def test_ff_sparse_forward_vs_dense_and_oracle(box, nsam, nhid, lattice):
                         RF_w=torch.as_tensor(wid), FF_con=torch.as_tensor(con), FF_str=torch.as_tensor(strn),
                         TH_sam=torch.as_tensor(ths), **_oracle_params(pt))
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5)
+    # the gradient of the five trainable parameters from the lists: the dense second pass, and fp64 autograd
+    G = torch.as_tensor(rs.randn(*want.shape))
+    g_dense = ff_model.ff_backward(params, saved, out, G.to('cuda'))
+    g_sparse = ff_model.ff_backward(params, keep, got, G.to('cuda'))
+    pg = {k: torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    w2 = of.ff_output(pos=of.grid_positions(box), stim=torch.as_tensor(stim, dtype=torch.float64),
+                      RF_w=torch.as_tensor(wid), FF_con=torch.as_tensor(con), FF_str=torch.as_tensor(strn),
+                      TH_sam=torch.as_tensor(ths), **_oracle_params(pg))
+    grads = torch.autograd.grad((G * w2).sum(), [pg[k] for k in ff_model.PARAM_NAMES])
+    for name, w in zip(ff_model.PARAM_NAMES, grads):
+        np.testing.assert_allclose(g_sparse[name], g_dense[name], rtol=5e-4, atol=1e-5)
+        np.testing.assert_allclose(g_sparse[name], float(w), rtol=2e-3, atol=1e-4)
     # an empty list is a unit without input: drive 0
     none = ff_model.ff_forward_sparse(params, wid, torch.full_like(idx, -1), val, ths, stim, box)
     thr = params['THR'] + np.sign(ths) * np.abs(ths) ** np.exp(params['As']) * np.exp(params['THR_del'])
