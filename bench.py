@@ -260,6 +260,10 @@ def run_c3(args, rank, world, local_rank, paper=False):
     fp32_ms = None
     if not paper and args.steps >= 2 and gan.gen.forward_variant(models) in SPLIT_VARIANTS:
         fp32_ms = timed_loop('mfma-fp32')[3] / args.steps * 1e3
+    # and with the one-launch backward (gen_kernel duo-fused: adjoint sweep + dL/dW on chip) in place of the two launches
+    fused_ms = None
+    if args.steps >= 2 and gan.gen.forward_variant(models) == 8:
+        fused_ms = timed_loop('duo-fused')[3] / args.steps * 1e3
     # dominant kernel: gen_forward_kernel, timed alone with HIP events on the launch stream
     bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
     kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
@@ -313,6 +317,10 @@ def run_c3(args, rank, world, local_rank, paper=False):
         out['fp32_mfma'] = {'ms_per_step': fp32_ms, 'value': world * 1e3 / fp32_ms, 'steps': args.steps, 'warmup': args.warmup,
                             'note': 'same loop on a fresh GAN with the same seeds, generator forward and adjoint on the fp32 MFMA '
                                     'kernels (gen_kernel mfma-fp32: fp32 operands), same warm-up, steps and max-over-ranks timing'}
+    if fused_ms is not None:
+        out['fused_backward'] = {'ms_per_step': fused_ms, 'value': world * 1e3 / fused_ms, 'steps': args.steps, 'warmup': args.warmup,
+                                 'note': 'same loop on a fresh GAN with the same seeds, generator backward as ONE launch (gen_kernel '
+                                         'duo-fused: ssn_gen_backward_fused_f32) instead of adjoint sweep + dL/dW product'}
     if phases is not None:
         out['phases'] = phases
     out['world_size'] = world
@@ -540,7 +548,7 @@ def main():
             out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                                                     'higher_is_better', 'scaling', 'dtype', 'data', 'config', 'roofline',
                                                     'last_gen_loss')}
-            for key in ('fp32_mfma', 'phases', 'gen_kernel', 'forward_variant'):
+            for key in ('fp32_mfma', 'fused_backward', 'phases', 'gen_kernel', 'forward_variant'):
                 if key in sec:
                     out['secondary'][key] = sec[key]
         if args.workload == 'c2' and args.extras and world == 1:
@@ -548,7 +556,7 @@ def main():
             # them too: C2 with the 8 bandwidths every real caller uses, C5, C1 through the drop-in symbols, the paper's shape.
             out['extras'] = {}
             keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
-                    'gen_kernel', 'forward_variant', 'last_gen_loss')
+                    'gen_kernel', 'forward_variant', 'last_gen_loss', 'fused_backward')
             for name, workload, steps, warmup, kw in (('c2nb8', 'c2nb8', 3, 1, {}), ('c5', 'c5', 5, 1, {}),
                                                       ('c1_dropin', 'c1', 1, 0, dict(via='dropin', cpu_sample=128)),
                                                       ('c3paper', 'c3paper', 20, 5, {})):

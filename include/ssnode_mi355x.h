@@ -267,6 +267,19 @@ int ssn_weight_grad_f64(const double *delta, const double *traj, double *gW, int
  * (the fp16-split kernels 4 / 5 / 6 / 8, which need it for their own scaling) it fills dmax[B] and sets *tracked = 1; otherwise *tracked = 0,
  * dmax is untouched and ssn_weight_grad_f32 is the kernel to call.  fp32, M <= 224.
  */
+/*
+ * The adjoint sweep and dL/dW in ONE launch (the two halves of the same `theano.grad`, networks/wgan.py:236-242 through
+ * ssn.py:354-385): what ssn_gen_backward_max_f32 followed by ssn_weight_grad_scaled_f32 compute, without the delta
+ * stream between them -- a draw's dL/dW accumulates in the register file of the workgroup that runs its sweep.
+ * df [B][NB][T][M] (f'(u) of the forward) is only read; gW device [B][M][M]; g_ext [B][NB][M] or NULL; dmax device [B]
+ * or NULL (max |delta| per draw; NaN marks a draw whose delta outgrew its lagged fp16 scale, and its gW is NaN too);
+ * xmax >= max |traj| as for ssn_weight_grad_scaled_f32.  fp32, NB <= 8, even 2N <= 208: ..._supported answers 1 / 0 for a
+ * shape, and the entry refuses the others (no fallback inside).
+ */
+int ssn_gen_backward_fused_supported(int B, int NB, int M, const ssn_gen_params *p, float xmax);
+int ssn_gen_backward_fused_f32(const float *W, const float *traj, const float *df, const float *g_time_avg, float *g_ext,
+                               float *gW, float *dmax, float xmax, double c_dyn, double c_rate, int B, int NB, int M,
+                               const ssn_gen_params *p, void *stream);
 int ssn_gen_backward_max_f32(const float *W, const float *traj, float *df_delta, const float *g_time_avg, float *g_ext,
                              float *dmax, int *tracked, double c_dyn, double c_rate, int B, int NB, int M,
                              const ssn_gen_params *p, void *stream);

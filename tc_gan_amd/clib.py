@@ -194,6 +194,11 @@ for _name in ('ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64'):
     getattr(libssnode, _name).restype = c_int
 libssnode.ssn_gen_backward_max_f32.argtypes = [c_void_p] * 6 + [POINTER(c_int), c_double, c_double, c_int, c_int, c_int, _gp, c_void_p]
 libssnode.ssn_gen_backward_max_f32.restype = c_int
+libssnode.ssn_gen_backward_fused_supported.argtypes = [c_int, c_int, c_int, _gp, c_float]
+libssnode.ssn_gen_backward_fused_supported.restype = c_int
+libssnode.ssn_gen_backward_fused_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                                 c_double, c_double, c_int, c_int, c_int, _gp, c_void_p]
+libssnode.ssn_gen_backward_fused_f32.restype = c_int
 libssnode.ssn_jds_grad_f32.argtypes = [c_void_p, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_float),
                                        c_void_p, c_int, c_int, c_void_p]
 libssnode.ssn_jds_grad_f64.argtypes = [c_void_p, c_void_p, POINTER(c_double), POINTER(c_double), POINTER(c_double),
@@ -339,7 +344,7 @@ DECLARED_SYMBOLS = (
     'ssn_penalty_means_f32', 'ssn_penalty_means_f64', 'ssn_penalty_means_probe_f32', 'ssn_penalty_means_probe_f64', 'ssn_philox_amp_f32', 'ssn_philox_amp_f64',
     'ssn_segment_sqnorms_f32', 'ssn_segment_sqnorms2_f32', 'ssn_interpolate_f32', 'ssn_probe_scatter_f32', 'ssn_probe_scatter_f64',
     'ssn_set_operand_precision', 'ssn_get_operand_precision', 'ssn_solve_batch_variant_for', 'ssn_segment_sqnorms_ws_doubles',
-    'ssn_gen_backward_max_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
+    'ssn_gen_backward_max_f32', 'ssn_gen_backward_fused_supported', 'ssn_gen_backward_fused_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
     'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_critic_step_gated_run', 'ssn_gen_grads_ws_doubles', 'ssn_gen_grads_f32', 'ssn_gen_apply_f32',
     'ssn_gen_inputs_philox_f32',
 )
@@ -362,7 +367,10 @@ GEN_KERNELS = collections.OrderedDict([
     ('split-1g', 5),      # fp16-split, one group per workgroup (state exact)
     ('split-alt', 6),     # fp16-split, two alternating groups (state exact)
     ('duo', 8),           # fp16-split, two draws per workgroup (W and state 23 bits by round to nearest)
+    ('duo-fused', 9),     # forward as 'duo'; backward = ssn_gen_backward_fused_f32 (adjoint sweep + dL/dW in one launch,
+                          # one draw per workgroup); a host-side choice: ssn_gen_params.kernel carries 8
 ])
+GEN_KERNEL_FUSED = 9
 OPERAND_PRECISIONS = {'fp32': 0, 'split': 1}
 
 

@@ -998,6 +998,34 @@ int ssn_gen_backward_max_f32(const float* W, const float* traj, float* df_delta,
                              const ssn_gen_params* p, void* stream) {
     return gen_backward_impl<float>(W, traj, df_delta, g_time_avg, g_ext, c_dyn, c_rate, B, NB, M, p, stream, dmax, tracked);
 }
+int ssn_gen_backward_fused_supported(int B, int NB, int M, const ssn_gen_params* p, float xmax) {
+    if (!p) return 0;
+    ssn::GenBwdArgs<float> a;
+    a.B = B; a.NB = NB; a.M = M; a.seqlen = p->seqlen; a.skip = p->skip_steps;
+    return p->skip_steps >= 0 && p->skip_steps < p->seqlen && (long)NB * p->seqlen * M < (1L << 29) &&
+           ssn::gen_backward_fused_supported(a, xmax);
+}
+int ssn_gen_backward_fused_f32(const float* W, const float* traj, const float* df, const float* g_time_avg, float* g_ext,
+                               float* gW, float* dmax, float xmax, double c_dyn, double c_rate, int B, int NB, int M,
+                               const ssn_gen_params* p, void* stream) {
+    if (B == 0 || NB == 0) return 0;
+    if (!p || !W || !traj || !df || !g_time_avg || !gW || !ssn_gen_backward_fused_supported(B, NB, M, p, xmax)) {
+        g_last_error = "ssn_gen_backward_fused: invalid argument or unsupported size (fp32, NB <= 8, even 2N <= 208, "
+                       "NB T 2N < 2^29, 0 < xmax < inf)";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    ssn::GenBwdArgs<float> a;
+    a.W = W; a.traj = traj; a.delta = const_cast<float*>(df); a.g_time_avg = g_time_avg; a.g_ext = g_ext;
+    a.B = B; a.NB = NB; a.M = M; a.seqlen = p->seqlen; a.skip = p->skip_steps;
+    a.eps_E = (float)(p->dt / p->tau_E); a.eps_I = (float)(p->dt / p->tau_I); a.theta = (float)p->rate_penalty_threshold;
+    a.c_dyn = (float)c_dyn; a.c_rate = (float)c_rate;
+    if (dmax) {
+        SSN_TRY(hipMemsetAsync(dmax, 0, sizeof(float) * (size_t)B, (hipStream_t)stream));
+        a.dmax = reinterpret_cast<unsigned*>(dmax);
+    }
+    SSN_TRY(ssn::launch_gen_backward_fused(a, gW, xmax, (hipStream_t)stream));
+    return 0;
+}
 int ssn_weight_grad_scaled_f32(const float* delta, const float* traj, float* gW, int B, long K, int M, const float* dmax,
                                float xmax, void* stream) {
     if (!delta || !traj || !gW || !dmax || B < 0 || K < 0 || M <= 0 || M > 224 || !(xmax > 0.f) || !(xmax < __builtin_inff()) ||

@@ -107,6 +107,9 @@ hipError_t launch_gen_backward_split(const GenBwdArgs<float>& a, hipStream_t st)
 hipError_t launch_gen_forward_duo(const GenFwdArgs<float>& a, hipStream_t st);
 hipError_t launch_solve_duo(const SolveArgs<float>& a, hipStream_t st);
 hipError_t launch_gen_backward_duo(const GenBwdArgs<float>& a, hipStream_t st);
+// adjoint sweep + dL/dW in one launch (ssn_fuse.hip): a.delta = f'(u), read only; gW [B][M][M]; xmax >= max |traj|
+bool gen_backward_fused_supported(const GenBwdArgs<float>& a, float xmax);
+hipError_t launch_gen_backward_fused(const GenBwdArgs<float>& a, float* gW, float xmax, hipStream_t st);
 hipError_t launch_gen_backward_mfma(const GenBwdArgs<float>& a, hipStream_t st);
 hipError_t launch_solve_mfma(const SolveArgs<float>& a, hipStream_t st);
 

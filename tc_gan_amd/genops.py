@@ -146,6 +146,28 @@ def gen_backward(W, traj, df, g_time_avg, c_dyn, c_rate, gp, want_g_ext=False, w
     return out if len(out) > 1 else df
 
 
+def gen_backward_fused_supported(B, NB, M, gp, xmax):
+    """Whether `gen_backward_fused` takes this shape (``ssn_gen_backward_fused_supported``)."""
+    return xmax is not None and bool(libssnode.ssn_gen_backward_fused_supported(int(B), int(NB), int(M), ctypes.byref(gp), float(xmax)))
+
+
+def gen_backward_fused(W, traj, df, g_time_avg, c_dyn, c_rate, gp, xmax, want_g_ext=False):
+    """Adjoint sweep and dL/dW in one launch (``ssn_gen_backward_fused_f32``): returns (gW (B, M, M), g_ext or None,
+    dmax (B,)); `df` is only read.  What `gen_backward(..., want_dmax=True)` + `weight_grad(..., dmax, xmax)` compute."""
+    clib.require_gpu()
+    B, NB, T, M = traj.shape
+    assert W.dtype == torch.float32 and df.shape == traj.shape
+    g_time_avg = g_time_avg.to(W.dtype).contiguous()
+    g_ext = torch.empty((B, NB, M), device=W.device, dtype=W.dtype) if want_g_ext else None
+    gW = torch.empty((B, M, M), device=W.device, dtype=W.dtype)
+    dmax = torch.empty((B,), device=W.device, dtype=torch.float32)
+    rc = libssnode.ssn_gen_backward_fused_f32(
+        W.data_ptr(), traj.data_ptr(), df.data_ptr(), g_time_avg.data_ptr(), g_ext.data_ptr() if want_g_ext else None,
+        gW.data_ptr(), dmax.data_ptr(), float(xmax), float(c_dyn), float(c_rate), B, NB, M, ctypes.byref(gp), _stream())
+    clib.check(rc, 'ssn_gen_backward_fused_f32')
+    return gW, g_ext, dmax
+
+
 def rate_bound(gp):
     """A bound on every rate of the fixed-time generator started at 0, or None: with the saturating I/O function and
     dt <= tau each Euler step is a convex combination of the state and f(u) <= rate_hard_bound (networks/ssn.py:566-576)."""

@@ -260,6 +260,11 @@ class TuningCurveGenerator(object):
             raise ValueError('Unknown parameters: {}'.format(rest))
 
     @property
+    def fused_backward(self):
+        """'duo-fused': `backward` runs the one-launch sweep + dL/dW (`genops.gen_backward_fused`)."""
+        return self.kernel == clib.GEN_KERNEL_FUSED
+
+    @property
     def gen_kernel(self):
         return next(name for name, code in clib.GEN_KERNELS.items() if code == self.kernel)
 
@@ -273,7 +278,8 @@ class TuningCurveGenerator(object):
     def gen_params(self, rate_penalty_threshold=200.0):
         return genops.make_gen_params(io_type=self.io_type, k=self.k, n=self.n, tau_E=self.tau_E, tau_I=self.tau_I,
                                       dt=self.dt, seqlen=self.seqlen, skip_steps=self.skip_steps,
-                                      rate_penalty_threshold=rate_penalty_threshold, kernel=self.kernel)
+                                      rate_penalty_threshold=rate_penalty_threshold,
+                                      kernel=8 if self.fused_backward else self.kernel)
 
     # -- noise -----------------------------------------------------------------------------
     def gen_noise(self, rng, stimulator_bandwidths, **_):
@@ -452,13 +458,24 @@ class TuningCurveGenerator(object):
         else:
             g_ta = torch.zeros_like(fwd['time_avg'])
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
-        res = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, dynamics_cost / max(fwd['n_dyn'], 1),
-                                  rate_cost / fwd['n_rate'], sv['gp'], want_g_ext=self.heteroin, want_dmax=True)
-        delta, g_ext, dmax = res if self.heteroin else (res[0], None, res[1])
-        # (kept for `poisoned_draws`: a draw whose adjoint outgrew the fp16 sweep's lagged scale has NaN here)
-        self.last_dmax = dmax
-        # (fp16 two-part form of dL/dW where the sweep handed over max |delta| per draw and the rates are bounded)
-        gW = genops.weight_grad(delta, fwd['traj'], dmax=dmax, xmax=genops.rate_bound(sv['gp']))
+        c_dyn, c_rate = dynamics_cost / max(fwd['n_dyn'], 1), rate_cost / fwd['n_rate']
+        if self.fused_backward:
+            B, NB, _, M = fwd['traj'].shape
+            xmax = genops.rate_bound(sv['gp'])
+            if self.dtype != 'float32' or not genops.gen_backward_fused_supported(B, NB, M, sv['gp'], xmax):
+                raise ValueError("gen_kernel 'duo-fused' needs fp32, at most 8 stimuli, 2N <= 208 and the saturating I/O "
+                                 "function with dt <= tau (a bound on the rates)")
+            gW, g_ext, dmax = genops.gen_backward_fused(sv['W'], fwd['traj'], fwd['df'], g_ta, c_dyn, c_rate, sv['gp'], xmax,
+                                                        want_g_ext=self.heteroin)
+            self.last_dmax = dmax
+        else:
+            res = genops.gen_backward(sv['W'], fwd['traj'], fwd['df'], g_ta, c_dyn, c_rate, sv['gp'],
+                                      want_g_ext=self.heteroin, want_dmax=True)
+            delta, g_ext, dmax = res if self.heteroin else (res[0], None, res[1])
+            # (kept for `poisoned_draws`: a draw whose adjoint outgrew the fp16 sweep's lagged scale has NaN here)
+            self.last_dmax = dmax
+            # (fp16 two-part form of dL/dW where the sweep handed over max |delta| per draw and the rates are bounded)
+            gW = genops.weight_grad(delta, fwd['traj'], dmax=dmax, xmax=genops.rate_bound(sv['gp']))
         if raw:
             pieces = dict(parts=genops.jds_grad_parts(gW, sv['z'], self.J, self.D, self.S), nv=0)
             if self.heteroin:

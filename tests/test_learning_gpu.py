@@ -27,7 +27,7 @@ def _distances(kind, kernel):
 
 
 @pytest.mark.parametrize('kind,kernels', [('moments', ('tile', 'mfma-fp32', 'split-wide', 'duo')),
-                                          ('cwgan', ('tile', 'mfma-fp32', 'split-wide', 'duo'))])
+                                          ('cwgan', ('tile', 'mfma-fp32', 'split-wide', 'duo', 'duo-fused'))])
 def test_seeded_run_moves_the_generator_toward_the_truth(kind, kernels):
     final = {}
     for kernel in kernels:
@@ -38,5 +38,5 @@ def test_seeded_run_moves_the_generator_toward_the_truth(kind, kernels):
         assert dist.min() <= 0.75 * d0, (kind, kernel, d0, dist.min())
         assert dist[0] < d0                                # already the first update goes the right way
         final[kernel] = dist[-1]
-    # VALU tile, fp32 matrix-core and both fp16-split families learn the same thing
+    # VALU tile, fp32 matrix-core, both fp16-split families and the one-launch backward learn the same thing
     assert max(final.values()) - min(final.values()) < 0.02, final

@@ -22,3 +22,27 @@ if hasattr(genops.libssnode, 'ssn_debug_duo_stamps'):
     n = max(int(buf[8]), 1)
     for name, o in (('wave 0', 0), ('wave 3', 4)):
         print('  draw 0 %s: chain %.0f  barrier %.0f  serial %.0f  barrier %.0f cycles per step' % ((name,) + tuple(buf[o + i] / n for i in range(4))))
+xmax = genops.rate_bound(gp)
+out = genops.gen_forward(W, ext, gp, save=True)      # (the loop above ran the in-place sweep over its own output)
+traj, df = out['traj'], out['df']
+dmax = torch.empty((B,), device='cuda')
+def two():
+    d, dm = genops.gen_backward(W, traj, df.clone(), gta, 1.0 / out['n_dyn'], 0.01 / out['n_rate'], gp, want_dmax=True)
+    return genops.weight_grad(d, traj, dmax=dm, xmax=xmax)
+def fused(): return genops.gen_backward_fused(W, traj, df, gta, 1.0 / out['n_dyn'], 0.01 / out['n_rate'], gp, xmax)
+def clone(): return df.clone()
+for name, fn in (('df.clone()', clone), ('two launches (adjoint + dL/dW, incl. the clone)', two), ('fused adjoint + dL/dW', fused)):
+    fn(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3): r = fn()
+    e1.record(); torch.cuda.synchronize()
+    print('%s %.2f ms' % (name, e0.elapsed_time(e1) / 3))
+a = two(); b = fused()[0]
+print('max |fused - two| / max |two| per draw: %.2e' % float(((a - b).abs().reshape(B, -1).max(dim=1).values / a.abs().reshape(B, -1).max(dim=1).values).max()))
+if hasattr(genops.libssnode, 'ssn_debug_fuse_stamps'):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 32)()
+    genops.libssnode.ssn_debug_fuse_stamps(buf)
+    for w in range(4):
+        n = max(int(buf[8 * w + 4]), 1)
+        print('  wave %d: update+serial %.0f  barrier %.0f  chain %.0f  barrier %.0f cycles per step' % ((w,) + tuple(buf[8 * w + i] / n for i in range(4))))
