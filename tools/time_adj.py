@@ -2,10 +2,13 @@ import os, sys, torch
 sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/tc_gan_amd') else os.getcwd())
 from tc_gan_amd import genops
 B, NB, M, T, skip = 1024, 8, 200, 1200, 1000
+KERNEL, GEN = 8, {}
+if len(sys.argv) > 1 and sys.argv[1] == 'paper':       # the paper's run: 128 draws, 2N = 202, 240 / 200 steps, tau_E = 2, the library's own choice
+    B, NB, M, T, skip, KERNEL, GEN = 128, 8, 202, 240, 200, 0, dict(tau_E=2.0)
 g = torch.Generator(device='cuda'); g.manual_seed(1)
 W = (torch.rand((B, M, M), device='cuda', generator=g) - 0.6) * 0.02
 ext = torch.rand((B, NB, M), device='cuda', generator=g) * 20
-gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=8)
+gp = genops.make_gen_params(seqlen=T, skip_steps=skip, kernel=KERNEL, **GEN)
 out = genops.gen_forward(W, ext, gp, save=True)
 gta = torch.rand((B, NB, M), device='cuda', generator=g)
 traj, df = out['traj'], out['df']
@@ -14,7 +17,7 @@ bwd(); e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_ti
 e0.record()
 for _ in range(3): bwd()
 e1.record(); torch.cuda.synchronize()
-print('adjoint (duo, in place, repeated) %.2f ms' % (e0.elapsed_time(e1) / 3))
+print('adjoint (in place, repeated) %.3f ms' % (e0.elapsed_time(e1) / 3))
 if hasattr(genops.libssnode, 'ssn_debug_duo_stamps'):
     import ctypes
     buf = (ctypes.c_ulonglong * 16)()
@@ -34,9 +37,9 @@ def clone(): return df.clone()
 for name, fn in (('df.clone()', clone), ('two launches (adjoint + dL/dW, incl. the clone)', two), ('fused adjoint + dL/dW', fused)):
     fn(); torch.cuda.synchronize()
     e0.record()
-    for _ in range(3): r = fn()
+    for _ in range(10): r = fn()
     e1.record(); torch.cuda.synchronize()
-    print('%s %.2f ms' % (name, e0.elapsed_time(e1) / 3))
+    print('%s %.3f ms' % (name, e0.elapsed_time(e1) / 10))
 a = two(); b = fused()[0]
 print('max |fused - two| / max |two| per draw: %.2e' % float(((a - b).abs().reshape(B, -1).max(dim=1).values / a.abs().reshape(B, -1).max(dim=1).values).max()))
 if hasattr(genops.libssnode, 'ssn_debug_fuse_stamps'):
