@@ -1,7 +1,7 @@
 // The BPTT adjoint sweep with dL/dW accumulated ON CHIP (round 4): one launch in place of gen_backward_duo_kernel (ssn_duo.hip) +
 // gw_split_kernel (ssn_gw.hip); the delta stream between them (7.9 GB at the C3 shape, written by one, read back with the
 // trajectory by the other) never exists.  Opt-in (ssn_gen_backward_fused_f32, --gen-kernel duo-fused): measured it TIES the
-// two launches at small draw counts and is 9 % slower at 1024 draws (9.15 against 8.4 ms), DESIGN 3.7d says why.
+// two launches at small draw counts and is 7 % slower at 1024 draws (8.93 against 8.3-8.4 ms), DESIGN 3.7d says why.
 //
 //   workgroup = 4 waves = ONE draw, one wave per SIMD, so a wave may use the whole 512-entry register file: its quarter of
 //   W^T as fp16 parts (SSN_FUSE_NPREG 16 x 32 parts in registers, the rest in LDS) AND a strip of the 13 x 13 grid of 16 x 16
@@ -11,8 +11,8 @@
 //        lagged power-of-two scale, delta_tau as two fp16 parts into the B image of this step's chain) + x_{tau-1} as two
 //        fp16 parts into a second image of the same layout + the rank-8 update of step tau + 1:
 //            gW[i][j] += sum_s delta_{tau+1}[s][i] x_tau[s][j]
-//        = one v_mfma_f32_16x16x32_f16 per tile: K = 32 = 8 stimuli x {d_h x_h, d_h x_m, d_m x_h, d_m x_m}, issued in 13
-//        pieces (one column of tiles each) spread over the serial part's own instruction stream;
+//        = one v_mfma_f32_16x16x32_f16 per tile: K = 32 = 8 stimuli x {d_h x_h, d_h x_m, d_m x_h, d_m x_m}, issued one at a
+//        time at fenced sites spread over the serial part's own instruction stream;
 //     B: chain W^T delta_tau (46 MFMAs per wave).
 //   Both operands of the update are per-neuron vectors over (part, stimulus), the transpose of what the images hold
 //   ([column = 8 part + stimulus][8 neurons]): ds_read_b64_tr_b16 delivers them transposed, two reads per operand, no
@@ -53,9 +53,6 @@
 #define SSN_FUSE_ASM asm
 #else
 #define SSN_FUSE_ASM asm volatile
-#endif
-#ifndef SSN_FUSE_DBG
-#define SSN_FUSE_DBG 0
 #endif
 #ifndef SSN_FUSE_ABLATE
 #define SSN_FUSE_ABLATE 0       // timing only (wrong results): 1 = no rank-8 update, 2 = no chain
@@ -285,10 +282,10 @@ __device__ __forceinline__ void fuse_backward_wave(const GenBwdArgs<float>& a, f
         ops.chain(b_rd + (unsigned)FL::DIMG + img, acc);
         if constexpr (WS::TAIL_SHARED) *(LdsF4)(size_t)(xs + (unsigned)(WV * S::XS)) = acc[NT - 1];
     };
-    // the rank-8 update of one step from the two images of that step (image offsets: 0 or BB), in NRT pieces (one column of
-    // tiles each) that the serial part of the NEXT step spreads over its own instruction stream: the matrix pipe works on a
-    // piece while the vector instructions between two pieces issue
-    hv8 aopf[NFR > 0 ? NFR : 1], aopl[NLR > 0 ? NLR : 1], ubn;
+    // the rank-8 update of one step from the two images of that step (image offsets: 0 or BB), MFMA by MFMA at sites that the
+    // serial part of the NEXT step spreads over its own instruction stream: the matrix pipe works on one while the vector
+    // instructions up to the next site issue
+    hv8 aopf[NFR > 0 ? NFR : 1], aopl[NLR > 0 ? NLR : 1], ubn, ubop;
     unsigned uimg = 0u;
     auto update_begin = [&](unsigned img) {
         uimg = img;
@@ -298,39 +295,43 @@ __device__ __forceinline__ void fuse_backward_wave(const GenBwdArgs<float>& a, f
         for (int r = 0; r < NLR; ++r) aopl[r] = fuse_read_tr(tr_a + (unsigned)FL::DIMG + img + (unsigned)((FT::NF + r) * 512));
         ubn = fuse_read_tr(tr_b + (unsigned)FL::XIMG + img);
     };
-    auto update_col = [&](int c) {                      // (c is a constant after inlining)
+    // MFMA number j of the step's NM, column by column (a column in the wave's run of the left-over rows has NLR more)
+    constexpr int NM = NFR * NRT + NLR * CW;
+    auto update_one = [&](int j) {                      // (j is a constant after inlining)
+        int c = 0, i = j;
+        for (; c < NRT; ++c) {
+            const int n = NFR + ((c >= FT::C0 && c < FT::C1) ? NLR : 0);
+            if (i < n) break;
+            i -= n;
+        }
         if (c >= NRT) return;
-        const hv8 bop = ubn;
-        if (c + 1 < NRT) ubn = fuse_read_tr(tr_b + (unsigned)FL::XIMG + uimg + (unsigned)((c + 1) * 512));
-#pragma unroll
-        for (int r = 0; r < NFR; ++r) SSN_FUSE_ASM("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(gwf[r][c]) : "v"(aopf[r]), "v"(bop));
-        if (c >= FT::C0 && c < FT::C1) {
-#pragma unroll
-            for (int r = 0; r < NLR; ++r)
-                SSN_FUSE_ASM("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(gwl[r][c - FT::C0 < CW ? (c - FT::C0 >= 0 ? c - FT::C0 : 0) : 0]) : "v"(aopl[r]), "v"(bop));
+        if (i == 0) {
+            ubop = ubn;
+            if (c + 1 < NRT) ubn = fuse_read_tr(tr_b + (unsigned)FL::XIMG + uimg + (unsigned)((c + 1) * 512));
+        }
+        if (i < NFR) SSN_FUSE_ASM("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(gwf[i < NFR ? i : 0][c < NRT ? c : 0]) : "v"(aopf[i < NFR ? i : 0]), "v"(ubop));
+        else {
+            const int r = i - NFR < NLR ? i - NFR : 0, cc = c - FT::C0 < CW ? (c - FT::C0 >= 0 ? c - FT::C0 : 0) : 0;
+            SSN_FUSE_ASM("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(gwl[r][cc]) : "v"(aopl[r]), "v"(ubop));
         }
     };
-    // slot k of NSLOT in the serial part: the pieces k NRT / NSLOT ... (k + 1) NRT / NSLOT - 1
-    constexpr int NSLOT = 2 * NTF + NE;
+    // site k of NSITE in the serial part issues MFMAs k NM / NSITE ... (k + 1) NM / NSITE - 1: one, sometimes two -- a second MFMA
+    // right behind the first waits 12 cycles for the pipe, and every vector instruction behind it waits too
+    constexpr int NSITE = 2 * NTF + 3 * NE + 4 * NTF + 2;
     auto update_slot = [&](auto UPD, auto KK) {
         if constexpr (decltype(UPD)::value && !(SSN_FUSE_ABLATE & 1)) {
-#if SSN_FUSE_DBG == 2
-            constexpr int k = decltype(KK)::value;
-            if constexpr (k == 0) { for (int c = 0; c < NRT; ++c) update_col(c); }
-            constexpr int c0 = 0, c1 = 0;
-#else
-            constexpr int k = decltype(KK)::value, c0 = k * NRT / NSLOT, c1 = (k + 1) * NRT / NSLOT;
-#endif
-            if constexpr (c1 > c0) update_col(c0);
-            if constexpr (c1 > c0 + 1) update_col(c0 + 1);
-            if constexpr (c1 > c0 + 2) update_col(c0 + 2);
-            static_assert(c1 - c0 <= 3, "pieces per slot");
-#if SSN_FUSE_DBG == 1
-            if constexpr (c1 > c0) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
-#endif
+            constexpr int k = decltype(KK)::value, j0 = k * NM / NSITE, j1 = (k + 1) * NM / NSITE;
+            static_assert(k < NSITE && j1 - j0 <= 3, "MFMAs per site");
+            // (fences: left alone, the scheduler gathers the MFMAs back into groups of three or four)
+            if constexpr (j1 > j0) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j1 > j0) update_one(j0);
+            if constexpr (j1 > j0 + 1) update_one(j0 + 1);
+            if constexpr (j1 > j0 + 2) update_one(j0 + 2);
+            if constexpr (j1 > j0) __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto join_tile = [&](int tf, float usc) {
+    auto join_tile = [&](auto UPD, auto TF, float usc) {
+        constexpr int tf = decltype(TF)::value;
         mf4 sm = acc[tf];
         if constexpr (WS::HEAD_SHARED) {
             if (tf == 0) {
@@ -339,7 +340,9 @@ __device__ __forceinline__ void fuse_backward_wave(const GenBwdArgs<float>& a, f
             }
         }
         carry[2 * tf] = fmaf(duo_join<true>(sm.x, sm.z, hi, sm.y, sm.w), usc, carry[2 * tf]);
+        update_slot(UPD, std::integral_constant<int, 2 * tf>{});
         carry[2 * tf + 1] = fmaf(duo_join<false>(sm.y, sm.w, hi), usc, carry[2 * tf + 1]);
+        update_slot(UPD, std::integral_constant<int, 2 * tf + 1>{});
     };
     auto serial = [&](auto WIN, auto UPD, int tau) {
         constexpr bool win_on = decltype(WIN)::value;
@@ -356,18 +359,20 @@ __device__ __forceinline__ void fuse_backward_wave(const GenBwdArgs<float>& a, f
         bexp = ref == 0u ? 0 : (bexp > 100 ? 100 : (bexp < -100 ? -100 : bexp));
         if constexpr (decltype(UPD)::value) {              // (every step but the first: tau < T)
             const float usc = duo_pow2(-wexp - bused);
-            static_for<NTF>([&](auto TF) { join_tile(decltype(TF)::value, usc); update_slot(UPD, TF); });
+            static_for<NTF>([&](auto TF) { join_tile(UPD, TF, usc); });
         }
         float delta[NE], dm = 0.f;
         static_for<NE>([&](auto II) {
             constexpr int i = decltype(II)::value;
             float a_t = carry[i];
             if constexpr (win_on) a_t += direct(i, tau, xm[i]);
+            update_slot(UPD, std::integral_constant<int, 2 * NTF + 3 * i>{});
             delta[i] = eps[i] * dfc[i] * a_t;
             dm = fmaxf(dm, __builtin_fabsf(delta[i]));
+            update_slot(UPD, std::integral_constant<int, 2 * NTF + 3 * i + 1>{});
             carry[i] = fmaf(-eps[i], a_t, a_t);                                   // (1 - eps) a_t
             if (GEXT) dsum[i] += delta[i];
-            update_slot(UPD, std::integral_constant<int, NTF + i>{});
+            update_slot(UPD, std::integral_constant<int, 2 * NTF + 3 * i + 2>{});
         });
         const float rs = live ? duo_pow2(bexp) : 0.f;
         if (!(dm * rs < 65504.f)) { delta[0] = __builtin_nanf(""); poisoned = true; }   // outgrew the lagged scale: poison, do not clamp
@@ -381,16 +386,20 @@ __device__ __forceinline__ void fuse_backward_wave(const GenBwdArgs<float>& a, f
             constexpr int tf = decltype(TF)::value;
             const int rt = RT0 + tf;
             unsigned h, m;
+            constexpr int s0 = 2 * NTF + 3 * NE + 4 * tf;
             duo_split2(delta[2 * tf], delta[2 * tf + 1], rs, h, m);
+            update_slot(UPD, std::integral_constant<int, s0>{});
             const unsigned wr = b_wr + (unsigned)FL::DIMG + img + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW);
             *(LdsU)(size_t)wr = h;
             *(LdsU)(size_t)(wr + 128u) = m;
+            update_slot(UPD, std::integral_constant<int, s0 + 1>{});
             unsigned xh, xl;
             duo_split2(xm[2 * tf], xm[2 * tf + 1], xsc, xh, xl);
+            update_slot(UPD, std::integral_constant<int, s0 + 2>{});
             const unsigned wx = b_wr + (unsigned)FL::XIMG + img + (unsigned)(((rt >> 1) * 4 + 2 * (rt & 1)) * S::BROW);
             *(LdsU)(size_t)wx = xh;
             *(LdsU)(size_t)(wx + 128u) = xl;
-            update_slot(UPD, std::integral_constant<int, NTF + NE + tf>{});
+            update_slot(UPD, std::integral_constant<int, s0 + 3>{});
         });
         if constexpr (win_on) {
 #pragma unroll
@@ -399,12 +408,14 @@ __device__ __forceinline__ void fuse_backward_wave(const GenBwdArgs<float>& a, f
         // the queues move up (B and C were loaded one and two steps ago), then the loads for step tau - 3 go into C
 #pragma unroll
         for (int i = 0; i < NE; ++i) { dfA[i] = dfB[i]; dfB[i] = dfC[i]; xA[i] = xB[i]; xB[i] = xC[i]; }
+        update_slot(UPD, std::integral_constant<int, NSITE - 2>{});
 #pragma unroll
         for (int tf = 0; tf < NTF; ++tf) {
             load2(rs_df, tau >= 4, at(tf, tau - 4), dfC[2 * tf], dfC[2 * tf + 1]);           // f'(u_{tau-3})
             load2(rs_traj, tau >= 5, at(tf, tau - 5), xC[2 * tf], xC[2 * tf + 1]);           // x_{tau-4}: step tau - 3 pairs it with delta_{tau-3}
         }
         bused = bexp;
+        update_slot(UPD, std::integral_constant<int, NSITE - 1>{});
         const unsigned wm = duo_wave_max_bits(live ? dm : 0.f);
         if (lane == 0) __hip_atomic_fetch_max((__attribute__((address_space(3))) unsigned*)(lds + FL::SLOTS) + (tau + 3) % 3, wm,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

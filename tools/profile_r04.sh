@@ -17,7 +17,7 @@ traces)
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5/trace -- python3 bench.py --workload c5 --steps 5 --warmup 1 --no-cpu-baseline > $out/c5_bench.json 2> $out/c5_trace.log || exit 1
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/c2nb8/trace -- python3 bench.py --workload c2nb8 --steps 3 --warmup 1 --no-cpu-baseline > $out/c2nb8_bench.json 2> $out/c2nb8_trace.log || exit 1
   for t in c2 c3 c3paper c5 c2nb8; do python3 tools/summarize_profile.py $out/$t $out/$t; done
-  python3 tools/trace_gaps.py $out/c3/trace "gen_forward_duo_kernel<208, true" $out/c3_iteration.csv > $out/c3_gaps.txt 2>&1
+  python3 tools/trace_gaps.py $out/c3/trace "gen_forward_duo_kernel<208, true" $out/c3_iteration.csv 2 > $out/c3_gaps.txt 2>&1   # (iteration 2: the last of the first loop; the fp32 and one-launch-backward comparison loops follow)
   ;;
 pmc1)
   bash tools/pmc_run.sh r04_solve tools/time_solver.py 8 6 > $out/pmc_solve.log 2>&1 || exit 1

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Where the wall time of a profiled loop goes that no kernel accounts for.
-usage: tools/trace_gaps.py <rocprofv3 output dir> [anchor kernel substring] [out.csv]
+usage: tools/trace_gaps.py <rocprofv3 output dir> [anchor kernel substring] [out.csv] [iteration]
 Reads *_kernel_trace.csv, cuts the launch sequence into iterations at every launch of the anchor kernel (default: the
-trajectory-saving generator forward, one per GAN iteration), and prints for the LAST full iteration: wall span, summed kernel
+trajectory-saving generator forward, one per GAN iteration), and prints for the LAST full iteration (or the one that starts at
+the anchor's launch number `iteration`, counted from 0: a command that runs several loops): wall span, summed kernel
 time, idle time, and the largest idle gaps with the kernels on either side.  With out.csv: per-kernel totals of that
 iteration (launches, summed us) -- a steady-state table, unlike --stats, which includes warm-up and set-up launches."""
 import collections
@@ -18,7 +19,7 @@ def short(name):
     return name[:90]
 
 
-def main(src, anchor='gen_forward_duo_kernel<208, true', out=None):
+def main(src, anchor='gen_forward_duo_kernel<208, true', out=None, which=None):
     files = glob.glob(os.path.join(src, '**', '*_kernel_trace.csv'), recursive=True)
     if not files:
         sys.exit('no kernel trace under ' + src)
@@ -29,7 +30,7 @@ def main(src, anchor='gen_forward_duo_kernel<208, true', out=None):
     cuts = [i for i, r in enumerate(rows) if anchor in r[2]]
     if len(cuts) < 3:
         sys.exit('anchor %r seen %d times' % (anchor, len(cuts)))
-    lo, hi = cuts[-2], cuts[-1]                       # one full steady-state iteration
+    lo, hi = (cuts[-2], cuts[-1]) if which is None else (cuts[int(which)], cuts[int(which) + 1])   # one full steady-state iteration
     it = rows[lo:hi]
     span = rows[hi][0] - it[0][0]
     busy = 0
