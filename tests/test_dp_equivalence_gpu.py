@@ -50,6 +50,27 @@ def _train(n_gen_steps=2, z_device_seed=None):
     return np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses), extra
 
 
+def _train_unconditional(n_gen_steps=2, gen_kernel='auto'):
+    """The unconditional GAN (networks/wgan.py): fixed probes, no condition columns; device noise, batch of 4 draws sharded over
+    the ranks; `gen_kernel='duo-fused'`: the one-launch backward under data parallelism."""
+    from tc_gan_amd.networks.wgan import make_gan
+    cfg = _config()
+    gan, _ = make_gan(dict(
+        J0=cfg['J0'], D0=cfg['D0'], S0=cfg['S0'], gen=cfg['gen'], disc=cfg['disc'], critic_iters_init=2, critic_iters=2,
+        include_inhibitory_neurons=True, lipschitz_cost=10.0, num_sites=10, seqlen=40, skip_steps=30, batchsize=4,
+        bandwidths=[0.0625, 0.125, 0.25, 0.75], contrasts=[20.], z_device_seed=7, gen_kernel=gen_kernel))
+    ncols = len(gan.bandwidths) * len(gan.contrasts) * len(gan.sample_sites) * 2
+    gan.set_dataset(np.random.RandomState(6).rand(9, ncols) * 10)
+    it = gan.learning()
+    losses, done = [], 0
+    while done < n_gen_steps:
+        info = next(it)
+        losses.append(info.disc_loss if info.is_discriminator else info.gen_loss)
+        done += not info.is_discriminator
+    return (np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses),
+            np.array([gan.reducer.calls]))
+
+
 def _train_moments(n_steps=3):
     """Moment matching: the loss depends on the moments of the GLOBAL minibatch (one all-reduce of the per-channel
     sums before the loss, one of the parameter gradients after the adjoint sweep)."""
@@ -96,7 +117,8 @@ def _worker(rank, world, port, out, what='gan'):
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     res = {'gan': _train, 'gan_devnoise': lambda: _train(z_device_seed=31), 'moments': _train_moments,
-           'find': _find_fixed_points}[what]()
+           'find': _find_fixed_points, 'wgan': _train_unconditional,
+           'wgan_fused': lambda: _train_unconditional(gen_kernel='duo-fused')}[what]()
     out.put((rank,) + res)
     dist.barrier()
     dist.destroy_process_group()
@@ -151,6 +173,34 @@ def test_two_ranks_with_device_noise_follow_the_single_process_run():
         np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+@pytest.mark.parametrize('what', ['wgan', 'wgan_fused'])
+def test_two_ranks_unconditional_gan_follows_the_single_process_run(what):
+    """networks/wgan.py under data parallelism (the loop, the reducer and the sharded Philox rows are the conditional GAN's):
+    same losses and parameters as one process, replicas bit-identical, six collectives for 4 critic + 2 generator updates --
+    with the two-launch backward and with the one-launch one (`duo-fused`)."""
+    sys.path.insert(0, ROOT)
+    kernel = 'duo-fused' if what == 'wgan_fused' else 'auto'
+    jds1, critic1, losses1, calls1 = _train_unconditional(gen_kernel=kernel)
+    assert calls1[0] == 0
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 25700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, what)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(res[r][3], losses1, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
+        assert res[r][4][0] == 6
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
 def test_two_ranks_moment_matching_follows_the_single_process_run():
