@@ -562,7 +562,16 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
             // The chain of step `it` runs before the verdict on step it - 1 is known: it reads the state that step published
             // whatever the verdict says, and if the verdict ends the solve its sums are simply not used.
             const bool run = !finished && it < max_iter;
-            if (run) { chain(); early(); }
+            if (run) {
+                chain();
+                early();
+            } else {
+                // (the sums are not used when the chain did not run: say so, or the compiler carries the old ones around the
+                // chain with a dozen register moves in front of every chain that does run)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) asm volatile("" : "=v"(acc[t]));
+                asm volatile("" : "=v"(r1e[0]), "=v"(r1e[1]));
+            }
 #if SSN_DUO_STAMP
             t1 = SSN_SOLVE_NOW();
 #endif
