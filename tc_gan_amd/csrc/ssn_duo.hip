@@ -175,13 +175,13 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
                     const int rt = RT0 + tf;
                     const int off = (toff < 0 || 16 * rt + 4 * lg + 2 * hi >= M) ? -1 : toff + (it * M + 16 * rt) * 4;
                     const fv2 rv = {rc[2 * tf], rc[2 * tf + 1]}, dv = {dfn[2 * (tf - T0)], dfn[2 * (tf - T0) + 1]};
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), rv), rs_traj, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), dv), rs_df, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), rv), rs_traj, off, 0, SSN_DUO_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), dv), rs_df, off, 0, SSN_DUO_STORE_AUX);
                 }
                 if constexpr (TAIL) {
                     const int off = toff_tail < 0 ? -1 : toff_tail + it * M * 4;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rc[NE - 1]), rs_traj, off, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[NV - 1]), rs_df, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rc[NE - 1]), rs_traj, off, 0, SSN_DUO_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dfn[NV - 1]), rs_df, off, 0, SSN_DUO_STORE_AUX);
                 }
             }
         }
@@ -720,7 +720,7 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     auto store2 = [&](const __amdgpu_buffer_rsrc_t& rs, bool on, const At& p, float x0, float x1) {
         const fv2 q = {x0, x1};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), q), on ? rs : rs_none,
-                                              voff[p.tf], on ? soff(p) : 0, 0);
+                                              voff[p.tf], on ? soff(p) : 0, SSN_DUO_STORE_AUX);
     };
     // f'(u) of three consecutive steps in a rotating set of registers: the step with phase PH = (T - tau) % 3 uses
     // df3[(PH + 1) % 3] and loads, two steps ahead, into df3[PH] -- no register copies between steps, so the wait for a

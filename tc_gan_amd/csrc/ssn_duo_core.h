@@ -47,6 +47,10 @@
 #endif
 
 
+#ifndef SSN_DUO_STORE_AUX
+#define SSN_DUO_STORE_AUX 0       // cache policy of the trajectory / f' / delta stores (raw buffer store aux: 1 sc0, 2 nt, 16 sc1)
+#endif
+
 namespace ssn {
 
 typedef _Float16 hv8 __attribute__((ext_vector_type(8)));
