@@ -83,6 +83,9 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
         rs_traj = __builtin_amdgcn_make_buffer_rsrc(a.traj + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
         rs_df = __builtin_amdgcn_make_buffer_rsrc(a.df + (size_t)b * blk_elems, 0, (int)(blk_elems * 4), 0x00020000);
         toff = live ? (int)(((size_t)s * T_ * M + 4 * lg + 2 * hi) * 4) : -1;
+#if SSN_DUO_STORE_LAYOUT
+        toff = live ? (int)((st * 16 + 4 * lg + 2 * hi) * 4) : -1;      // TIMING ONLY (wrong results): [T][row tile][stimulus][16 rows]
+#endif
     }
     const int toff_tail = (SAVE && live && row_tail < M) ? (int)(((size_t)s * T_ * M + row_tail) * 4) : -1;
     using LdsH8 = const __attribute__((address_space(3))) hv8*;
@@ -173,7 +176,11 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
 #pragma unroll
                 for (int tf = T0; tf < T1; ++tf) {
                     const int rt = RT0 + tf;
+#if SSN_DUO_STORE_LAYOUT
+                    const int off = (toff < 0 || 16 * rt + 4 * lg + 2 * hi >= M) ? -1 : toff + ((it * S::NRT + rt) * 8) * 64;
+#else
                     const int off = (toff < 0 || 16 * rt + 4 * lg + 2 * hi >= M) ? -1 : toff + (it * M + 16 * rt) * 4;
+#endif
                     const fv2 rv = {rc[2 * tf], rc[2 * tf + 1]}, dv = {dfn[2 * (tf - T0)], dfn[2 * (tf - T0) + 1]};
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), rv), rs_traj, off, 0, SSN_DUO_STORE_AUX);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(unsigned __attribute__((ext_vector_type(2))), dv), rs_df, off, 0, SSN_DUO_STORE_AUX);

@@ -47,6 +47,9 @@
 #endif
 
 
+#ifndef SSN_DUO_STORE_LAYOUT
+#define SSN_DUO_STORE_LAYOUT 0    // 1: timing experiment, WRONG results -- every wave store 512 contiguous bytes
+#endif
 #ifndef SSN_DUO_STORE_AUX
 #define SSN_DUO_STORE_AUX 0       // cache policy of the trajectory / f' / delta stores (raw buffer store aux: 1 sc0, 2 nt, 16 sc1)
 #endif
