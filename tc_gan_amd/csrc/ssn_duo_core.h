@@ -47,6 +47,9 @@
 #endif
 
 
+#ifndef SSN_DUO_NL_SAVE
+#define SSN_DUO_NL_SAVE 0           // W parts per wave the forward with stores keeps in LDS (2N > 152; 4 until round 4: 5.1-5.3 against 5.02 ms)
+#endif
 #ifndef SSN_DUO_STORE_LAYOUT
 #define SSN_DUO_STORE_LAYOUT 0    // 1: timing experiment, WRONG results -- every wave store 512 contiguous bytes
 #endif
@@ -84,8 +87,10 @@ struct Duo16 {
     // protocol) keep the low parts (W_m) of the last NL units of every wave in LDS instead of registers (one 16-byte operand
     // per lane and unit, re-read every step) -- otherwise they spill into the time loop.  Measured at C3 / C2 with 8 stimuli:
     // plain forward 3.38 ms with NL = 0 against 3.67 with 4 (the extra reads sit on the chain's critical path, and it did not
-    // spill); forward with stores 6.1 -> 5.6 ms, solver 40.2 -> 34.3 ms with NL = 4.
-    static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? 4 : 0; }
+    // spill); forward with stores 6.1 -> 5.6 ms, solver 40.2 -> 34.3 ms with NL = 4.  (Round 4: with the chain's B operand one tile
+    // ahead and the serial part as it is now, the forward with stores no longer spills in the time loop at NL = 0: 5.02 ms
+    // against 5.1-5.3 with 4, SSN_DUO_NL_SAVE.)
+    static constexpr int nl(bool heavy) { return (heavy && MK > 152) ? SSN_DUO_NL_SAVE : 0; }
     static constexpr int nl_solve() { return MK > 152 ? SSN_DUO_SOLVE_NL : 0; }
     // adjoint sweep: 10 state values per row and stimulus -- by the number of row tiles a wave finishes (6 or 8 values per lane)
     // (window steps / the steps after the window: the window keeps four trajectory rows per value in registers)
