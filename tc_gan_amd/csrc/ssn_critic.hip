@@ -23,6 +23,7 @@
 // The layer GEMMs here are tiny (batch x 11..512 x 512): they are launch/latency bound,
 // not MFMA bound; the tile is chosen for simplicity and full generality in the strides.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <hip/hip_bf16.h>
 #include <type_traits>
 #include <cstdlib>
@@ -614,6 +615,32 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
     return critic_forward_pass(net, h, out, batch, bf16, st);
 }
 
+// The two halves of a critic update -- the Wasserstein term on [xg; xd] and the gradient penalty on xp -- are independent
+// chains of ~20 small launches each (forward, backward chain, weight gradients), latency-bound one after the other: the
+// penalty half runs on a second stream beside the first (fork behind the inputs, join in front of the final sums).  The
+// results do not change by a bit: every weight-gradient GEMM is split over K into slabs of its own, and the slabs are added
+// by ONE kernel after the join, in the order the GEMMs were ISSUED (critic_splitk_flush) -- which is the host's order, not
+// the order of execution.  A shape whose weight-gradient GEMMs would add into the gradient directly (choose_splits == 1:
+// K < 512 or >= 256 output tiles) keeps the one stream.  SSN_CRITIC_PAR=0 switches the second stream off (A/B runs).
+struct CriticFork { hipStream_t aux; hipEvent_t fork, join; };
+static CriticFork* critic_fork() {
+    static std::mutex mu;
+    static CriticFork* per_dev[64] = {};
+    static const bool on = [] { const char* e = getenv("SSN_CRITIC_PAR"); return !(e && e[0] == '0'); }();
+    if (!on) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_dev[dev]) {
+        CriticFork* f = new CriticFork{};
+        if (hipStreamCreateWithFlags(&f->aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&f->join, hipEventDisableTiming) != hipSuccess) { delete f; return nullptr; }
+        per_dev[dev] = f;
+    }
+    return per_dev[dev];
+}
+
 // Full critic loss + gradient.  stats[0..3] = mean D(xg), mean D(xd), penalty, loss.
 hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
                             const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
@@ -641,6 +668,16 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     float* tmp = p; p += dims[L];
     critic_splitk_begin(p, critic_splitk_scratch_floats(dims, nlayers, bgd + np));     // the rest of the workspace
     struct PlanScope { ~PlanScope() { critic_splitk_begin(nullptr, 0); } } plan_scope;    // closed on every return path
+    // second stream for the penalty half, when every weight-gradient GEMM of both halves goes to slabs (see critic_fork)
+    bool par = np > 0 && bgd > 0 && choose_splits(dims[L], 1, bgd) > 1;
+    for (int l = 0; l < L && par; ++l) par = choose_splits(dims[l], dims[l + 1], bgd) > 1 && choose_splits(dims[l], dims[l + 1], np) > 1;
+    CriticFork* const fk = par ? critic_fork() : nullptr;
+    hipStream_t sp = st;                            // stream of the penalty half
+    if (fk) {
+        if ((e = hipEventRecord(fk->fork, st)) != hipSuccess) return e;          // behind the memset and everything the caller queued
+        if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
+        sp = fk->aux;
+    }
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type, nc);
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type, nc);
     if ((e = critic_forward_pass(net, h, dvals, bgd, bf16, st)) != hipSuccess) return e;
@@ -659,13 +696,13 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st)) != hipSuccess) return e;
 
     // ---------------- (2) gradient penalty on xp ------------------------------------------------
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type, nc);
-    if ((e = critic_forward_pass(net, hp, dp, np, bf16, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, sp, xp, cp, hp[0], np, nx, hide_cell_type, nc);
+    if ((e = critic_forward_pass(net, hp, dp, np, bf16, sp)) != hipSuccess) return e;
     // input gradient g = dD/dh0 per sample: v_L = m_L * w_out, chain down to vp[0]
-    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, st, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L], net.leak);
-    if ((e = critic_backward_chain(net, hp, vp, np, nullptr, true, bf16, st)) != hipSuccess) return e;
+    hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, sp, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L], net.leak);
+    if ((e = critic_backward_chain(net, hp, vp, np, nullptr, true, bf16, sp)) != hipSuccess) return e;
     // penalty and its gradient w.r.t. g: ep[0] = ghat (np x n0)
-    hipLaunchKernelGGL(gp_head_kernel, dim3(1), dim3(256), 0, st, vp[0], ep[0], stats + 2, np, dims[0], nx);
+    hipLaunchKernelGGL(gp_head_kernel, dim3(1), dim3(256), 0, sp, vp[0], ep[0], stats + 2, np, dims[0], nx);
     // backprop through the linear chain g = v_1 W_1^T, v_{l} = m_l * (v_{l+1} W_{l+1}^T), v_L = m_L * w_out:
     //   dW_l[i][k] += lmd * sum_b e_{l-1}[b][i] v_l[b][k],   e_l = m_l * (e_{l-1} W_l)   (e_0 = ghat)
     long off = 0;
@@ -677,7 +714,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
             g.B = vp[l + 1]; g.sbk = nout; g.sbn = 1;
             g.C = grads + off; g.ldc = nout; g.M = nin; g.N = nout; g.K = np;
             g.alpha = lmd; g.beta = 1.f; g.epilogue = EPI_PLAIN;
-            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+            if ((e = gemm(g, bf16, sp)) != hipSuccess) return e;
         }
         {
             GemmArgs g{};                                       // e_{l+1} = m_{l+1} * (e_l W_l)
@@ -685,12 +722,17 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
             g.B = net.W[l]; g.sbk = nout; g.sbn = 1;
             g.C = ep[l + 1]; g.ldc = nout; g.M = np; g.N = nout; g.K = nin;
             g.epilogue = EPI_MASK; g.mask = hp[l + 1]; g.ldm = nout; g.leak = net.leak;
-            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+            if ((e = gemm(g, bf16, sp)) != hipSuccess) return e;
         }
         off += (long)nin * nout + nout;
     }
     // d/dw_out[k] += lmd * sum_b e_L[b][k]      (v_L = m_L * w_out, mask already applied in e_L)
-    hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(1024), 0, st, ep[L], tmp, np, dims[L], 0.f);
+    hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(1024), 0, sp, ep[L], tmp, np, dims[L], 0.f);
+    if (fk) {                                       // join: the sums below and the slab reduction see both halves
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(fk->join, fk->aux)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, fk->join, 0)) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(dims[L])), dim3(256), 0, st, grads + (net.nparams - dims[L]), tmp, lmd, (long)dims[L]);
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
     if ((e = hipGetLastError()) != hipSuccess) return e;
