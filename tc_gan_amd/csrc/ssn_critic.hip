@@ -23,7 +23,6 @@
 // The layer GEMMs here are tiny (batch x 11..512 x 512): they are launch/latency bound,
 // not MFMA bound; the tile is chosen for simplicity and full generality in the strides.
 #include <hip/hip_runtime.h>
-#include <mutex>
 #include <hip/hip_bf16.h>
 #include <type_traits>
 #include <cstdlib>
@@ -560,9 +559,13 @@ static hipError_t critic_forward_pass(const CriticNet& net, float* const* h, flo
 // Backward chain with masks from h[]: v[L] given; computes v[l-1] = m_{l-1} * (v[l] W_l^T) down to
 // v[0] = v[1] W_1^T (no mask on the input).  If grads != nullptr also accumulates parameter gradients
 // of "sum_b up_b D_b" style losses: dW_l += h_{l-1}^T v_l,  db_l += colsum(v_l).
+struct CriticFork;
+static hipError_t critic_hand_over(CriticFork* fk, hipStream_t from);
+static hipStream_t critic_grad_stream(CriticFork* fk, hipStream_t st);
 static hipError_t critic_backward_chain(const CriticNet& net, float* const* h, float* const* v, int batch, float* grads,
-                                        bool want_input_grad, bool bf16, hipStream_t st) {
+                                        bool want_input_grad, bool bf16, hipStream_t st, CriticFork* fk = nullptr) {
     hipError_t e;
+    const hipStream_t sg = critic_grad_stream(fk, st);        // weight gradients and bias sums (st itself without a fork)
     long off_end = net.nparams - net.dims[net.nlayers];
     long off = off_end;
     for (int l = net.nlayers - 1; l >= 0; --l) {
@@ -577,8 +580,9 @@ static hipError_t critic_backward_chain(const CriticNet& net, float* const* h, f
             g.B = v[l + 1]; g.sbk = nout; g.sbn = 1;        // op(B)(b, k)
             g.C = grads + off_w; g.ldc = nout; g.M = nin; g.N = nout; g.K = batch;
             g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
-            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
-            hipLaunchKernelGGL(colsum_kernel, dim3((nout + 63) / 64), dim3(1024), 0, st, v[l + 1], grads + off_b, batch, nout, 1.f);
+            if ((e = critic_hand_over(fk, st)) != hipSuccess) return e;          // v[l + 1] is queued on st
+            if ((e = gemm(g, bf16, sg)) != hipSuccess) return e;
+            hipLaunchKernelGGL(colsum_kernel, dim3((nout + 63) / 64), dim3(1024), 0, sg, v[l + 1], grads + off_b, batch, nout, 1.f);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (l > 0 || want_input_grad) {
@@ -617,29 +621,46 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
 
 // The two halves of a critic update -- the Wasserstein term on [xg; xd] and the gradient penalty on xp -- are independent
 // chains of ~20 small launches each (forward, backward chain, weight gradients), latency-bound one after the other: the
-// penalty half runs on a second stream beside the first (fork behind the inputs, join in front of the final sums).  The
+// penalty half runs on a second stream beside the first (fork behind the inputs, join in front of the final sums), and the
+// weight-gradient GEMMs and bias sums of BOTH halves -- which nothing in the chains waits for -- on a third, each behind an
+// event that says its operands are queued.  The
 // results do not change by a bit: every weight-gradient GEMM is split over K into slabs of its own, and the slabs are added
 // by ONE kernel after the join, in the order the GEMMs were ISSUED (critic_splitk_flush) -- which is the host's order, not
 // the order of execution.  A shape whose weight-gradient GEMMs would add into the gradient directly (choose_splits == 1:
 // K < 512 or >= 256 output tiles) keeps the one stream.  SSN_CRITIC_PAR=0 switches the second stream off (A/B runs).
-struct CriticFork { hipStream_t aux; hipEvent_t fork, join; };
+struct CriticFork {
+    hipStream_t aux, gs;               // penalty half; weight-gradient GEMMs and bias column sums of both halves
+    hipEvent_t fork, join, join_g;
+    hipEvent_t ready[24]; int nready;  // "operands of the next gradient GEMM are there", one per hand-over, reused every call
+    // the gradient stream takes its next launch behind everything `from` holds so far
+    hipError_t hand_over(hipStream_t from) {
+        hipEvent_t ev = ready[nready++ % 24];
+        hipError_t e = hipEventRecord(ev, from);
+        return e != hipSuccess ? e : hipStreamWaitEvent(gs, ev, 0);
+    }
+};
 static CriticFork* critic_fork() {
-    static std::mutex mu;
-    static CriticFork* per_dev[64] = {};
+    static thread_local CriticFork* per_dev[64] = {};   // per calling thread and device: the event ring is not shared
     static const bool on = [] { const char* e = getenv("SSN_CRITIC_PAR"); return !(e && e[0] == '0'); }();
     if (!on) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
     if (!per_dev[dev]) {
         CriticFork* f = new CriticFork{};
-        if (hipStreamCreateWithFlags(&f->aux, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&f->join, hipEventDisableTiming) != hipSuccess) { delete f; return nullptr; }
+        bool ok = hipStreamCreateWithFlags(&f->aux, hipStreamNonBlocking) == hipSuccess &&
+                  hipStreamCreateWithFlags(&f->gs, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&f->join, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&f->join_g, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 24 && ok; ++i) ok = hipEventCreateWithFlags(&f->ready[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { delete f; return nullptr; }
         per_dev[dev] = f;
     }
     return per_dev[dev];
 }
+
+static hipError_t critic_hand_over(CriticFork* fk, hipStream_t from) { return fk ? fk->hand_over(from) : hipSuccess; }
+static hipStream_t critic_grad_stream(CriticFork* fk, hipStream_t st) { return fk ? fk->gs : st; }
 
 // Full critic loss + gradient.  stats[0..3] = mean D(xg), mean D(xd), penalty, loss.
 hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
@@ -673,6 +694,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     for (int l = 0; l < L && par; ++l) par = choose_splits(dims[l], dims[l + 1], bgd) > 1 && choose_splits(dims[l], dims[l + 1], np) > 1;
     CriticFork* const fk = par ? critic_fork() : nullptr;
     hipStream_t sp = st;                            // stream of the penalty half
+    const hipStream_t sg = critic_grad_stream(fk, st);   // stream of the weight-gradient GEMMs and bias sums
     if (fk) {
         if ((e = hipEventRecord(fk->fork, st)) != hipSuccess) return e;          // behind the memset and everything the caller queued
         if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
@@ -690,10 +712,11 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
         g.B = up; g.sbk = 1; g.sbn = 1;
         g.C = grads + (net.nparams - dims[L]); g.ldc = 1; g.M = dims[L]; g.N = 1; g.K = bgd;
         g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
-        if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+        if ((e = critic_hand_over(fk, st)) != hipSuccess) return e;              // h[L] and up are queued on st
+        if ((e = gemm(g, bf16, sg)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)bgd * dims[L])), dim3(256), 0, st, h[L], net.wout, up, v[L], bgd, dims[L], net.leak);
-    if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st)) != hipSuccess) return e;
+    if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st, fk)) != hipSuccess) return e;
 
     // ---------------- (2) gradient penalty on xp ------------------------------------------------
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, sp, xp, cp, hp[0], np, nx, hide_cell_type, nc);
@@ -714,7 +737,8 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
             g.B = vp[l + 1]; g.sbk = nout; g.sbn = 1;
             g.C = grads + off; g.ldc = nout; g.M = nin; g.N = nout; g.K = np;
             g.alpha = lmd; g.beta = 1.f; g.epilogue = EPI_PLAIN;
-            if ((e = gemm(g, bf16, sp)) != hipSuccess) return e;
+            if ((e = critic_hand_over(fk, sp)) != hipSuccess) return e;          // e_l (and v_{l+1} before it) are queued on sp
+            if ((e = gemm(g, bf16, sg)) != hipSuccess) return e;
         }
         {
             GemmArgs g{};                                       // e_{l+1} = m_{l+1} * (e_l W_l)
@@ -732,6 +756,8 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(fk->join, fk->aux)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(st, fk->join, 0)) != hipSuccess) return e;
+        if ((e = hipEventRecord(fk->join_g, fk->gs)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(st, fk->join_g, 0)) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(dims[L])), dim3(256), 0, st, grads + (net.nparams - dims[L]), tmp, lmd, (long)dims[L]);
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
