@@ -253,7 +253,7 @@ def run_c3(args, rank, world, local_rank, paper=False):
         assert np.isfinite(info.gen_loss)
         return gan, shape, bandwidths, elapsed, info, phases
 
-    gan, (N, models, NB, T, skip), bandwidths, elapsed, info, phases = timed_loop('auto')
+    gan, (N, models, NB, T, skip), bandwidths, elapsed, info, phases = timed_loop(os.environ.get('BENCH_GEN_KERNEL', 'auto'))    # (A/B runs only)
     forward_ms_in_loop = timed_loop.forward_ms_in_loop
     # the same loop -- same seeds, fresh GAN, same warm-up, steps and max-over-ranks -- with the generator's W.r on the fp32
     # matrix instructions (W and state carried with all 24 bits), so that the line holds both numbers (`fp32_mfma` below)
