@@ -592,6 +592,31 @@ int ssn_philox_amp_f32(unsigned long long seed, unsigned long long offset, const
 int ssn_philox_amp_f64(unsigned long long seed, unsigned long long offset, const double *v, double *zin, double *amp,
                        unsigned long long n, int M, int bernoulli, void *stream);
 
+/*
+ * The reference's OWN noise stream on the device: numpy's RandomState.random_sample (= rng.rand), bit for bit.
+ * tc_gan/networks/ssn.py:434-439 draws `zs = rng.rand(batchsize, 2N, 2N)` from the RandomState the GAN shares with its
+ * minibatch sampler (stream order networks/cwgan.py:438-481) and hands it to Theano in floatX (utils/theanoutils.py:9-16:
+ * fp64 -> fp32 by round to nearest even).  numpy (pinned 1.13.1, requirements-conda.txt:46) implements RandomState as
+ * randomkit's MT19937; this call continues that generator from the caller's state:
+ *   key[624], *pos   numpy's `RandomState.get_state()[1:3]` (HOST, in/out; 0 <= pos <= 624).  On return they are the state
+ *                    numpy itself would have after `random_sample(total)`: pass them to `set_state` and the next host draw
+ *                    (`choice`, `rand`) continues exactly as in the reference.  The call returns once that state is known; it
+ *                    waits for a short chain on a stream of the library's own, never for `stream`.
+ *   total            doubles the draw consumes (2 words each: (a >> 5, b >> 6) -> (a 2^26 + b) / 2^53)
+ *   skip, count      doubles [skip, skip + count) of the draw are written to out[0 .. count) (device) on `stream`; the rest is
+ *                    not generated -- a rank of a data-parallel job passes its own rows of the global draw.  count = 0 only
+ *                    advances the state.
+ * _f32 rounds each double to the nearest float (ties to even), as numpy's astype(float32) does.  Any slice costs jump-ahead
+ * by precomputed polynomials (Haramoto et al. 2008; ssn_mt19937_poly.h), built at the first call (tens of ms per level).
+ * ssn_mt19937_jump_poly is the host-side arithmetic alone, for tests: bits[313] = t^(624 nblocks) mod the characteristic
+ * polynomial; needs no device.
+ */
+int ssn_mt19937_random_sample_f32(unsigned int *key, int *pos, unsigned long long total, unsigned long long skip,
+                                  unsigned long long count, float *out, void *stream);
+int ssn_mt19937_random_sample_f64(unsigned int *key, int *pos, unsigned long long total, unsigned long long skip,
+                                  unsigned long long count, double *out, void *stream);
+int ssn_mt19937_jump_poly(unsigned long long nblocks, unsigned long long *bits);
+
 #ifdef __cplusplus
 }
 #endif

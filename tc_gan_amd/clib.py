@@ -347,7 +347,15 @@ DECLARED_SYMBOLS = (
     'ssn_gen_backward_max_f32', 'ssn_gen_backward_fused_supported', 'ssn_gen_backward_fused_f32', 'ssn_weight_grad_scaled_f32', 'ssn_build_w_philox_f32', 'ssn_build_w_philox_f64',
     'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_critic_step_gated_run', 'ssn_gen_grads_ws_doubles', 'ssn_gen_grads_f32', 'ssn_gen_apply_f32',
     'ssn_gen_inputs_philox_f32',
+    'ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64', 'ssn_mt19937_jump_poly',
 )
+
+for _name in ('ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p, POINTER(c_int), ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong,
+                                          c_void_p, c_void_p]
+    getattr(libssnode, _name).restype = c_int
+libssnode.ssn_mt19937_jump_poly.argtypes = [ctypes.c_ulonglong, c_void_p]
+libssnode.ssn_mt19937_jump_poly.restype = c_int
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]
 libssnode.ssn_set_operand_precision.restype = c_int

@@ -1139,6 +1139,26 @@ int ssn_build_w_philox_f64(unsigned long long seed, unsigned long long offset, c
     SSN_TRY(ssn::launch_build_w_philox<double>(seed, offset, jds, W, z, B, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits) {
+    if (!bits) { g_last_error = "ssn_mt19937_jump_poly: null output"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    if (ssn::mt19937_jump_poly(nblocks, bits) != 0) {
+        g_last_error = "ssn_mt19937_jump_poly: the characteristic polynomial did not come out with degree 19937";
+        return SSN_ERR_BASE + (int)hipErrorUnknown;
+    }
+    return 0;
+}
+int ssn_mt19937_random_sample_f32(unsigned int* key, int* pos, unsigned long long total, unsigned long long skip,
+                                  unsigned long long count, float* out, void* stream) {
+    if (!key || !pos) { g_last_error = "ssn_mt19937_random_sample: null state"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::mt19937_draw(key, pos, total, skip, count, out, 4, (hipStream_t)stream));
+    return 0;
+}
+int ssn_mt19937_random_sample_f64(unsigned int* key, int* pos, unsigned long long total, unsigned long long skip,
+                                  unsigned long long count, double* out, void* stream) {
+    if (!key || !pos) { g_last_error = "ssn_mt19937_random_sample: null state"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::mt19937_draw(key, pos, total, skip, count, out, 8, (hipStream_t)stream));
+    return 0;
+}
 int ssn_gen_inputs_philox_f32(const ssn_gen_inputs* a, void* stream) {
     if (!a || !a->J || !a->D || !a->S || !a->bw || !a->con || !a->W || !a->ext || a->B < 0 || a->NB < 0 || a->N <= 0 ||
         (a->v && (!a->zin || !a->amp))) {

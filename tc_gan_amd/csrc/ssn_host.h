@@ -223,4 +223,9 @@ template <typename T> hipError_t launch_penalty_means(const T* dyn, const T* rat
                                                       int nsamp = 0, int NB = 0, int M = 0);
 template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int dim, hipStream_t st);
 
+// ssn_mt19937.hip: numpy's RandomState.random_sample on the device (key / pos: the host state, in/out)
+int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits);
+hipError_t mt19937_draw(unsigned int* key, int* pos, unsigned long long total, unsigned long long skip, unsigned long long count,
+                        void* out, int elem, hipStream_t st);
+
 }  // namespace ssn

@@ -62,6 +62,31 @@ def make_flat_param_names(named_params):
     return tuple(names)
 
 
+def device_rand(rng, shape, tdtype, rows=None):
+    """``rng.rand(*shape)`` of a ``numpy.random.RandomState`` -- the reference's ``zs = rng.rand(batchsize, 2N, 2N)``
+    (ssn.py:434-439) -- generated on the device, bit for bit (`ssn_mt19937_random_sample_*`), as a tensor of `tdtype`
+    (float32: each double rounded to nearest, like the reference's downcast to floatX).  `rng` is left in the state numpy
+    would have left it in, so the host draws that follow (minibatch `choice`, `eps`) continue the reference's stream.
+    `rows = (lo, hi)`: only rows lo..hi-1 of the draw are generated (a rank's share of the global draw); the state still
+    advances by the whole draw."""
+    kind, key, pos, has_gauss, cached = rng.get_state()
+    if kind != 'MT19937':
+        raise ValueError('device_rand continues numpy RandomState (MT19937) streams only, got {!r}'.format(kind))
+    clib.require_gpu()
+    shape = tuple(int(n) for n in shape)
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    per_row = int(np.prod(shape[1:], dtype=np.int64))
+    lo, hi = (0, shape[0]) if rows is None else (int(rows[0]), int(rows[1]))
+    out = torch.empty((hi - lo,) + shape[1:], device='cuda', dtype=tdtype)
+    cpos = ctypes.c_int(int(pos))
+    fn = (clib.libssnode.ssn_mt19937_random_sample_f32 if tdtype == torch.float32
+          else clib.libssnode.ssn_mt19937_random_sample_f64)
+    clib.check(fn(key.ctypes.data, ctypes.byref(cpos), shape[0] * per_row, lo * per_row, (hi - lo) * per_row,
+                  out.data_ptr(), clib.stream_ptr()), 'ssn_mt19937_random_sample')
+    rng.set_state((kind, key, cpos.value, has_gauss, cached))
+    return out
+
+
 class PhiloxDraw(object):
     """A slice of a `DeviceNoise` stream that has been reserved but not generated."""
 
