@@ -314,22 +314,23 @@ class ConditionalBPTTWassersteinGAN(object):
         return batch.shard(self.reducer.rank, self.reducer.world) if self.reducer.on else batch
 
     def _draw_noise(self, batch):
-        """Host noise in the reference's stream order (ssn.py:434-439, 764-767: zs, then zs_in): the GLOBAL
-        draw, then this rank's rows -- a data-parallel run consumes the RandomState exactly like a
-        single-GPU run.  Empty in device-noise mode (the generator draws from its Philox stream)."""
+        """Noise in the reference's stream order (ssn.py:434-439, 764-767: zs, then zs_in): the GLOBAL draw is consumed from
+        the shared RandomState, this rank's rows are returned -- a data-parallel run consumes the RandomState exactly like a
+        single-GPU run.  z itself is generated on the device (`ssn.device_rand`: only this rank's rows; the host never sees
+        it) unless the generator was built with `z_host_draw`.  Empty in Philox mode (`z_device_seed`)."""
         if self.gen._zgen is not None:
             return {}
-        if self.reducer.on and not getattr(self, '_warned_host_noise', False):
-            # parity mode under data parallelism: EVERY rank draws the global (num_models, 2N, 2N) fp64 tensor on the host
-            # and keeps 1/world of it, so the host cost per step grows with the job.  Meant for equivalence tests.
-            self._warned_host_noise = True
-            logger.warning('host-side noise with %d ranks: every rank draws all %d models\' z on the host each step; '
-                           'use --z-device-seed for multi-GPU runs', self.reducer.world, batch.num_models)
-        noise = self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((batch.num_models, 1)))
+        rows = None
         if self.reducer.on:
             per = batch.num_models // self.reducer.world
-            noise = {k: v[self.reducer.rank * per:(self.reducer.rank + 1) * per] for k, v in noise.items()}
-        return noise
+            rows = (self.reducer.rank * per, (self.reducer.rank + 1) * per)
+            if self.gen.z_host_draw and not getattr(self, '_warned_host_noise', False):
+                # host draw under data parallelism: EVERY rank draws the global (num_models, 2N, 2N) fp64 tensor on the host
+                # and keeps 1/world of it, so the host cost per step grows with the job.  Meant for equivalence tests.
+                self._warned_host_noise = True
+                logger.warning('host-side noise with %d ranks: every rank draws all %d models\' z on the host each step',
+                               self.reducer.world, batch.num_models)
+        return self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((batch.num_models, 1)), rows=rows)
 
     def gen_forward(self, batch, noise=None, save=False):
         local = self._local(batch)
@@ -806,7 +807,7 @@ def make_gan(config):
         unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'),
         z_device_seed=take('z_device_seed', None), shard=(reducer.rank, reducer.world),
-        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=gen_kernel)
+        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=gen_kernel, z_host_draw=take('z_host_draw', False))
     rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
     disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
     seed = take('seed', 0)

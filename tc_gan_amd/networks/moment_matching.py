@@ -111,11 +111,11 @@ class BPTTMomentMatcher(object):
     def _draw_noise(self):
         if self.gen._zgen is not None:
             return {}
-        noise = self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((self.global_batchsize, 1)))
+        rows = None
         if self.reducer.on:
             per = self.gen.batchsize
-            noise = {k: v[self.reducer.rank * per:(self.reducer.rank + 1) * per] for k, v in noise.items()}
-        return noise
+            rows = (self.reducer.rank * per, (self.reducer.rank + 1) * per)
+        return self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((self.global_batchsize, 1)), rows=rows)
 
     def moment_loss_grad(self, x):
         """x (B_local, D) fp32 CUDA -> (gx, L0, gen_moments (2, D) numpy)."""
@@ -196,7 +196,7 @@ def make_moment_matcher(config):
         include_time_avg=take('include_time_avg', False), unroll_scan=take('unroll_scan', False),
         dtype=take('gen_dtype', 'float32'), z_device_seed=take('z_device_seed', None),
         shard=(reducer.rank, reducer.world),
-        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=take('gen_kernel', 'auto'))
+        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=take('gen_kernel', 'auto'), z_host_draw=take('z_host_draw', False))
     bounds = {name: (take(name + '_min', 1e-3), take(name + '_max', 10.0)) for name in 'JDS'}
     bounds['V'] = _v_bounds(take('V_min', 0), take('V_max', 1), ssn_type)
     upd_cfg = {k: take(k) for k in ('learning_rate', 'update_name', 'update_config', 'reg_l2_penalty', 'reg_l2_decay',

@@ -62,6 +62,11 @@ def make_flat_param_names(named_params):
     return tuple(names)
 
 
+def _is_mt19937(rng):
+    return isinstance(rng, np.random.RandomState) and rng.get_state(legacy=True)[0] == 'MT19937' \
+        if hasattr(rng, 'get_state') else False
+
+
 def device_rand(rng, shape, tdtype, rows=None):
     """``rng.rand(*shape)`` of a ``numpy.random.RandomState`` -- the reference's ``zs = rng.rand(batchsize, 2N, 2N)``
     (ssn.py:434-439) -- generated on the device, bit for bit (`ssn_mt19937_random_sample_*`), as a tensor of `tdtype`
@@ -199,7 +204,7 @@ class TuningCurveGenerator(object):
     def __init__(self, num_sites, num_tcdom, smoothness, J, D, S, k, n, tau_E, tau_I, dt, io_type,
                  seqlen, skip_steps, batchsize, probes=None, include_rate_penalty=True,
                  include_time_avg=False, unroll_scan=False, dtype='float32', z_device_seed=None, shard=(0, 1),
-                 ssn_type='default', V=0, dist_in='bernoulli', gen_kernel='auto'):
+                 ssn_type='default', V=0, dist_in='bernoulli', gen_kernel='auto', z_host_draw=False):
         clib.require_gpu()
         # kernel family of the forward / adjoint launches (`ssn_gen_params.kernel`, names in clib.GEN_KERNELS): explicit
         # state of the generator, written to info.json and checkpoints -- 'auto' follows the library's operand-precision
@@ -249,6 +254,9 @@ class TuningCurveGenerator(object):
         self._zgen = None
         if z_device_seed is not None:
             self._zgen = DeviceNoise(int(z_device_seed), *shard)
+        # reference-stream mode (no z_device_seed): `zs = rng.rand(...)` of the caller's RandomState is generated on the device,
+        # bit for bit (`device_rand`); z_host_draw = True keeps the draw on the host (numpy itself: the A/B of the tests)
+        self.z_host_draw = bool(z_host_draw)
 
     num_neurons = property(lambda self: 2 * self.num_sites)
     conditional = property(lambda self: self.probes is None)
@@ -307,9 +315,11 @@ class TuningCurveGenerator(object):
                                       kernel=8 if self.fused_backward else self.kernel)
 
     # -- noise -----------------------------------------------------------------------------
-    def gen_noise(self, rng, stimulator_bandwidths, **_):
-        """ssn.py:434-439: ``zs = rng.rand(batchsize, 2N, 2N)`` from the HOST RandomState (parity mode),
-        or a device Philox draw when the generator was built with `z_device_seed` (perf mode)."""
+    def gen_noise(self, rng, stimulator_bandwidths, rows=None, **_):
+        """ssn.py:434-439: ``zs = rng.rand(batchsize, 2N, 2N)`` of the caller's RandomState -- the reference's stream, generated
+        on the device bit for bit and leaving `rng` as numpy would (`device_rand`; `z_host_draw`: numpy draws it on the host) --
+        or a device Philox draw when the generator was built with `z_device_seed` (another stream: perf mode).
+        `rows = (lo, hi)`: this rank's models of the global draw (the whole draw is consumed, only these rows are returned)."""
         num_models = np.shape(stimulator_bandwidths)[0]
         M = self.num_neurons
         if self._zgen is not None:
@@ -320,11 +330,15 @@ class TuningCurveGenerator(object):
                 # (reserved like z: _device_inputs generates it together with the stimulus and W, `ssn_gen_inputs_philox_f32`)
                 noise['model_zs_in'] = self._zgen.lazy_signs_and_amp((num_models, M), self.tdtype, vs, self.dist_in == 'bernoulli')
             return noise
-        noise = dict(model_zs=rng.rand(num_models, M, M))
-        if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720
+        sl = slice(None) if rows is None else slice(int(rows[0]), int(rows[1]))
+        if self.z_host_draw or not _is_mt19937(rng):
+            noise = dict(model_zs=rng.rand(num_models, M, M)[sl])
+        else:
+            noise = dict(model_zs=device_rand(rng, (num_models, M, M), self.tdtype, rows=rows))
+        if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720; small: stays on the host
             shape = (num_models, M)
             noise['model_zs_in'] = (rng.choice(2, shape) * 2 - 1 if self.dist_in == 'bernoulli'
-                                    else rng.rand(*shape) * 2 - 1)
+                                    else rng.rand(*shape) * 2 - 1)[sl]
         return noise
 
     # -- forward ------------------------------------------------------------------------------

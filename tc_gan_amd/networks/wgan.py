@@ -130,7 +130,7 @@ def make_gan(config):
         include_rate_penalty=take('include_rate_penalty', True), include_time_avg=take('include_time_avg', False),
         unroll_scan=take('unroll_scan', False), dtype=take('gen_dtype', 'float32'),
         z_device_seed=take('z_device_seed', None), shard=(reducer.rank, reducer.world),
-        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=gen_kernel)
+        ssn_type=ssn_type, V=V, dist_in=dist_in, gen_kernel=gen_kernel, z_host_draw=take('z_host_draw', False))
     rate_penalty_threshold = gen_cfg.pop('rate_penalty_threshold')
     disc_rate_penalty_bound = disc_cfg.pop('rate_penalty_bound')
     seed = take('seed', 0)

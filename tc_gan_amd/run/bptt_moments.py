@@ -70,7 +70,9 @@ def make_parser():
     parser.add_argument('--gen-kernel', default='auto', choices=tuple(clib.GEN_KERNELS),
                         help='Kernel family of the generator forward / adjoint (new; see tc_gan.run.bptt_cwgan --help)')
     parser.add_argument('--z-device-seed', default=None, type=int,
-                        help='Draw z on the device (Philox) instead of the host RandomState (new; fast mode)')
+                        help='Draw z from a Philox stream of this seed instead of the RandomState (new; another noise stream)')
+    parser.add_argument('--z-host-draw', action='store_true',
+                        help='Draw z with numpy on the host (default: the same RandomState stream continued on the device)')
     parser.add_argument('--n_bandwidths', default=4, type=int, choices=(1, 4, 5, 8))
     parser.add_argument('--load-gen-param', help='generator.csv whose last row is the starting point.')
     execution.add_base_learning_options(parser)

@@ -99,8 +99,11 @@ def add_bptt_common_options(parser):
                              'adjoint grows more than 2^8 within one step makes its gradient NaN (never a clamped finite value) '
                              'and the run logs how many draws did -- mfma-fp32 has no such limit')
     parser.add_argument('--z-device-seed', default=None, type=int,
-                        help='Draw z on the device (Philox4x32-10, one stream sharded over the ranks) instead of the '
-                             'host RandomState (new; fast mode, and the mode to use for multi-GPU runs)')
+                        help='Draw z from a Philox4x32-10 stream of this seed (sharded over the ranks) instead of the '
+                             'RandomState the reference draws it from (new; ANOTHER noise stream, no host round trip at all)')
+    parser.add_argument('--z-host-draw', action='store_true',
+                        help='Draw z = rng.rand(batch, 2N, 2N) with numpy on the host, as the reference does.  Default: the '
+                             'same RandomState stream continued on the device, bit for bit (ssn_mt19937_random_sample_*)')
 
 
 def add_learning_options(parser):

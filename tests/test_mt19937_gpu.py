@@ -91,3 +91,46 @@ def test_repeated_draws_follow_numpy_through_a_sequence():
         got = device_rand(dev, (32, 204, 204), torch.float32)
         assert np.array_equal(got.cpu().numpy(), want), step
     assert np.array_equal(_state(host)[0], _state(dev)[0]) and _state(host)[1] == _state(dev)[1]
+
+
+def _gan_run(z_host_draw, ssn_type='default', records=12, **over):
+    from oracle import ssn_numpy as on
+    from tc_gan_amd.networks.cwgan import make_gan
+    JDS = on.new_JDS()
+    cfg = dict(num_sites=10, seqlen=40, skip_steps=30, num_models=6, probes_per_model=2, norm_probes=[0, 0.5],
+               include_inhibitory_neurons=True, bandwidths=[0.0625, 0.125, 0.25, 0.75], contrasts=[5., 20.],
+               J0=JDS['J'], D0=JDS['D'], S0=JDS['S'], critic_iters_init=3, critic_iters=2, lipschitz_cost=10.0, ssn_type=ssn_type,
+               gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01, rate_penalty_threshold=5.0),
+               disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[16, 16], normalization='none',
+                         nonlinearity='rectify', precision='fp32'), z_host_draw=z_host_draw)
+    cfg.update(over)
+    gan, _ = make_gan(cfg)
+    ncols = len(gan.bandwidths) * len(gan.contrasts) * len(gan.norm_probes) * 2
+    gan.set_dataset(np.random.RandomState(3).rand(9, ncols) * 10)
+    it = gan.learning()
+    out = []
+    for _ in range(records):
+        info = next(it)
+        out.append(info.disc_loss if info.is_discriminator else info.gen_loss)
+    st = gan.rng.get_state()
+    return np.array(out), st[1].copy(), int(st[2]), gan.get_gen_param(), gan.disc.get_flat().copy()
+
+
+@pytest.mark.parametrize('ssn_type', ['default', 'deg-heteroin'])
+def test_gan_loop_device_draw_equals_host_draw(ssn_type):
+    """The default loop (z continued on the device from the shared RandomState) and the loop that lets numpy draw z on the
+    host: same losses record for record, same parameters, and the SAME RandomState afterwards -- minibatch `choice`s, `eps`
+    and z interleave as in cwgan.py:438-481 in both."""
+    a = _gan_run(False, ssn_type)
+    b = _gan_run(True, ssn_type)
+    assert np.array_equal(a[0], b[0])
+    assert np.array_equal(a[1], b[1]) and a[2] == b[2]
+    for x, y in zip(a[3], b[3]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a[4], b[4])
+
+
+def test_gan_loop_device_draw_fp64_generator():
+    a = _gan_run(False, gen_dtype='float64', records=6)
+    b = _gan_run(True, gen_dtype='float64', records=6)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
