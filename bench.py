@@ -125,7 +125,7 @@ def _traffic(key):
 
 
 def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iters_init=5, critic_iters=5, models=None,
-                gen_kernel='auto'):
+                gen_kernel='auto', z_mode='philox'):
     """The GAN of BASELINE config 3/4 (or, `paper=True`, of scripts/fig4/gan/run.json) with its truth data set:
     returns (gan, (N, models_per_rank, NB, T, skip), bandwidths).  Shared by the bench and by the full-size parity test."""
     from tc_gan_amd.networks.cwgan import make_gan
@@ -136,12 +136,15 @@ def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iter
     cfg = dict(num_sites=N, num_models=models * world, probes_per_model=1, norm_probes=[0.0],
                include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
                seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=critic_iters_init, critic_iters=critic_iters,
-               lipschitz_cost=10.0, z_device_seed=4321,      # one Philox stream, sharded over the ranks by make_gan
-               gen_kernel=gen_kernel,
+               lipschitz_cost=10.0, gen_kernel=gen_kernel,
                gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
                          nonlinearity='rectify', precision=disc_precision))
+    # z_mode: 'philox' = one Philox stream sharded over the ranks (--z-device-seed: NOT the reference's noise), 'refstream' = the
+    # reference's own stream, rng.rand of the GAN's RandomState(seed 0), continued on the device bit for bit (the package
+    # default), 'numpy' = the same stream drawn by numpy on the host (--z-host-draw: what the reference itself does)
+    cfg.update({'philox': dict(z_device_seed=4321), 'refstream': {}, 'numpy': dict(z_host_draw=True)}[z_mode])
     if paper:
         cfg.update(tau_E=2, ssn_type='deg-heteroin', V=0.1)
         cfg['gen'].update(learning_rate=1e-4, update_name='rmsprop', dynamics_cost=0.0, rate_cost=100.0)
@@ -193,7 +196,13 @@ def _forward_roofline(variant, achieved, traffic, kernel_ms, M, steps_in_loop):
             'kernel_ms': kernel_ms, 'flops_per_unit': 2 * M + 8, 'ssn_steps_per_s_in_loop': steps_in_loop}
 
 
-def run_c3(args, rank, world, local_rank, paper=False):
+Z_MODES = {'philox': 'device-side z (Philox)',
+           'refstream': "z = the reference's RandomState stream (seed 0, shared with the minibatch sampler) continued on the device "
+                        'bit for bit (ssn_mt19937_random_sample_f32)',
+           'numpy': "z = rng.rand drawn by numpy on the host, as the reference does (--z-host-draw)"}
+
+
+def run_c3(args, rank, world, local_rank, paper=False, z_mode='philox', comparisons=True):
     """``paper=True``: the shape of the reference's published run (scripts/fig4/gan/run.json): 2N=202, 128 models,
     seqlen 240 / skip 200, tau_E=2, deg-heteroin SSN, 4x128 critic with LayerNorm on layers 2-4, rmsprop.
     Default: BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
@@ -205,7 +214,8 @@ def run_c3(args, rank, world, local_rank, paper=False):
     import torch.distributed as dist
     def timed_loop(gen_kernel):
         """warm-up + `steps` GAN iterations of a FRESH GAN (same seeds), barrier + synchronize on both sides, MAX over ranks."""
-        gan, shape, bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision, gen_kernel=gen_kernel)
+        gan, shape, bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision, gen_kernel=gen_kernel,
+                                             z_mode=z_mode)
         gan.reducer.timed = dist.is_initialized()
         it = gan.learning()
 
@@ -251,25 +261,27 @@ def run_c3(args, rank, world, local_rank, paper=False):
                       'host_draw_ms': {'max': float(hi[1]), 'min': float(lo[1])},
                       'collectives_per_iteration': (gan.reducer.calls - calls0) / args.steps}
         assert np.isfinite(info.gen_loss)
+        timed_loop.host_draw_ms = gan.host_draw_seconds * 1e3 / args.steps
         return gan, shape, bandwidths, elapsed, info, phases
 
     gan, (N, models, NB, T, skip), bandwidths, elapsed, info, phases = timed_loop(os.environ.get('BENCH_GEN_KERNEL', 'auto'))    # (A/B runs only)
     forward_ms_in_loop = timed_loop.forward_ms_in_loop
+    host_draw_ms = timed_loop.host_draw_ms
     # the same loop -- same seeds, fresh GAN, same warm-up, steps and max-over-ranks -- with the generator's W.r on the fp32
     # matrix instructions (W and state carried with all 24 bits), so that the line holds both numbers (`fp32_mfma` below)
     fp32_ms = None
-    if not paper and args.steps >= 2 and gan.gen.forward_variant(models) in SPLIT_VARIANTS:
+    if comparisons and not paper and args.steps >= 2 and gan.gen.forward_variant(models) in SPLIT_VARIANTS:
         fp32_ms = timed_loop('mfma-fp32')[3] / args.steps * 1e3
     # and with the one-launch backward (gen_kernel duo-fused: adjoint sweep + dL/dW on chip) in place of the two launches
     fused_ms = None
-    if args.steps >= 2 and gan.gen.forward_variant(models) == 8:
+    if comparisons and args.steps >= 2 and gan.gen.forward_variant(models) == 8:
         fused_ms = timed_loop('duo-fused')[3] / args.steps * 1e3
     # dominant kernel: gen_forward_kernel, timed alone with HIP events on the launch stream
     bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
     kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
               prober_model_ids=np.arange(models), prober_cell_types=np.zeros(models))
     from tc_gan_amd import genops
-    noise = gan.gen.gen_noise(None, bw)
+    noise = gan.gen.gen_noise(gan.rng, bw)
     ext, z, W = gan.gen._device_inputs(bw, kw['stimulator_contrasts'], noise['model_zs'], noise.get('model_zs_in'))
     gp = gan.gen.gen_params(200.0)
     genops.gen_forward(W, ext, gp)
@@ -303,16 +315,20 @@ def run_c3(args, rank, world, local_rank, paper=False):
         'data': 'synthetic',
         'config': {'workload': ('C3 paper shape (scripts/fig4/gan/run.json): 2N=202, 128 models x 8 bandwidths per GPU, '
                                 'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
-                                'rmsprop, device-side z (Philox)') if paper else
+                                'rmsprop, ' + Z_MODES[z_mode]) if paper else
                                'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
                                '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
-                               'device-side z (Philox)', 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
+                               + Z_MODES[z_mode], 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
         'roofline': _forward_roofline(variant, achieved, traffic, kernel_ms, M, 7 * units * iters_per_s * world),
         'last_gen_loss': info.gen_loss, 'gen_kernel': out_extra_kernel, 'forward_variant': variant,
     }
     # (kernel_ms: mean duration of the plain forwards inside the timed loop; kernel_ms_alone: the same launch repeated by
     # itself after the loop, on an idle card)
     out['roofline']['kernel_ms_alone'] = kernel_ms_alone
+    # host time per iteration inside the loop's RNG draws (minibatch choice, eps, and -- z_mode 'numpy' -- z itself; in 'refstream'
+    # mode the part of ssn_mt19937_random_sample_f32 the host waits for: the state after the draw)
+    out['z_mode'] = z_mode
+    out['host_draw_ms'] = host_draw_ms
     if fp32_ms is not None:
         out['fp32_mfma'] = {'ms_per_step': fp32_ms, 'value': world * 1e3 / fp32_ms, 'steps': args.steps, 'warmup': args.warmup,
                             'note': 'same loop on a fresh GAN with the same seeds, generator forward and adjoint on the fp32 MFMA '
@@ -484,6 +500,8 @@ def main():
     ap.add_argument('--no-extras', dest='extras', action='store_false',
                     help='default (C2) workload on one GPU: skip the short c2nb8 / c5 / c1-dropin / c3paper runs that ride along '
                          'as `extras`')
+    ap.add_argument('--z-mode', default='philox', choices=sorted(Z_MODES),
+                    help="c3 / c3paper: where z comes from (see make_c3_gan)")
     ap.add_argument('--disc-precision', default='bf16', choices=['bf16', 'fp32'],
                     help='c3: critic GEMM operand precision (BASELINE config 3 names bf16 MFMA)')
     ap.add_argument('--via', default='batched', choices=['batched', 'dropin'],
@@ -531,9 +549,9 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     if args.workload == 'c3paper':
-        out = run_c3(args, rank, world, local_rank, paper=True)
+        out = run_c3(args, rank, world, local_rank, paper=True, z_mode=args.z_mode)
     elif args.workload == 'c3':
-        out = run_c3(args, rank, world, local_rank)
+        out = run_c3(args, rank, world, local_rank, z_mode=args.z_mode)
     elif args.workload == 'c5':
         out = run_c5(args, rank, world, local_rank)
     elif args.workload == 'c1' and args.via == 'dropin':
@@ -556,14 +574,23 @@ def main():
             # them too: C2 with the 8 bandwidths every real caller uses, C5, C1 through the drop-in symbols, the paper's shape.
             out['extras'] = {}
             keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
-                    'gen_kernel', 'forward_variant', 'last_gen_loss', 'fused_backward')
+                    'gen_kernel', 'forward_variant', 'last_gen_loss', 'fused_backward', 'z_mode', 'host_draw_ms', 'numpy_host_draw_ms')
             for name, workload, steps, warmup, kw in (('c2nb8', 'c2nb8', 3, 1, {}), ('c5', 'c5', 5, 1, {}),
                                                       ('c1_dropin', 'c1', 1, 0, dict(via='dropin', cpu_sample=128)),
-                                                      ('c3paper', 'c3paper', 20, 5, {})):
+                                                      ('c3paper', 'c3paper', 20, 5, {}),
+                                                      ('c3_refstream', 'c3', max(args.secondary_steps, 3), 2, {}),
+                                                      ('c3paper_refstream', 'c3paper', 20, 5, {})):
                 sub = argparse.Namespace(**dict(vars(args), workload=workload, steps=steps, warmup=warmup, variant=-1,
                                                 no_cpu_baseline=(name != 'c1_dropin'), **kw))
                 t_extra = time.perf_counter()
-                if workload == 'c3paper':
+                if name.endswith('_refstream'):
+                    # the C3 loop WITHOUT --z-device-seed: the reference's noise stream (RandomState seed 0), z on the device
+                    res = run_c3(sub, rank, world, local_rank, paper=workload == 'c3paper', z_mode='refstream', comparisons=False)
+                    rs_t = np.random.RandomState(0)
+                    t_np = time.perf_counter()
+                    rs_t.rand(*((128, 202, 202) if workload == 'c3paper' else (1024, 200, 200)))
+                    res['numpy_host_draw_ms'] = (time.perf_counter() - t_np) * 1e3 * 6     # six z draws per iteration on this host
+                elif workload == 'c3paper':
                     res = run_c3(sub, rank, world, local_rank, paper=True)
                 elif workload == 'c5':
                     res = run_c5(sub, rank, world, local_rank)
