@@ -10,13 +10,15 @@
 // level (digit d = 1..63 times the stride), so that any state is at most one jump per level away and all states of a level
 // are computed by ONE launch from the states of the level above.
 //
-//   mt_jump_kernel   one workgroup per (state, share of the polynomial's taps): regenerates the 20560 words the taps can
-//                    reach into LDS, accumulates XOR of x[tap + j] for its share; consumers XOR the F shares when they load
-//                    the state.  LDS-read bound (624 words per tap).
-//   mt_gen_kernel    one wave per segment: in-place regeneration in LDS (2.5 KB per wave), 104 words per pass (52 lanes x 2
-//                    words: a pass depends on no pass nearer than two back), tempering, the (a >> 5, b >> 6) -> double of
-//                    randomkit's rk_double, rounding to fp32 where asked (round to nearest even = numpy's astype), coalesced
-//                    stores of the [skip, skip + count) window only (the rows of one rank of a data-parallel job).
+//   mt_expand_kernel one workgroup per parent state: the 20608 words x[] its children's taps can reach, to memory.
+//   mt_jump_kernel   one workgroup per (state, quarter of the polynomial's tap range): its window of the parent's x[] in LDS,
+//                    twice (the second copy shifted by one word, so that every tap is ONE aligned 8-byte read per lane: words
+//                    tap + 2 t, tap + 2 t + 1 for lane t); taps arrive as LDS byte offsets by scalar loads, 16 per load, one group
+//                    ahead; XOR into two registers per lane.  Consumers XOR the four shares when they load the state.
+//   mt_gen_kernel    one workgroup per segment: wave 0 regenerates block after block (104 words per pass, 52 lanes x 2 words:
+//                    a pass depends on no pass nearer than two back), waves 1-3 temper the block before, form randomkit's
+//                    rk_double (a >> 5, b >> 6) -> double, round to fp32 where asked (round to nearest even = numpy's astype)
+//                    and store the [skip, skip + count) window only (the rows of one rank of a data-parallel job).
 //   mt_final_kernel  the state after the whole draw (every rank needs it, whatever rows it generates): a chain of at most
 //                    four single-state jumps + at most four regenerations on a side stream of the library's own; the host
 //                    waits for this chain only, never for the caller's stream.
@@ -37,9 +39,15 @@ constexpr int kStride0Log2 = 2;
 constexpr int kRadixLog2 = 6;
 constexpr int kSegLevel = 1;               // segments are the states of level 1
 constexpr int kSegBlocks = 1 << (kStride0Log2 + kRadixLog2 * kSegLevel);   // 256
-constexpr int kTapCap = 19968;             // taps of one polynomial (uint16), padded
-constexpr int kXLen = 20704;               // words of the regenerated sequence a jump workgroup keeps (19936 + 255 + 512 + 1)
-constexpr int kMaxShare = 16;
+// a polynomial's taps are cut into kShares index ranges of kShareSpan; one workgroup accumulates one share of one state
+constexpr int kShares = 4;
+constexpr int kShareSpan = 4992;                       // 4 * 4992 = 19968 >= 19937
+constexpr int kWinWords = kShareSpan + kN + 16;        // words of the sequence a share can reach (5616) + pad
+constexpr int kCopy1Off = kWinWords * 4;               // byte offset of the copy shifted by one word (8-byte reads of odd taps)
+constexpr int kZeroOff = 2 * kCopy1Off;                // 320 x 8 bytes of zeros: the target of the padding codes
+constexpr int kJumpLds = kZeroOff + 320 * 8;           // 47616 bytes: three workgroups per CU
+constexpr int kCodeCap = kShareSpan + 256;             // codes of one share (uint16 byte offsets): groups of 128, one group of pad
+constexpr int kXSeq = 20608;                           // words of an expanded sequence (3 * 4992 + 5616 = 20592 are read)
 
 struct Key { uint32_t w[kN]; };
 
@@ -55,96 +63,129 @@ __device__ __forceinline__ uint32_t temper_d(uint32_t y) {
     return y;
 }
 
-// ---- jump ------------------------------------------------------------------------------------------------------------
-struct JumpArgs {
-    Key root;                   // the caller's key: the parent of the top level
-    const uint32_t* parent;     // [..][pF][624] shares of the states one level up, or nullptr: root
-    long parent_lo;             // index (in units of the parent level's stride) of parent[0]
-    int pF;
-    uint32_t* dst;              // [count][F][624]
-    long lo;                    // index (in units of this level's stride) of dst[0]
-    int F;
-    const uint32_t* taps;       // this level: [63][kTapCap / 2] dwords, two taps each, ascending
-    const int* ntaps;           // [63]
+// ---- expand: the word sequence x[0 .. kXSeq) of a state ---------------------------------------------------------------------
+struct ExpandArgs {
+    Key root;                   // the caller's key (states == nullptr)
+    const uint32_t* states;     // [count][nparts][624] partial sums of states, or nullptr: root
+    int nparts;
+    uint32_t* xseq;             // [count][kXSeq]
 };
 
-__global__ __launch_bounds__(256) void mt_jump_kernel(const JumpArgs a) {
+__device__ __forceinline__ uint32_t xor_parts(const uint32_t* src, int nparts, int j) {
+    uint32_t v = 0;
+    for (int q = 0; q < nparts; ++q) v ^= src[(size_t)q * kN + j];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void mt_expand_kernel(const ExpandArgs a) {
     extern __shared__ __align__(16) uint32_t x[];
     const int tid = threadIdx.x;
-    const long n = a.lo + (long)blockIdx.x;
-    const int f = blockIdx.y;
-    const int d = (int)(n & 63);
-    uint32_t* out = a.dst + ((size_t)blockIdx.x * a.F + f) * kN;
-    const uint32_t* src = a.parent ? a.parent + (size_t)((n >> kRadixLog2) - a.parent_lo) * a.pF * kN : nullptr;
-    for (int j = tid; j < kN; j += 256) {
-        uint32_t v = 0;
-        if (src) { for (int s = 0; s < a.pF; ++s) v ^= src[(size_t)s * kN + j]; }
-        else v = a.root.w[j];
-        x[j] = v;
-    }
-    if (d == 0) {            // the parent's own state: share 0 carries it (exact, low bits of word 0 included), the others nothing
+    const uint32_t* src = a.states ? a.states + (size_t)blockIdx.x * a.nparts * kN : nullptr;
+    for (int j = tid; j < kN; j += 256) x[j] = src ? xor_parts(src, a.nparts, j) : a.root.w[j];
+    __syncthreads();
+    for (int k0 = 0; k0 + kN < kXSeq; k0 += kN - kM) {          // 227 independent words per step
+        const int k = k0 + tid;
+        if (tid < kN - kM && k + kN < kXSeq) x[k + kN] = x[k + kM] ^ twist_d(x[k], x[k + 1]);
         __syncthreads();
-        for (int j = tid; j < kN; j += 256) out[j] = f == 0 ? x[j] : 0u;
+    }
+    uint32_t* o = a.xseq + (size_t)blockIdx.x * kXSeq;
+    for (int k = tid; k < kXSeq; k += 256) o[k] = x[k];
+}
+
+// ---- jump ------------------------------------------------------------------------------------------------------------
+struct JumpArgs {
+    const uint32_t* xseq;       // [..][kXSeq] expanded sequences of the states one level up (or of the root)
+    long parent_lo;             // index (in units of the parent level's stride) of xseq[0]
+    uint32_t* dst;              // [count][kShares * sub][624]
+    long lo;                    // index (in units of this level's stride) of dst[0]
+    int sub;                    // workgroups per share (1, 2 or 4: few states -> more workgroups each)
+    const uint16_t* codes;      // this level: [63][kShares][kCodeCap] LDS byte offsets of the taps, padded with kZeroOff
+    const int* counts;          // [63][kShares], multiples of 128
+};
+
+// Two taps: the codes of a group of 128 sit in the wave's lanes (one dword = two uint16 LDS byte offsets per lane, fetched by a
+// vector load a group ahead: the vector-memory counter is not the LDS counter, so waiting for codes never drains the reads in
+// flight) and come to the scalar side by v_readlane.
+#define SSN_MT_TAP2(k)                                                                          \
+    {                                                                                           \
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, k);                     \
+        const uint2 u = *(const uint2*)(lds + lane8 + (w & 0xffffu));                           \
+        const uint2 v = *(const uint2*)(lds + lane8 + (w >> 16));                               \
+        acc0 ^= u.x; acc1 ^= u.y; acc0 ^= v.x; acc1 ^= v.y;                                     \
+    }
+#define SSN_MT_TAP8(k) SSN_MT_TAP2(k) SSN_MT_TAP2(k + 1) SSN_MT_TAP2(k + 2) SSN_MT_TAP2(k + 3)
+
+__global__ __launch_bounds__(320) void mt_jump_kernel(const JumpArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const long n = a.lo + (long)blockIdx.x;
+    const int f = blockIdx.y / a.sub, sb = blockIdx.y % a.sub;
+    const int d = (int)(n & 63);
+    const uint32_t* xs = a.xseq + (size_t)((n >> kRadixLog2) - a.parent_lo) * kXSeq;
+    uint32_t* out = a.dst + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kN;
+    if (d == 0) {            // the parent's own state: part 0 carries it (exact, low bits of word 0 included), the others nothing
+        for (int j = tid; j < kN; j += 320) out[j] = blockIdx.y == 0 ? xs[j] : 0u;
         return;
     }
-    const uint32_t* tp = a.taps + (size_t)(d - 1) * (kTapCap / 2);
-    const int nt = a.ntaps[d - 1];
-    const int e0 = (int)((long)nt * f / a.F), e1 = (int)((long)nt * (f + 1) / a.F);
-    const int last = e1 > e0 ? (int)((tp[(e1 - 1) >> 1] >> (((e1 - 1) & 1) * 16)) & 0xffffu) : -1;
-    // x[624 .. last + 624): 227 independent words per step
-    const int need = last + kN;                                  // words [0, need) are read by the valid outputs
+    const int base = f * kShareSpan;
+    uint32_t* c0 = (uint32_t*)lds;
+    uint32_t* c1 = (uint32_t*)(lds + kCopy1Off);
+    uint32_t* zz = (uint32_t*)(lds + kZeroOff);
+    for (int k = tid; k <= kShareSpan + kN; k += 320) {
+        const uint32_t v = xs[base + k];
+        if (k < kShareSpan + kN) c0[k] = v;
+        if (k) c1[k - 1] = v;
+    }
+    for (int k = tid; k < 640; k += 320) zz[k] = 0u;
     __syncthreads();
-    for (int k0 = 0; k0 + kN < need; k0 += kN - kM) {
-        const int k = k0 + tid;
-        if (tid < kN - kM && k + kN < need) x[k + kN] = x[k + kM] ^ twist_d(x[k], x[k + 1]);
-        __syncthreads();
+    const int groups = a.counts[(d - 1) * kShares + f] >> 7;                 // groups of 128 taps
+    const int g0 = groups * sb / a.sub, g1 = groups * (sb + 1) / a.sub;
+    const uint32_t* cp = (const uint32_t*)(a.codes + ((size_t)(d - 1) * kShares + f) * kCodeCap) + (tid & 63);
+    const int lane8 = (tid < kN / 2 ? tid : kN / 2 - 1) * 8;
+    uint32_t acc0 = 0, acc1 = 0;
+    uint32_t cw = cp[(size_t)g0 * 64];
+    for (int g = g0; g < g1; ++g) {
+        const uint32_t cnext = cp[(size_t)(g + 1) * 64];                   // (the table is padded: one group ahead is in bounds)
+        SSN_MT_TAP8(0) SSN_MT_TAP8(4) SSN_MT_TAP8(8) SSN_MT_TAP8(12) SSN_MT_TAP8(16) SSN_MT_TAP8(20) SSN_MT_TAP8(24) SSN_MT_TAP8(28)
+        SSN_MT_TAP8(32) SSN_MT_TAP8(36) SSN_MT_TAP8(40) SSN_MT_TAP8(44) SSN_MT_TAP8(48) SSN_MT_TAP8(52) SSN_MT_TAP8(56) SSN_MT_TAP8(60)
+        cw = cnext;
     }
-    uint32_t acc0 = 0, acc1 = 0, acc2 = 0;
-    const uint32_t* xt = x + tid;
-    for (int e = e0; e < e1; ++e) {
-        const int t = (int)((tp[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-        acc0 ^= xt[t];
-        acc1 ^= xt[t + 256];
-        acc2 ^= xt[t + 512];            // (tid >= 112: beyond the state, never stored; inside the allocation)
-    }
-    out[tid] = acc0;
-    out[tid + 256] = acc1;
-    if (tid + 512 < kN) out[tid + 512] = acc2;
+    if (tid < kN / 2) { out[2 * tid] = acc0; out[2 * tid + 1] = acc1; }
 }
 
 // ---- the state after the draw ----------------------------------------------------------------------------------------
 // One wave: loads the state (XOR of shares) `steps` - 1 blocks before the wanted one, regenerates `steps` >= 1 times (the last
 // regeneration makes every bit of the key numpy's, the low bits of word 0 included), writes the key.
-__global__ __launch_bounds__(64) void mt_final_kernel(const uint32_t* state, int F, int steps, uint32_t* out) {
-    __shared__ __align__(16) uint32_t key[kN + 8];
-    volatile uint32_t* k = key;
+__global__ __launch_bounds__(64) void mt_final_kernel(const uint32_t* state, int nparts, int steps, uint32_t* out) {
+    __shared__ __align__(16) uint32_t k[kN + 8];
     const int lane = threadIdx.x;
-    for (int j = lane; j < kN; j += 64) {
-        uint32_t v = 0;
-        for (int s = 0; s < F; ++s) v ^= state[(size_t)s * kN + j];
-        k[j] = v;
-    }
+    for (int j = lane; j < kN; j += 64) k[j] = xor_parts(state, nparts, j);
+    asm volatile("" ::: "memory");
     for (int b = 0; b < steps; ++b) {
-        for (int c = 0; c < 6; ++c) {
-            if (lane < 52) {
-                const int i = 104 * c + 2 * lane;
-                const uint32_t a0 = k[i], a1 = k[i + 1], a2 = k[i + 2 == kN ? 0 : i + 2];
-                int i1 = i + kM; if (i1 >= kN) i1 -= kN;
-                int i2 = i1 + 1; if (i2 == kN) i2 = 0;
-                const uint32_t m0 = k[i1], m1 = k[i2];
-                k[i] = m0 ^ twist_d(a0, a1);
-                k[i + 1] = m1 ^ twist_d(a1, a2);
-            }
+        for (int c = 0; c < 6; ++c) {           // in place: a pass reads its own and later OLD words, and new words >= 124 back
+            const bool act = lane < 52;
+            const int i = 104 * c + 2 * (act ? lane : 51);
+            const uint32_t a0 = k[i], a1 = k[i + 1], a2 = k[i + 2 == kN ? 0 : i + 2];
+            int i1 = i + kM; if (i1 >= kN) i1 -= kN;
+            int i2 = i1 + 1; if (i2 == kN) i2 = 0;
+            const uint32_t m0 = k[i1], m1 = k[i2];
+            asm volatile("" ::: "memory");      // (one wave: the LDS unit takes its accesses in program order)
+            if (act) { k[i] = m0 ^ twist_d(a0, a1); k[i + 1] = m1 ^ twist_d(a1, a2); }
+            asm volatile("" ::: "memory");
         }
     }
     for (int j = lane; j < kN; j += 64) out[j] = k[j];
 }
 
 // ---- generation ------------------------------------------------------------------------------------------------------
+// One workgroup per segment, four waves: wave 0 regenerates block after block (old block in one LDS buffer, new block into the
+// other: 104 words per pass, 52 lanes x 2 words; a pass reads new words no nearer than 124 back, so the next pass's operands are
+// fetched before this pass's store), waves 1-3 temper, convert and store the block made in the round before, two passes each.
+// One workgroup barrier per block.
 template <typename T>
 struct GenArgs {
-    const uint32_t* states;     // [s_hi - s_lo + 1][F][624]
-    int F;
+    const uint32_t* states;     // [s_hi - s_lo + 1][nparts][624]
+    int nparts;
     long s_lo, s_hi;            // segments to run
     long b_hi;                  // last block whose words are wanted
     int pos;                    // position in block 0 of stream word 0
@@ -152,70 +193,106 @@ struct GenArgs {
     T* out;
 };
 
-template <typename T>
-__device__ __forceinline__ void emit_pair(const GenArgs<T>& a, uint32_t wa, uint32_t wb, long q) {
-    const long qq = q - a.skip;
-    if (qq >= 0 && qq < a.count) {
+constexpr int kBufStride = kN + 8;
+
+struct GenOperands { uint32_t a0, a1, a2, m0, m1; };
+
+// operands of pass c of a regeneration: old block at word offset `oldw`, new block at `neww` of `flat`
+template <int C>
+__device__ __forceinline__ GenOperands gen_load(const uint32_t* flat, int oldw, int neww, int l) {
+    const int i = 104 * C + 2 * l;
+    GenOperands r;
+    r.a0 = flat[oldw + i];
+    r.a1 = flat[oldw + i + 1];
+    r.a2 = flat[(i + 2 < kN) ? oldw + i + 2 : neww];
+    r.m0 = flat[(i + kM < kN) ? oldw + i + kM : neww + i + kM - kN];
+    r.m1 = flat[(i + kM + 1 < kN) ? oldw + i + kM + 1 : neww + i + kM + 1 - kN];
+    asm volatile("" ::: "memory");      // (the wave's LDS accesses stay in program order: other lanes' stores are read)
+    return r;
+}
+template <int C>
+__device__ __forceinline__ void gen_store(uint32_t* flat, int neww, int l, bool act, const GenOperands& r) {
+    const int i = 104 * C + 2 * l;
+    const uint32_t n0 = r.m0 ^ twist_d(r.a0, r.a1), n1 = r.m1 ^ twist_d(r.a1, r.a2);
+    if (act) { flat[neww + i] = n0; flat[neww + i + 1] = n1; }
+    asm volatile("" ::: "memory");
+}
+template <int P>
+__device__ __forceinline__ void gen_block(uint32_t* flat, int lane) {
+    constexpr int oldw = P * kBufStride, neww = (1 - P) * kBufStride;
+    const bool act = lane < 52;
+    const int l = act ? lane : 51;
+    GenOperands r0 = gen_load<0>(flat, oldw, neww, l);
+    GenOperands r1 = gen_load<1>(flat, oldw, neww, l);
+    gen_store<0>(flat, neww, l, act, r0);
+    r0 = gen_load<2>(flat, oldw, neww, l);
+    gen_store<1>(flat, neww, l, act, r1);
+    r1 = gen_load<3>(flat, oldw, neww, l);
+    gen_store<2>(flat, neww, l, act, r0);
+    r0 = gen_load<4>(flat, oldw, neww, l);
+    gen_store<3>(flat, neww, l, act, r1);
+    r1 = gen_load<5>(flat, oldw, neww, l);         // (pass 5 reads new[0] and new[396]: passes 0 and 3, stored above)
+    gen_store<4>(flat, neww, l, act, r0);
+    gen_store<5>(flat, neww, l, act, r1);
+}
+
+template <typename T, bool ODD>
+__device__ __forceinline__ void emit_pass(const GenArgs<T>& a, const uint32_t* blk, const uint32_t* carry_in,
+                                          int c, int lane, long qb) {
+    const bool act = lane < 52;
+    const int i = 104 * c + 2 * (act ? lane : 51);
+    uint32_t w0, w1;
+    if (ODD) {                      // pair (word i - 1, word i); the first pair of a block starts in the block before
+        w0 = blk[i ? i - 1 : 0];
+        w1 = blk[i];
+        if (i == 0) w0 = *carry_in;
+    } else {
+        w0 = blk[i];
+        w1 = blk[i + 1];
+    }
+    w0 = temper_d(w0);
+    w1 = temper_d(w1);
+    const long qq = qb + (i >> 1) - a.skip;
+    if (act && (unsigned long)qq < (unsigned long)a.count) {
         // randomkit rk_double: (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53, exact in double
-        const double v = ((double)(wa >> 5) * 67108864.0 + (double)(wb >> 6)) * (1.0 / 9007199254740992.0);
+        const double v = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);
         a.out[qq] = (T)v;          // T = float: round to nearest even, as numpy's astype(float32)
     }
 }
 
-template <typename T>
+template <typename T, bool ODD>
 __global__ __launch_bounds__(256) void mt_gen_kernel(const GenArgs<T> a) {
-    __shared__ __align__(16) uint32_t keys[4][kN + 8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long seg = a.s_lo + (long)blockIdx.x * 4 + wave;
-    if (seg > a.s_hi) return;                       // (no workgroup barrier in this kernel: waves are independent)
-    volatile uint32_t* k = keys[wave];
-    const uint32_t* src = a.states + (size_t)(seg - a.s_lo) * a.F * kN;
-    for (int j = lane; j < kN; j += 64) {
-        uint32_t v = 0;
-        for (int s = 0; s < a.F; ++s) v ^= src[(size_t)s * kN + j];
-        k[j] = v;
-    }
-    const bool odd = a.pos & 1;
-    const bool act = lane < 52;
-    // doubles pair stream words (2q, 2q + 1); with an odd position a pair is (word i - 1, word i) of a block, i even, and the
-    // first pair of a block takes its first word from the block before: `carry`
-    uint32_t carry = temper_d(k[kN - 1]);
+    __shared__ __align__(16) uint32_t buf[2 * kBufStride];
+    __shared__ uint32_t carry[2];          // raw last word of the block emitted in the round before (ODD)
+    uint32_t* flat = buf;
+    uint32_t* vcarry = carry;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long seg = a.s_lo + (long)blockIdx.x;
+    const uint32_t* src = a.states + (size_t)blockIdx.x * a.nparts * kN;
+    for (int j = tid; j < kN; j += 256) flat[j] = xor_parts(src, a.nparts, j);
+    __syncthreads();
+    if (tid == 0) { vcarry[0] = flat[kN - 1]; vcarry[1] = 0u; }
+    __syncthreads();
     const long b0 = seg * kSegBlocks;               // the block the loaded state holds
-    if (seg == 0 && a.pos < kN) {
-        // the rest of the caller's current block (exact copy of its key)
-        const long qb = -(long)((a.pos + (odd ? 1 : 0)) >> 1);
-        for (int c = 0; c < 6; ++c) {
-            const int i = 104 * c + 2 * (act ? lane : 51);
-            const uint32_t t0 = temper_d(k[i]), t1 = temper_d(k[i + 1]);
-            if (odd) {
-                uint32_t prev = __shfl_up(t1, 1);
-                if (lane == 0) prev = carry;
-                if (act) emit_pair(a, prev, t0, qb + (i >> 1));
-                carry = __builtin_amdgcn_readlane(t1, 51);
-            } else if (act) emit_pair(a, t0, t1, qb + (i >> 1));
+    long nbl = a.b_hi - b0;
+    if (nbl > kSegBlocks) nbl = kSegBlocks;
+    if (nbl < 0) nbl = 0;
+    const int nb = (int)nbl;
+    const int first = (seg == 0 && a.pos < kN) ? 0 : 1;     // segment 0 also emits the rest of the caller's current block
+    for (int bb = 0; bb <= nb; ++bb) {
+        const int p = bb & 1;
+        if (wave == 0) {
+            if (bb < nb) { if (p) gen_block<1>(flat, lane); else gen_block<0>(flat, lane); }
+        } else if (bb >= first) {
+            const long b = b0 + bb;
+            const long qb = (b * kN - a.pos - (ODD ? 1 : 0)) >> 1;         // (exact: the numerator is even)
+            const uint32_t* blk = flat + p * kBufStride;
+            const int c = 2 * (wave - 1);
+            emit_pass<T, ODD>(a, blk, vcarry + (p ^ 1), c, lane, qb);
+            emit_pass<T, ODD>(a, blk, vcarry + (p ^ 1), c + 1, lane, qb);
+            if (ODD && wave == 3 && lane == 0) vcarry[p] = blk[kN - 1];
         }
-    }
-    long nb = a.b_hi - b0;
-    if (nb > kSegBlocks) nb = kSegBlocks;
-    for (long bb = 1; bb <= nb; ++bb) {
-        const long b = b0 + bb;
-        const long qb = (b * kN - a.pos - (odd ? 1 : 0)) >> 1;     // (exact: the numerator is even)
-        for (int c = 0; c < 6; ++c) {
-            const int i = 104 * c + 2 * (act ? lane : 51);
-            const uint32_t a0 = k[i], a1 = k[i + 1], a2 = k[i + 2 == kN ? 0 : i + 2];
-            int i1 = i + kM; if (i1 >= kN) i1 -= kN;
-            int i2 = i1 + 1; if (i2 == kN) i2 = 0;
-            const uint32_t m0 = k[i1], m1 = k[i2];
-            const uint32_t n0 = m0 ^ twist_d(a0, a1), n1 = m1 ^ twist_d(a1, a2);
-            if (act) { k[i] = n0; k[i + 1] = n1; }
-            const uint32_t t0 = temper_d(n0), t1 = temper_d(n1);
-            if (odd) {
-                uint32_t prev = __shfl_up(t1, 1);
-                if (lane == 0) prev = carry;
-                if (act) emit_pair(a, prev, t0, qb + (i >> 1));
-                carry = __builtin_amdgcn_readlane(t1, 51);
-            } else if (act) emit_pair(a, t0, t1, qb + (i >> 1));
-        }
+        __syncthreads();
     }
 }
 
@@ -226,8 +303,8 @@ struct HostTables {
     bool field_ok = false, field_tried = false;
     Poly base[kLevels];                                  // t^(624 * stride_l)
     bool have[kLevels] = {};
-    std::vector<uint32_t> taps[kLevels];                 // [63][kTapCap / 2]
-    std::vector<int> ntaps[kLevels];                     // [63]
+    std::vector<uint16_t> codes[kLevels];                // [63][kShares][kCodeCap]
+    std::vector<int> counts[kLevels];                    // [63][kShares]
     bool ensure_field() {
         if (!field_tried) { field_tried = true; field_ok = field.init(); }
         return field_ok;
@@ -245,16 +322,21 @@ struct HostTables {
                 base[q] = base[q - 1];
                 for (int s = 0; s < kRadixLog2; ++s) base[q] = field.sqr(base[q]);
             }
-            taps[q].assign((size_t)63 * (kTapCap / 2), 0u);
-            ntaps[q].assign(63, 0);
+            codes[q].assign((size_t)63 * kShares * kCodeCap, (uint16_t)kZeroOff);
+            counts[q].assign(63 * kShares, 0);
             Poly p = base[q];
             for (int d = 1; d <= 63; ++d) {
                 if (d > 1) p = field.mul(p, base[q]);
-                uint32_t* tp = taps[q].data() + (size_t)(d - 1) * (kTapCap / 2);
-                int nt = 0;
-                for (int i = 0; i < kDeg; ++i)
-                    if (get_bit(p.w, i)) { tp[nt >> 1] |= (uint32_t)i << ((nt & 1) * 16); ++nt; }
-                ntaps[q][d - 1] = nt;
+                for (int f = 0; f < kShares; ++f) {
+                    uint16_t* cp = codes[q].data() + ((size_t)(d - 1) * kShares + f) * kCodeCap;
+                    int nt = 0;
+                    for (int rel = 0; rel < kShareSpan; ++rel) {
+                        const int i = f * kShareSpan + rel;
+                        if (i < kDeg && get_bit(p.w, i))       // even tap: 8 bytes at word rel of the window; odd: at rel - 1 of the shifted copy
+                            cp[nt++] = (uint16_t)((rel & ~1) * 4 + (rel & 1) * kCopy1Off);
+                    }
+                    counts[q][(d - 1) * kShares + f] = (nt + 127) & ~127;     // (the padding reads zeros)
+                }
             }
             have[q] = true;
         }
@@ -264,14 +346,14 @@ struct HostTables {
 static HostTables& host_tables() { static HostTables* t = new HostTables; return *t; }
 
 struct DeviceTables {
-    uint32_t* taps[kLevels] = {};
-    int* ntaps[kLevels] = {};
+    uint16_t* codes[kLevels] = {};
+    int* counts[kLevels] = {};
     bool lds_attr = false;
     // side stream, pinned state buffer and workspace of the chain that computes the state after the draw
     hipStream_t side = nullptr;
     hipEvent_t done = nullptr;
     uint32_t* pinned = nullptr;      // [624]
-    uint32_t* chain = nullptr;       // [kLevels][kMaxShare][624]
+    uint32_t* chain = nullptr;       // [kLevels][kShares * 4][624] states + [kXSeq] sequence
     std::mutex chain_mu;             // the chain's buffers are one set per device: calls on a device take turns in it
 };
 static std::mutex g_dev_mu;
@@ -286,8 +368,8 @@ static hipError_t device_tables(int need_level, DeviceTables** out) {
     DeviceTables*& t = g_dev[dev];
     if (!t) t = new DeviceTables;
     if (!t->lds_attr) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(kXLen * sizeof(uint32_t)));
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_expand_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(kXSeq * sizeof(uint32_t)));
         if (e != hipSuccess) return e;
         t->lds_attr = true;
     }
@@ -297,30 +379,27 @@ static hipError_t device_tables(int need_level, DeviceTables** out) {
         if ((e = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, hi)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&t->done, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipHostMalloc((void**)&t->pinned, sizeof(uint32_t) * kN, hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipMalloc((void**)&t->chain, sizeof(uint32_t) * (size_t)kLevels * kMaxShare * kN)) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&t->chain, sizeof(uint32_t) * ((size_t)kLevels * kShares * 4 * kN + kXSeq))) != hipSuccess) return e;
     }
     HostTables& h = host_tables();
     std::lock_guard<std::mutex> gh(h.mu);
     if (!h.ensure_level(need_level)) return hipErrorUnknown;
     for (int l = 0; l <= need_level; ++l) {
-        if (t->taps[l]) continue;
-        uint32_t* dt = nullptr; int* dn = nullptr;
-        if ((e = hipMalloc((void**)&dt, h.taps[l].size() * sizeof(uint32_t))) != hipSuccess) return e;
-        if ((e = hipMalloc((void**)&dn, 63 * sizeof(int))) != hipSuccess) return e;
-        if ((e = hipMemcpy(dt, h.taps[l].data(), h.taps[l].size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
-        if ((e = hipMemcpy(dn, h.ntaps[l].data(), 63 * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
-        t->taps[l] = dt; t->ntaps[l] = dn;
+        if (t->codes[l]) continue;
+        uint16_t* dc = nullptr; int* dn = nullptr;
+        if ((e = hipMalloc((void**)&dc, h.codes[l].size() * sizeof(uint16_t))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&dn, h.counts[l].size() * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMemcpy(dc, h.codes[l].data(), h.codes[l].size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        if ((e = hipMemcpy(dn, h.counts[l].data(), h.counts[l].size() * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return e;
+        t->codes[l] = dc; t->counts[l] = dn;
     }
     *out = t;
     return hipSuccess;
 }
 
-static int share_for(long count) {
-    int F = 1;
-    while (F < kMaxShare && count * (F * 2) <= 512) F *= 2;
-    return F;
-}
 static inline int level_shift(int l) { return kStride0Log2 + kRadixLog2 * l; }
+// workgroups per share of a round with `count` states: enough to put a workgroup on most CUs when the states are few
+static inline int sub_for(long count) { return count * kShares * 4 <= 512 ? 4 : (count * kShares * 2 <= 512 ? 2 : 1); }
 
 }  // namespace mt
 
@@ -345,7 +424,6 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
     if (total > (1ull << 40)) return hipErrorInvalidValue;
     const long p_end = (long)pos + 2 * (long)total;              // position of the first unconsumed word, from block 0
     const long b_f = p_end <= kN ? 0 : (p_end - 1) / kN;         // block of the state after the draw
-    // levels needed: the top digit of the last block / segment must be < 64
     long b_hi = 0, s_lo = 0, s_hi = 0;
     if (count) {
         const long b_lo = ((long)pos + 2 * (long)skip) / kN;
@@ -353,6 +431,7 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
         s_lo = b_lo >= 1 ? (b_lo - 1) / kSegBlocks : 0;
         s_hi = b_hi >= 1 ? (b_hi - 1) / kSegBlocks : 0;
     }
+    // levels needed: the top digit of the last block / segment must be < 64
     int top_e = 0, top_b = kSegLevel;
     const long tgt = b_f >= 1 ? b_f - 1 : 0;                    // the chain reaches block b_f - 1, then regenerates once
     while ((tgt >> level_shift(top_e)) >= 64) if (++top_e >= kLevels) return hipErrorInvalidValue;
@@ -361,57 +440,71 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
     hipError_t e = device_tables(top_e > top_b ? top_e : top_b, &t);
     if (e != hipSuccess) return e;
 
+    ExpandArgs xa;
+    std::memcpy(xa.root.w, key, sizeof xa.root.w);
+    const size_t xlds = kXSeq * sizeof(uint32_t);
     JumpArgs ja;
-    std::memcpy(ja.root.w, key, sizeof ja.root.w);
-    const size_t lds = kXLen * sizeof(uint32_t);
 
-    // (1) the state after the draw, on the side stream
+    // (1) the state after the draw, on the side stream: one state per level, top down, then at most four regenerations
     std::unique_lock<std::mutex> chain_lock(t->chain_mu, std::defer_lock);
     if (b_f >= 1) {
         chain_lock.lock();
-        const uint32_t* parent = nullptr; long parent_lo = 0; int pF = 1;
+        uint32_t* xseq = t->chain + (size_t)kLevels * kShares * 4 * kN;
+        const uint32_t* parent = nullptr;
+        constexpr int kChainSub = 4;
         for (int l = top_e; l >= 0; --l) {
             const long idx = tgt >> level_shift(l);
-            ja.parent = parent; ja.parent_lo = parent_lo; ja.pF = pF;
-            ja.dst = t->chain + (size_t)l * kMaxShare * kN; ja.lo = idx; ja.F = kMaxShare;
-            ja.taps = t->taps[l]; ja.ntaps = t->ntaps[l];
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(1, kMaxShare), dim3(256), lds, t->side, ja);
-            parent = ja.dst; parent_lo = idx; pF = kMaxShare;
+            xa.states = parent; xa.nparts = kShares * kChainSub; xa.xseq = xseq;
+            hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), xlds, t->side, xa);
+            ja.xseq = xseq; ja.parent_lo = idx >> kRadixLog2;
+            ja.dst = t->chain + (size_t)l * kShares * kChainSub * kN; ja.lo = idx; ja.sub = kChainSub;
+            ja.codes = t->codes[l]; ja.counts = t->counts[l];
+            hipLaunchKernelGGL(mt_jump_kernel, dim3(1, kShares * kChainSub), dim3(320), kJumpLds, t->side, ja);
+            parent = ja.dst;
         }
         const int steps = (int)(tgt & ((1 << kStride0Log2) - 1)) + 1;
-        hipLaunchKernelGGL(mt_final_kernel, dim3(1), dim3(64), 0, t->side, parent, pF, steps, t->pinned);
+        hipLaunchKernelGGL(mt_final_kernel, dim3(1), dim3(64), 0, t->side, parent, kShares * kChainSub, steps, t->pinned);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(t->done, t->side)) != hipSuccess) return e;
     }
 
-    // (2) the wanted doubles, on the caller's stream
+    // (2) the wanted doubles, on the caller's stream: the states of every level between the root and the segments, top down
     if (count) {
-        const uint32_t* parent = nullptr; long parent_lo = 0; int pF = 1;
+        const uint32_t* parent = nullptr; long parent_cnt = 1; int parent_parts = 1;
         uint32_t* bufs[kLevels] = {};
+        uint32_t* xbufs[kLevels] = {};
         for (int l = top_b; l >= kSegLevel; --l) {
             const int sh = level_shift(l) - level_shift(kSegLevel);
             const long lo = s_lo >> sh, hi = s_hi >> sh, cnt = hi - lo + 1;
-            const int F = share_for(cnt);
-            if ((e = hipMallocAsync((void**)&bufs[l], sizeof(uint32_t) * (size_t)cnt * F * kN, st)) != hipSuccess) break;
-            ja.parent = parent; ja.parent_lo = parent_lo; ja.pF = pF;
-            ja.dst = bufs[l]; ja.lo = lo; ja.F = F;
-            ja.taps = t->taps[l]; ja.ntaps = t->ntaps[l];
-            hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt, F), dim3(256), lds, st, ja);
-            parent = bufs[l]; parent_lo = lo; pF = F;
+            if ((e = hipMallocAsync((void**)&xbufs[l], sizeof(uint32_t) * (size_t)parent_cnt * kXSeq, st)) != hipSuccess) break;
+            const int sub = sub_for(cnt);
+            if ((e = hipMallocAsync((void**)&bufs[l], sizeof(uint32_t) * (size_t)cnt * kShares * sub * kN, st)) != hipSuccess) break;
+            xa.states = parent; xa.nparts = parent_parts; xa.xseq = xbufs[l];
+            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)parent_cnt), dim3(256), xlds, st, xa);
+            ja.xseq = xbufs[l]; ja.parent_lo = lo >> kRadixLog2;
+            ja.dst = bufs[l]; ja.lo = lo; ja.sub = sub;
+            ja.codes = t->codes[l]; ja.counts = t->counts[l];
+            hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt, kShares * sub), dim3(320), kJumpLds, st, ja);
+            parent = bufs[l]; parent_cnt = cnt; parent_parts = kShares * sub;
         }
         if (e == hipSuccess) {
-            const long nseg = s_hi - s_lo + 1;
+            const unsigned nseg = (unsigned)(s_hi - s_lo + 1);
+            const bool odd = pos & 1;
             if (elem == 4) {
-                GenArgs<float> ga{parent, pF, s_lo, s_hi, b_hi, pos, (long)skip, (long)count, (float*)out};
-                hipLaunchKernelGGL(mt_gen_kernel<float>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, ga);
+                GenArgs<float> ga{parent, parent_parts, s_lo, s_hi, b_hi, pos, (long)skip, (long)count, (float*)out};
+                if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true>), dim3(nseg), dim3(256), 0, st, ga);
+                else hipLaunchKernelGGL((mt_gen_kernel<float, false>), dim3(nseg), dim3(256), 0, st, ga);
             } else {
-                GenArgs<double> ga{parent, pF, s_lo, s_hi, b_hi, pos, (long)skip, (long)count, (double*)out};
-                hipLaunchKernelGGL(mt_gen_kernel<double>, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, st, ga);
+                GenArgs<double> ga{parent, parent_parts, s_lo, s_hi, b_hi, pos, (long)skip, (long)count, (double*)out};
+                if (odd) hipLaunchKernelGGL((mt_gen_kernel<double, true>), dim3(nseg), dim3(256), 0, st, ga);
+                else hipLaunchKernelGGL((mt_gen_kernel<double, false>), dim3(nseg), dim3(256), 0, st, ga);
             }
             e = hipGetLastError();
         }
-        for (int l = 0; l < kLevels; ++l)
+        for (int l = 0; l < kLevels; ++l) {
             if (bufs[l]) { const hipError_t fe = hipFreeAsync(bufs[l], st); if (e == hipSuccess) e = fe; }
+            if (xbufs[l]) { const hipError_t fe = hipFreeAsync(xbufs[l], st); if (e == hipSuccess) e = fe; }
+        }
     }
 
     // (3) the new state: wait for the side chain only
