@@ -5,10 +5,10 @@
 // host RandomState is numpy's own after the same draw.
 //
 // MT19937 is one sequential recurrence (x[k+624] = x[k+397] ^ twist(x[k], x[k+1])).  The stream is cut into SEGMENTS of
-// kSegBlocks = 256 blocks of 624 words; segment s starts from the state 256 s blocks ahead of the caller's, which is reached by
-// jump-ahead polynomials (ssn_mt19937_poly.h): a ladder of levels with strides 4, 256, 16384, 2^20 blocks, 63 polynomials per
-// level (digit d = 1..63 times the stride), so that any state is at most one jump per level away and all states of a level
-// are computed by ONE launch from the states of the level above.
+// 64 * step blocks of 624 words (step = 1, 2, 4, 8 by the size of the draw); a segment starts from a state so many blocks ahead of
+// the caller's, which is reached by jump-ahead polynomials (ssn_mt19937_poly.h): a ladder of levels with strides 64, 4096, 2^18,
+// 2^24 blocks, 63 polynomials per level (digit d = 1..63 times the stride), so that any segment state is at most one jump per
+// level away and all states of a level are computed by ONE launch from the states of the level above.
 //
 //   mt_expand_kernel one workgroup per parent state: the 20608 words x[] its children's taps can reach, to memory.
 //   mt_jump_kernel   one workgroup per (state, quarter of the polynomial's tap range): its window of the parent's x[] in LDS,
@@ -19,13 +19,14 @@
 //                    a pass depends on no pass nearer than two back), waves 1-3 temper the block before, form randomkit's
 //                    rk_double (a >> 5, b >> 6) -> double, round to fp32 where asked (round to nearest even = numpy's astype)
 //                    and store the [skip, skip + count) window only (the rows of one rank of a data-parallel job).
-//   mt_final_kernel  the state after the whole draw (every rank needs it, whatever rows it generates): a chain of at most
-//                    four single-state jumps + at most four regenerations on a side stream of the library's own; the host
-//                    waits for this chain only, never for the caller's stream.
+//   mt_solo_kernel   the state after the whole draw (every rank needs it, whatever rows it generates): ONE launch on a side
+//                    stream of the library's own, by the exact polynomial of the draw's length (kept per length); the host
+//                    waits for this launch only, never for the caller's stream.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 #include "ssn_host.h"
@@ -34,11 +35,11 @@
 namespace ssn {
 namespace mt {
 
-constexpr int kLevels = 4;                 // strides 4 * 64^l blocks
-constexpr int kStride0Log2 = 2;
+constexpr int kLevels = 4;                 // strides 64 * 64^l blocks
+constexpr int kStride0Log2 = 6;
 constexpr int kRadixLog2 = 6;
-constexpr int kSegLevel = 1;               // segments are the states of level 1
-constexpr int kSegBlocks = 1 << (kStride0Log2 + kRadixLog2 * kSegLevel);   // 256
+constexpr int kSegLevel = 0;               // segments start at states of level 0: every `step`-th one, 64 * step blocks long
+constexpr int kSoloParts = 16;             // workgroups of the kernel that computes the state after the draw
 // a polynomial's taps are cut into kShares index ranges of kShareSpan; one workgroup accumulates one share of one state
 constexpr int kShares = 4;
 constexpr int kShareSpan = 4992;                       // 4 * 4992 = 19968 >= 19937
@@ -54,6 +55,15 @@ struct Key { uint32_t w[kN]; };
 __device__ __forceinline__ uint32_t twist_d(uint32_t u, uint32_t v) {
     const uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
     return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+// the same in six instructions for the generator wave, whose instruction count is the kernel's time (the compiler turns the
+// C form into and / and / or / shift / and / compare / select: ten)
+__device__ __forceinline__ uint32_t twist_xor(uint32_t u, uint32_t v, uint32_t far) {
+    uint32_t y, m;
+    const uint32_t lowmask = 0x7fffffffu;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(y) : "s"(lowmask), "v"(v), "v"(u));     // (mask & v) | (~mask & u)
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m) : "v"(v));                               // bit 0 of v, sign-extended: 0 or ~0
+    return far ^ (y >> 1) ^ (m & 0x9908b0dfu);
 }
 __device__ __forceinline__ uint32_t temper_d(uint32_t y) {
     y ^= y >> 11;
@@ -97,7 +107,8 @@ struct JumpArgs {
     const uint32_t* xseq;       // [..][kXSeq] expanded sequences of the states one level up (or of the root)
     long parent_lo;             // index (in units of the parent level's stride) of xseq[0]
     uint32_t* dst;              // [count][kShares * sub][624]
-    long lo;                    // index (in units of this level's stride) of dst[0]
+    long lo;                    // index (in units of this level's stride) of dst[0]; dst[k] is state lo + k * step
+    int step;
     int sub;                    // workgroups per share (1, 2 or 4: few states -> more workgroups each)
     const uint16_t* codes;      // this level: [63][kShares][kCodeCap] LDS byte offsets of the taps, padded with kZeroOff
     const int* counts;          // [63][kShares], multiples of 128
@@ -118,7 +129,7 @@ struct JumpArgs {
 __global__ __launch_bounds__(320) void mt_jump_kernel(const JumpArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x;
-    const long n = a.lo + (long)blockIdx.x;
+    const long n = a.lo + (long)blockIdx.x * a.step;
     const int f = blockIdx.y / a.sub, sb = blockIdx.y % a.sub;
     const int d = (int)(n & 63);
     const uint32_t* xs = a.xseq + (size_t)((n >> kRadixLog2) - a.parent_lo) * kXSeq;
@@ -154,27 +165,93 @@ __global__ __launch_bounds__(320) void mt_jump_kernel(const JumpArgs a) {
 }
 
 // ---- the state after the draw ----------------------------------------------------------------------------------------
-// One wave: loads the state (XOR of shares) `steps` - 1 blocks before the wanted one, regenerates `steps` >= 1 times (the last
-// regeneration makes every bit of the key numpy's, the low bits of word 0 included), writes the key.
-__global__ __launch_bounds__(64) void mt_final_kernel(const uint32_t* state, int nparts, int steps, uint32_t* out) {
-    __shared__ __align__(16) uint32_t k[kN + 8];
-    const int lane = threadIdx.x;
-    for (int j = lane; j < kN; j += 64) k[j] = xor_parts(state, nparts, j);
-    asm volatile("" ::: "memory");
-    for (int b = 0; b < steps; ++b) {
-        for (int c = 0; c < 6; ++c) {           // in place: a pass reads its own and later OLD words, and new words >= 124 back
-            const bool act = lane < 52;
-            const int i = 104 * c + 2 * (act ? lane : 51);
-            const uint32_t a0 = k[i], a1 = k[i + 1], a2 = k[i + 2 == kN ? 0 : i + 2];
-            int i1 = i + kM; if (i1 >= kN) i1 -= kN;
-            int i2 = i1 + 1; if (i2 == kN) i2 = 0;
-            const uint32_t m0 = k[i1], m1 = k[i2];
-            asm volatile("" ::: "memory");      // (one wave: the LDS unit takes its accesses in program order)
-            if (act) { k[i] = m0 ^ twist_d(a0, a1); k[i + 1] = m1 ^ twist_d(a1, a2); }
-            asm volatile("" ::: "memory");
-        }
+// Every rank needs it, whatever rows it generates, and the HOST waits for it (its next `choice` continues from there): ONE
+// launch on a stream of the library's own.  The jump is by the exact polynomial of this draw's length (t^(624 T) mod phi, T =
+// blocks to the one before the last: computed on the host at the first draw of that length, ~15 ms, and kept), so there is one
+// level and no chain of dependent launches, each of which would queue for a CU beside the caller's kernels.
+// grid (1, kSoloParts): workgroup y = (share, quarter of the share's taps).  It regenerates its own window of the sequence from
+// the caller's key (run-up through a ring of 1248 words, then the window in place), accumulates its taps, writes its partial
+// state; the workgroup that finishes last XORs the partials, regenerates once (every bit of the key becomes numpy's, the low
+// bits of word 0 included) and writes the key to pinned host memory.
+struct SoloArgs {
+    Key root;
+    const uint16_t* codes;      // [kShares][kCodeCap]
+    const int* counts;          // [kShares]
+    uint32_t* partials;         // [kSoloParts][624]
+    unsigned* counter;          // zero between launches
+    uint32_t* out;              // [624], host-visible
+};
+
+__global__ __launch_bounds__(320) void mt_solo_kernel(const SoloArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ uint32_t ring[2 * kN];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    constexpr int sub = kSoloParts / kShares;
+    const int f = blockIdx.y / sub, sb = blockIdx.y % sub;
+    const int base = f * kShareSpan;
+    uint32_t* c0 = (uint32_t*)lds;
+    uint32_t* c1 = (uint32_t*)(lds + kCopy1Off);
+    uint32_t* zz = (uint32_t*)(lds + kZeroOff);
+    for (int j = tid; j < kN; j += 320) ring[j] = a.root.w[j];
+    for (int k = tid; k < 640; k += 320) zz[k] = 0u;
+    __syncthreads();
+    // run-up: x[624 .. ) in the ring (x[k] at k mod 1248) until x[base .. base + 624) is there
+    int k0 = 0;
+    for (; k0 < base; k0 += kN - kM) {
+        const int k = k0 + tid;
+        if (tid < kN - kM)
+            ring[(k + kN) % (2 * kN)] = ring[(k + kM) % (2 * kN)] ^ twist_d(ring[k % (2 * kN)], ring[(k + 1) % (2 * kN)]);
+        __syncthreads();
     }
-    for (int j = lane; j < kN; j += 64) out[j] = k[j];
+    for (int j = tid; j < kN; j += 320) c0[j] = ring[(base + j) % (2 * kN)];
+    __syncthreads();
+    for (int q0 = 0; q0 + kN <= kShareSpan + kN; q0 += kN - kM) {          // the window, in place
+        const int q = q0 + tid;
+        if (tid < kN - kM && q + kN <= kShareSpan + kN) c0[q + kN] = c0[q + kM] ^ twist_d(c0[q], c0[q + 1]);
+        __syncthreads();
+    }
+    for (int k = tid; k < kShareSpan + kN; k += 320) c1[k] = c0[k + 1];
+    __syncthreads();
+    const int groups = a.counts[f] >> 7;
+    const int g0 = groups * sb / sub, g1 = groups * (sb + 1) / sub;
+    const uint32_t* cp = (const uint32_t*)(a.codes + (size_t)f * kCodeCap) + (tid & 63);
+    const int lane8 = (tid < kN / 2 ? tid : kN / 2 - 1) * 8;
+    uint32_t acc0 = 0, acc1 = 0;
+    uint32_t cw = cp[(size_t)g0 * 64];
+    for (int g = g0; g < g1; ++g) {
+        const uint32_t cnext = cp[(size_t)(g + 1) * 64];
+        SSN_MT_TAP8(0) SSN_MT_TAP8(4) SSN_MT_TAP8(8) SSN_MT_TAP8(12) SSN_MT_TAP8(16) SSN_MT_TAP8(20) SSN_MT_TAP8(24) SSN_MT_TAP8(28)
+        SSN_MT_TAP8(32) SSN_MT_TAP8(36) SSN_MT_TAP8(40) SSN_MT_TAP8(44) SSN_MT_TAP8(48) SSN_MT_TAP8(52) SSN_MT_TAP8(56) SSN_MT_TAP8(60)
+        cw = cnext;
+    }
+    uint32_t* mine = a.partials + (size_t)blockIdx.y * kN;
+    if (tid < kN / 2) { mine[2 * tid] = acc0; mine[2 * tid + 1] = acc1; }
+    // the last workgroup to get here finishes the job (nobody waits for anybody)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(a.counter, 1u) == (unsigned)kSoloParts - 1u;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    for (int j = tid; j < kN; j += 320) {
+        uint32_t v = 0;
+        for (int q = 0; q < kSoloParts; ++q) v ^= __builtin_nontemporal_load(a.partials + (size_t)q * kN + j);
+        ring[j] = v;
+    }
+    __syncthreads();
+    // one regeneration, not in place: new block into ring[624 ..)
+    for (int q0 = 0; q0 < kN; q0 += kN - kM) {
+        const int q = q0 + tid;
+        if (tid < kN - kM && q < kN) {
+            const uint32_t nxt = q + 1 < kN ? ring[q + 1] : ring[kN];                 // x[624] = the new word 0
+            const uint32_t far = q + kM < kN ? ring[q + kM] : ring[kN + q + kM - kN];
+            ring[kN + q] = far ^ twist_d(ring[q], nxt);
+        }
+        __syncthreads();
+    }
+    for (int j = tid; j < kN; j += 320) a.out[j] = ring[kN + j];
+    if (tid == 0) *a.counter = 0u;
 }
 
 // ---- generation ------------------------------------------------------------------------------------------------------
@@ -187,13 +264,14 @@ struct GenArgs {
     const uint32_t* states;     // [s_hi - s_lo + 1][nparts][624]
     int nparts;
     long s_lo, s_hi;            // segments to run
+    int seg_blocks;             // blocks per segment
     long b_hi;                  // last block whose words are wanted
     int pos;                    // position in block 0 of stream word 0
     long skip, count;           // doubles [skip, skip + count) of the draw go to out[0 .. count)
     T* out;
 };
 
-constexpr int kBufStride = kN + 8;
+constexpr int kBufStride = kN + 32;        // (words 624.. of a buffer: where the twelve idle lanes of a pass put their stores)
 
 struct GenOperands { uint32_t a0, a1, a2, m0, m1; };
 
@@ -212,9 +290,8 @@ __device__ __forceinline__ GenOperands gen_load(const uint32_t* flat, int oldw, 
 }
 template <int C>
 __device__ __forceinline__ void gen_store(uint32_t* flat, int neww, int l, bool act, const GenOperands& r) {
-    const int i = 104 * C + 2 * l;
-    const uint32_t n0 = r.m0 ^ twist_d(r.a0, r.a1), n1 = r.m1 ^ twist_d(r.a1, r.a2);
-    if (act) { flat[neww + i] = n0; flat[neww + i + 1] = n1; }
+    const uint32_t n0 = twist_xor(r.a0, r.a1, r.m0), n1 = twist_xor(r.a1, r.a2, r.m1);
+    *(uint2*)(flat + neww + (act ? 104 * C + 2 * l : kN + 2 * (l - 52))) = make_uint2(n0, n1);     // (no branch: lanes 52-63 store aside)
     asm volatile("" ::: "memory");
 }
 template <int P>
@@ -224,16 +301,16 @@ __device__ __forceinline__ void gen_block(uint32_t* flat, int lane) {
     const int l = act ? lane : 51;
     GenOperands r0 = gen_load<0>(flat, oldw, neww, l);
     GenOperands r1 = gen_load<1>(flat, oldw, neww, l);
-    gen_store<0>(flat, neww, l, act, r0);
+    gen_store<0>(flat, neww, lane, act, r0);
     r0 = gen_load<2>(flat, oldw, neww, l);
-    gen_store<1>(flat, neww, l, act, r1);
+    gen_store<1>(flat, neww, lane, act, r1);
     r1 = gen_load<3>(flat, oldw, neww, l);
-    gen_store<2>(flat, neww, l, act, r0);
+    gen_store<2>(flat, neww, lane, act, r0);
     r0 = gen_load<4>(flat, oldw, neww, l);
-    gen_store<3>(flat, neww, l, act, r1);
+    gen_store<3>(flat, neww, lane, act, r1);
     r1 = gen_load<5>(flat, oldw, neww, l);         // (pass 5 reads new[0] and new[396]: passes 0 and 3, stored above)
-    gen_store<4>(flat, neww, l, act, r0);
-    gen_store<5>(flat, neww, l, act, r1);
+    gen_store<4>(flat, neww, lane, act, r0);
+    gen_store<5>(flat, neww, lane, act, r1);
 }
 
 template <typename T, bool ODD>
@@ -273,9 +350,9 @@ __global__ __launch_bounds__(256) void mt_gen_kernel(const GenArgs<T> a) {
     __syncthreads();
     if (tid == 0) { vcarry[0] = flat[kN - 1]; vcarry[1] = 0u; }
     __syncthreads();
-    const long b0 = seg * kSegBlocks;               // the block the loaded state holds
+    const long b0 = seg * a.seg_blocks;             // the block the loaded state holds
     long nbl = a.b_hi - b0;
-    if (nbl > kSegBlocks) nbl = kSegBlocks;
+    if (nbl > a.seg_blocks) nbl = a.seg_blocks;
     if (nbl < 0) nbl = 0;
     const int nb = (int)nbl;
     const int first = (seg == 0 && a.pos < kN) ? 0 : 1;     // segment 0 also emits the rest of the caller's current block
@@ -297,6 +374,21 @@ __global__ __launch_bounds__(256) void mt_gen_kernel(const GenArgs<T> a) {
 }
 
 // ---- host: polynomial tables -------------------------------------------------------------------------------------------
+// LDS byte offsets of a polynomial's taps, share by share (even tap: 8 bytes at word `rel` of the share's window; odd: at
+// rel - 1 of the copy shifted by one word); counts padded to groups of 128 with the offset of the zero area
+static void pack_codes(const Poly& p, uint16_t* codes, int* counts) {
+    for (int f = 0; f < kShares; ++f) {
+        uint16_t* cp = codes + (size_t)f * kCodeCap;
+        for (int q = 0; q < kCodeCap; ++q) cp[q] = (uint16_t)kZeroOff;
+        int nt = 0;
+        for (int rel = 0; rel < kShareSpan; ++rel) {
+            const int i = f * kShareSpan + rel;
+            if (i < kDeg && get_bit(p.w, i)) cp[nt++] = (uint16_t)((rel & ~1) * 4 + (rel & 1) * kCopy1Off);
+        }
+        counts[f] = (nt + 127) & ~127;
+    }
+}
+
 struct HostTables {
     std::mutex mu;
     Field field;
@@ -327,16 +419,7 @@ struct HostTables {
             Poly p = base[q];
             for (int d = 1; d <= 63; ++d) {
                 if (d > 1) p = field.mul(p, base[q]);
-                for (int f = 0; f < kShares; ++f) {
-                    uint16_t* cp = codes[q].data() + ((size_t)(d - 1) * kShares + f) * kCodeCap;
-                    int nt = 0;
-                    for (int rel = 0; rel < kShareSpan; ++rel) {
-                        const int i = f * kShareSpan + rel;
-                        if (i < kDeg && get_bit(p.w, i))       // even tap: 8 bytes at word rel of the window; odd: at rel - 1 of the shifted copy
-                            cp[nt++] = (uint16_t)((rel & ~1) * 4 + (rel & 1) * kCopy1Off);
-                    }
-                    counts[q][(d - 1) * kShares + f] = (nt + 127) & ~127;     // (the padding reads zeros)
-                }
+                pack_codes(p, codes[q].data() + (size_t)(d - 1) * kShares * kCodeCap, counts[q].data() + (d - 1) * kShares);
             }
             have[q] = true;
         }
@@ -349,15 +432,45 @@ struct DeviceTables {
     uint16_t* codes[kLevels] = {};
     int* counts[kLevels] = {};
     bool lds_attr = false;
-    // side stream, pinned state buffer and workspace of the chain that computes the state after the draw
+    // side stream, pinned state buffer and workspace of the kernel that computes the state after the draw
     hipStream_t side = nullptr;
     hipEvent_t done = nullptr;
     uint32_t* pinned = nullptr;      // [624]
-    uint32_t* chain = nullptr;       // [kLevels][kShares * 4][624] states + [kXSeq] sequence
-    std::mutex chain_mu;             // the chain's buffers are one set per device: calls on a device take turns in it
+    uint32_t* chain = nullptr;       // [kSoloParts][624] partial states + the arrival counter
+    std::mutex chain_mu;             // one set per device: calls on a device take turns in it
+    // exact polynomials by jump length in blocks (a run draws the same shapes over and over: two lengths per shape)
+    struct Exact { uint16_t* codes; int* counts; };
+    std::map<long, Exact> exact;
 };
 static std::mutex g_dev_mu;
 static DeviceTables* g_dev[64] = {};
+
+// the device copy of t^(624 nblocks) mod phi (caller holds t->chain_mu)
+static hipError_t exact_poly(DeviceTables* t, long nblocks, DeviceTables::Exact* out) {
+    auto it = t->exact.find(nblocks);
+    if (it != t->exact.end()) { *out = it->second; return hipSuccess; }
+    if (t->exact.size() >= 256) {          // (a run that keeps changing its draw length: start over rather than grow for ever)
+        for (auto& kv : t->exact) { (void)hipFree(kv.second.codes); (void)hipFree(kv.second.counts); }
+        t->exact.clear();
+    }
+    std::vector<uint16_t> codes((size_t)kShares * kCodeCap);
+    int counts[kShares];
+    {
+        HostTables& h = host_tables();
+        std::lock_guard<std::mutex> g(h.mu);
+        if (!h.ensure_field()) return hipErrorUnknown;
+        pack_codes(h.field.block_jump((unsigned long long)nblocks), codes.data(), counts);
+    }
+    DeviceTables::Exact x{};
+    hipError_t e;
+    if ((e = hipMalloc((void**)&x.codes, codes.size() * sizeof(uint16_t))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&x.counts, sizeof counts)) != hipSuccess) return e;
+    if ((e = hipMemcpy(x.codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMemcpy(x.counts, counts, sizeof counts, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    t->exact[nblocks] = x;
+    *out = x;
+    return hipSuccess;
+}
 
 static hipError_t device_tables(int need_level, DeviceTables** out) {
     int dev = 0;
@@ -379,11 +492,12 @@ static hipError_t device_tables(int need_level, DeviceTables** out) {
         if ((e = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, hi)) != hipSuccess) return e;
         if ((e = hipEventCreateWithFlags(&t->done, hipEventDisableTiming)) != hipSuccess) return e;
         if ((e = hipHostMalloc((void**)&t->pinned, sizeof(uint32_t) * kN, hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipMalloc((void**)&t->chain, sizeof(uint32_t) * ((size_t)kLevels * kShares * 4 * kN + kXSeq))) != hipSuccess) return e;
+        if ((e = hipMalloc((void**)&t->chain, sizeof(uint32_t) * ((size_t)kSoloParts * kN + 16))) != hipSuccess) return e;
+        if ((e = hipMemset(t->chain, 0, sizeof(uint32_t) * ((size_t)kSoloParts * kN + 16))) != hipSuccess) return e;
     }
     HostTables& h = host_tables();
     std::lock_guard<std::mutex> gh(h.mu);
-    if (!h.ensure_level(need_level)) return hipErrorUnknown;
+    if (need_level >= 0 && !h.ensure_level(need_level)) return hipErrorUnknown;
     for (int l = 0; l <= need_level; ++l) {
         if (t->codes[l]) continue;
         uint16_t* dc = nullptr; int* dn = nullptr;
@@ -425,19 +539,28 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
     const long p_end = (long)pos + 2 * (long)total;              // position of the first unconsumed word, from block 0
     const long b_f = p_end <= kN ? 0 : (p_end - 1) / kN;         // block of the state after the draw
     long b_hi = 0, s_lo = 0, s_hi = 0;
+    int step = 1;
     if (count) {
         const long b_lo = ((long)pos + 2 * (long)skip) / kN;
         b_hi = ((long)pos + 2 * (long)(skip + count) - 1) / kN;
-        s_lo = b_lo >= 1 ? (b_lo - 1) / kSegBlocks : 0;
-        s_hi = b_hi >= 1 ? (b_hi - 1) / kSegBlocks : 0;
+        // segment length 64 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
+        // workgroups per state, 768 at a time, ~70 us a round; a segment's workgroup generates a block in ~0.5 us
+        double best = 1e30;
+        for (int c = 1; c <= 8; c *= 2) {
+            const long nseg = (b_hi - b_lo + 64 * c) / (64 * c);
+            const double cost = 70.0 * (double)((4 * nseg + 767) / 768) + 0.5 * 64 * c;
+            if (cost < best) { best = cost; step = c; }
+        }
+        const long seg_blocks = (long)step << kStride0Log2;
+        s_lo = b_lo >= 1 ? (b_lo - 1) / seg_blocks : 0;
+        s_hi = b_hi >= 1 ? (b_hi - 1) / seg_blocks : 0;
     }
-    // levels needed: the top digit of the last block / segment must be < 64
-    int top_e = 0, top_b = kSegLevel;
-    const long tgt = b_f >= 1 ? b_f - 1 : 0;                    // the chain reaches block b_f - 1, then regenerates once
-    while ((tgt >> level_shift(top_e)) >= 64) if (++top_e >= kLevels) return hipErrorInvalidValue;
-    while ((s_hi >> (level_shift(top_b) - level_shift(kSegLevel))) >= 64) if (++top_b >= kLevels) return hipErrorInvalidValue;
+    // levels needed: the top digit of the last segment must be < 64
+    int top_b = count ? kSegLevel : -1;
+    if (count)
+        while (((s_hi * step) >> (level_shift(top_b) - level_shift(kSegLevel))) >= 64) if (++top_b >= kLevels) return hipErrorInvalidValue;
     DeviceTables* t = nullptr;
-    hipError_t e = device_tables(top_e > top_b ? top_e : top_b, &t);
+    hipError_t e = device_tables(top_b, &t);
     if (e != hipSuccess) return e;
 
     ExpandArgs xa;
@@ -445,25 +568,17 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
     const size_t xlds = kXSeq * sizeof(uint32_t);
     JumpArgs ja;
 
-    // (1) the state after the draw, on the side stream: one state per level, top down, then at most four regenerations
+    // (1) the state after the draw, on the side stream: block b_f - 1 by the exact polynomial, then one regeneration
     std::unique_lock<std::mutex> chain_lock(t->chain_mu, std::defer_lock);
     if (b_f >= 1) {
         chain_lock.lock();
-        uint32_t* xseq = t->chain + (size_t)kLevels * kShares * 4 * kN;
-        const uint32_t* parent = nullptr;
-        constexpr int kChainSub = 4;
-        for (int l = top_e; l >= 0; --l) {
-            const long idx = tgt >> level_shift(l);
-            xa.states = parent; xa.nparts = kShares * kChainSub; xa.xseq = xseq;
-            hipLaunchKernelGGL(mt_expand_kernel, dim3(1), dim3(256), xlds, t->side, xa);
-            ja.xseq = xseq; ja.parent_lo = idx >> kRadixLog2;
-            ja.dst = t->chain + (size_t)l * kShares * kChainSub * kN; ja.lo = idx; ja.sub = kChainSub;
-            ja.codes = t->codes[l]; ja.counts = t->counts[l];
-            hipLaunchKernelGGL(mt_jump_kernel, dim3(1, kShares * kChainSub), dim3(320), kJumpLds, t->side, ja);
-            parent = ja.dst;
-        }
-        const int steps = (int)(tgt & ((1 << kStride0Log2) - 1)) + 1;
-        hipLaunchKernelGGL(mt_final_kernel, dim3(1), dim3(64), 0, t->side, parent, kShares * kChainSub, steps, t->pinned);
+        DeviceTables::Exact ex{};
+        if ((e = exact_poly(t, b_f - 1, &ex)) != hipSuccess) return e;
+        SoloArgs sa;
+        std::memcpy(sa.root.w, key, sizeof sa.root.w);
+        sa.codes = ex.codes; sa.counts = ex.counts;
+        sa.partials = t->chain; sa.counter = (unsigned*)(t->chain + (size_t)kSoloParts * kN); sa.out = t->pinned;
+        hipLaunchKernelGGL(mt_solo_kernel, dim3(1, kSoloParts), dim3(320), kJumpLds, t->side, sa);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if ((e = hipEventRecord(t->done, t->side)) != hipSuccess) return e;
     }
@@ -475,14 +590,16 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
         uint32_t* xbufs[kLevels] = {};
         for (int l = top_b; l >= kSegLevel; --l) {
             const int sh = level_shift(l) - level_shift(kSegLevel);
-            const long lo = s_lo >> sh, hi = s_hi >> sh, cnt = hi - lo + 1;
+            // level 0: the segment starts (every step-th state); above: every state between the first and the last one's ancestors
+            const int lstep = l == kSegLevel ? step : 1;
+            const long lo = (s_lo * step) >> sh, hi = (s_hi * step) >> sh, cnt = (hi - lo) / lstep + 1;
             if ((e = hipMallocAsync((void**)&xbufs[l], sizeof(uint32_t) * (size_t)parent_cnt * kXSeq, st)) != hipSuccess) break;
             const int sub = sub_for(cnt);
             if ((e = hipMallocAsync((void**)&bufs[l], sizeof(uint32_t) * (size_t)cnt * kShares * sub * kN, st)) != hipSuccess) break;
             xa.states = parent; xa.nparts = parent_parts; xa.xseq = xbufs[l];
             hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)parent_cnt), dim3(256), xlds, st, xa);
             ja.xseq = xbufs[l]; ja.parent_lo = lo >> kRadixLog2;
-            ja.dst = bufs[l]; ja.lo = lo; ja.sub = sub;
+            ja.dst = bufs[l]; ja.lo = lo; ja.step = lstep; ja.sub = sub;
             ja.codes = t->codes[l]; ja.counts = t->counts[l];
             hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt, kShares * sub), dim3(320), kJumpLds, st, ja);
             parent = bufs[l]; parent_cnt = cnt; parent_parts = kShares * sub;
@@ -491,11 +608,11 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
             const unsigned nseg = (unsigned)(s_hi - s_lo + 1);
             const bool odd = pos & 1;
             if (elem == 4) {
-                GenArgs<float> ga{parent, parent_parts, s_lo, s_hi, b_hi, pos, (long)skip, (long)count, (float*)out};
+                GenArgs<float> ga{parent, parent_parts, s_lo, s_hi, step << kStride0Log2, b_hi, pos, (long)skip, (long)count, (float*)out};
                 if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true>), dim3(nseg), dim3(256), 0, st, ga);
                 else hipLaunchKernelGGL((mt_gen_kernel<float, false>), dim3(nseg), dim3(256), 0, st, ga);
             } else {
-                GenArgs<double> ga{parent, parent_parts, s_lo, s_hi, b_hi, pos, (long)skip, (long)count, (double*)out};
+                GenArgs<double> ga{parent, parent_parts, s_lo, s_hi, step << kStride0Log2, b_hi, pos, (long)skip, (long)count, (double*)out};
                 if (odd) hipLaunchKernelGGL((mt_gen_kernel<double, true>), dim3(nseg), dim3(256), 0, st, ga);
                 else hipLaunchKernelGGL((mt_gen_kernel<double, false>), dim3(nseg), dim3(256), 0, st, ga);
             }

@@ -45,8 +45,8 @@ def test_small_draws_bit_equal_numpy(seed, warm, shape):
 
 @pytest.mark.parametrize('warm', [0, 777])
 def test_segment_and_level_boundaries(warm):
-    # 256 blocks of 312 doubles per segment; 64 segments per level-2 stride: cross both
-    for n in (256 * 312 - 1, 256 * 312, 256 * 312 + 1, 3 * 256 * 312 + 17, 65 * 256 * 312 + 5):
+    # 64 * step blocks of 312 doubles per segment (step 1, 2, 4 by size); 64 states per stride of the level above: cross them
+    for n in (64 * 312 - 1, 64 * 312, 64 * 312 + 1, 3 * 64 * 312 + 17, 65 * 64 * 312 + 5, 256 * 312 + 1, 65 * 256 * 312 + 5, 2 * 64 * 64 * 312 + 77):
         _check(5, warm, (n,), torch.float64)
 
 
