@@ -109,7 +109,10 @@ def cpu_baseline(N, NB, T, sample_B, threads):
     units = float(M) * sample_B * NB * T
     n1 = max(2, min(sample_B, 16))                      # the same call pattern on ONE thread, a few draws
     best1 = time_threaded_solves(fn, Ws[:n1], exts, N, T, 1)
-    return dict(value=units / best, unit='neuron*batch*Euler-steps/s', cores=threads, kind=kind,
+    # the box the baseline ran on: every core this process may use is used (the reference sizes its pool by cpu_count(),
+    # ssnode.py:436, utils/systems.py:5-37); `cores` = threads = affinity_cores
+    return dict(value=units / best, unit='neuron*batch*Euler-steps/s', cores=threads, threads=threads,
+                affinity_cores=len(os.sched_getaffinity(0)), host_cpu_count=os.cpu_count(), kind=kind,
                 value_1thread=float(M) * n1 * NB * T / best1,
                 sample='%d of the workload\'s weight draws x %d stimuli x %d steps, 2N=%d, fp64, '
                        '%d Python threads over ctypes (best of 2 after warm-up, %.2f s)' %
@@ -428,7 +431,7 @@ def run_c5(args, rank, world, local_rank):
 
 def run_c1_dropin(args):
     """BASELINE config 1 through the boundary a maintainer gets by copying libssnode.so into tc_gan/ext/:
-    `find_fixed_points_parallel`'s pattern (ssnode.py:423-510) -- a pool of 16 Python threads, one task per
+    `find_fixed_points_parallel`'s pattern (ssnode.py:423-510) -- a pool of one Python thread per usable core, one task per
     weight draw, one `solve_dynamics_asym_tanh_euler` call per (draw, stimulus), host fp64 buffers -- timed on the
     GPU library and, beside it, on the reference's own C build.  PCIe, launch and synchronisation are all inside
     the timed region (this is the host-buffer entry point); `roofline` is null: a one-workgroup fp64 solve per
@@ -437,7 +440,7 @@ def run_c1_dropin(args):
     from tc_gan_amd.clib import libssnode
     N, B, NB, T, desc = WORKLOADS['c1']
     M = 2 * N
-    threads = min(len(os.sched_getaffinity(0)), 16)
+    threads = len(os.sched_getaffinity(0))               # every core this process may use, as the reference's cpu_count() pool
     fn = _bind_solve(libssnode.solve_dynamics_asym_tanh_euler)
     sample = args.cpu_sample or B * max(args.steps, 1)
     J, D, S = new_jds()
@@ -506,7 +509,7 @@ def main():
                     help='c3: critic GEMM operand precision (BASELINE config 3 names bf16 MFMA)')
     ap.add_argument('--via', default='batched', choices=['batched', 'dropin'],
                     help="c1 only: 'dropin' times the reference's call pattern (one solve_dynamics_* call per "
-                         "(draw, stimulus) from a 16-thread pool) through the zero-change drop-in symbols")
+                         "(draw, stimulus) from a pool of one thread per usable core) through the zero-change drop-in symbols")
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -755,7 +758,7 @@ def run_solver(args, rank, world, local_rank):
         out['dtype'] = 'f32 (W.r on fp16 matrix cores as an exact-product split of 23-bit operands)'
     out['world_size'] = world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = min(len(os.sched_getaffinity(0)), 16)           # the 1-GPU box's CPU share
+        threads = len(os.sched_getaffinity(0))                    # every core this process may use (no cap)
         # ~10-20 s of host work at C2: the whole batch (4096 draws, ~5 s per pass on 16 threads), warm-up + best of 2
         sample = args.cpu_sample or (64 if args.workload == 'c1' else min(B, max(threads * 8, 4096 // NB)))
         out['cpu_baseline'] = cpu_baseline(N, NB, T, sample, threads)

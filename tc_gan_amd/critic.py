@@ -176,8 +176,23 @@ class Critic(object):
             return t
         return torch.as_tensor(t).to('cuda', torch.float32).contiguous()
 
+    def _checked(self, *pairs):
+        """(x, cond) pairs as device tensors; refuses a condition the critic was not built for (the library reads a NULL
+        `cond` as "no condition columns": on a conditional critic it would then read nx + 3 columns from rows of nx)."""
+        out = []
+        for x, cond in pairs:
+            x, cond = self._f32(x), self._f32(cond)
+            if (cond is _NoCond) != (not self.conditional):
+                raise ValueError('this critic is {}conditional: cond must {}be given'.format(
+                    '' if self.conditional else 'un', '' if self.conditional else 'not '))
+            if x.dim() != 2 or x.shape[1] != self.nx or (self.conditional and tuple(cond.shape) != (x.shape[0], 3)):
+                raise ValueError('critic input of shape {} / cond {}: expected (batch, {}) / (batch, 3)'.format(
+                    tuple(x.shape), None if cond is _NoCond else tuple(cond.shape), self.nx))
+            out += [x, cond]
+        return out
+
     def forward(self, x, cond):
-        x, cond = self._f32(x), self._f32(cond)
+        x, cond = self._checked((x, cond))
         batch = x.shape[0]
         out = torch.empty(batch, device=self.device, dtype=torch.float32)
         ws = self._workspace(batch, 0)
@@ -198,7 +213,7 @@ class Critic(object):
 
     def loss_grad(self, xg, cg, xd, cd, xp, cp, lmd):
         """Fills ``self.grads`` and ``self.stats`` = [mean D(xg), mean D(xd), penalty, loss] (device)."""
-        xg, cg, xd, cd, xp, cp = (self._f32(t) for t in (xg, cg, xd, cd, xp, cp))
+        xg, cg, xd, cd, xp, cp = self._checked((xg, cg), (xd, cd), (xp, cp))
         ng, nd, npn = xg.shape[0], xd.shape[0], xp.shape[0]
         ws = self._workspace(ng + nd, npn)
         self._dvals = torch.empty(ng + nd, device=self.device, dtype=torch.float32)
@@ -234,7 +249,7 @@ class Critic(object):
 
     def input_grad(self, x, cond, scale):
         """gx = scale * dD/dx summed over nothing (per sample), stats[0] = mean D(x)."""
-        x, cond = self._f32(x), self._f32(cond)
+        x, cond = self._checked((x, cond))
         batch = x.shape[0]
         gx = torch.empty((batch, self.nx), device=self.device, dtype=torch.float32)
         ws = self._workspace(batch, batch)
@@ -260,7 +275,7 @@ class Critic(object):
         """mean D(xg) - mean D(xd) (cwgan.py:139-147) as a 1-element device tensor (`out`, when given), no host wait:
         ONE library call (`ssn_critic_accuracy`: two forwards -- every output row depends on its own input row only, and
         stacking the rows would cost two more launches -- and one reduction in a fixed order)."""
-        xg, cg, xd, cd = (self._f32(t) for t in (xg, cg, xd, cd))
+        xg, cg, xd, cd = self._checked((xg, cg), (xd, cd))
         ng, nd = xg.shape[0], xd.shape[0]
         ws = self._workspace(max(ng, nd), 0)
         if out is None:

@@ -631,7 +631,7 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
 struct CriticFork {
     hipStream_t aux, gs;               // penalty half; weight-gradient GEMMs and bias column sums of both halves
     hipEvent_t fork, join, join_g;
-    hipEvent_t ready[24]; int nready;  // "operands of the next gradient GEMM are there", one per hand-over, reused every call
+    hipEvent_t ready[24]; unsigned nready;  // "operands of the next gradient GEMM are there", one per hand-over, reused every call
     // the gradient stream takes its next launch behind everything `from` holds so far
     hipError_t hand_over(hipStream_t from) {
         hipEvent_t ev = ready[nready++ % 24];
@@ -695,8 +695,24 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     CriticFork* const fk = par ? critic_fork() : nullptr;
     hipStream_t sp = st;                            // stream of the penalty half
     const hipStream_t sg = critic_grad_stream(fk, st);   // stream of the weight-gradient GEMMs and bias sums
+    // Once the side streams carry work, EVERY way out of this function joins them to st first: an error return that left
+    // them running would hand the caller back a workspace that is still being read and written.
+    struct JoinScope {
+        CriticFork* fk; hipStream_t st; bool forked = false, joined = false;
+        hipError_t join() {
+            if (!fk || !forked || joined) return hipSuccess;
+            joined = true;
+            hipError_t e = hipEventRecord(fk->join, fk->aux), e2;
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, fk->join, 0);
+            e2 = hipEventRecord(fk->join_g, fk->gs);
+            if (e2 == hipSuccess) e2 = hipStreamWaitEvent(st, fk->join_g, 0);
+            return e != hipSuccess ? e : e2;
+        }
+        ~JoinScope() { (void)join(); }
+    } join_scope{fk, st};
     if (fk) {
         if ((e = hipEventRecord(fk->fork, st)) != hipSuccess) return e;          // behind the memset and everything the caller queued
+        join_scope.forked = true;
         if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
         sp = fk->aux;
     }
@@ -754,10 +770,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     hipLaunchKernelGGL(colsum_kernel, dim3((dims[L] + 63) / 64), dim3(1024), 0, sp, ep[L], tmp, np, dims[L], 0.f);
     if (fk) {                                       // join: the sums below and the slab reduction see both halves
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipEventRecord(fk->join, fk->aux)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(st, fk->join, 0)) != hipSuccess) return e;
-        if ((e = hipEventRecord(fk->join_g, fk->gs)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(st, fk->join_g, 0)) != hipSuccess) return e;
+        if ((e = join_scope.join()) != hipSuccess) return e;
     }
     hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(dims[L])), dim3(256), 0, st, grads + (net.nparams - dims[L]), tmp, lmd, (long)dims[L]);
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, st, stats, lmd);
@@ -852,8 +865,12 @@ __global__ void __launch_bounds__(256) optimizer_kernel(OptArgs o) {
         }
         // decoupled decay on the OLD value (wgan.py:158-163, apply_l2_decay / apply_l1_decay)
         pn -= o.lr * o.l2_decay * p0 + o.lr * o.l1_decay * ((p0 > 0.f) - (p0 < 0.f));
-        if (o.clip_lo_v) pn = fminf(fmaxf(pn, o.clip_lo_v[e]), o.clip_hi_v[e]);      // (bounds per element: the reference's numpy clip broadcasts)
-        else if (o.clip) pn = fminf(fmaxf(pn, o.clip_lo), o.clip_hi);       // wgan.py:244-251
+        // wgan.py:244-251.  A NaN update stays NaN, as it does in Theano's clip (a switch on comparisons): fmaxf(NaN, lo) would
+        // hand back the lower bound and hide a poisoned gradient from the drivers' NaN guards
+        if (pn == pn) {
+            if (o.clip_lo_v) pn = fminf(fmaxf(pn, o.clip_lo_v[e]), o.clip_hi_v[e]);      // (bounds per element: the reference's numpy clip broadcasts)
+            else if (o.clip) pn = fminf(fmaxf(pn, o.clip_lo), o.clip_hi);
+        }
         o.p[e] = pn;
         if (o.record) {
             o.record[e] = pn;

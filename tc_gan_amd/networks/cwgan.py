@@ -438,9 +438,10 @@ class ConditionalBPTTWassersteinGAN(object):
                 self.disc_updater.restore(self.disc.params, ctx.snapshot)        # the skipped step of cwgan.py:493-498
             ctx.skipped = True
             host = np.array([host[0], host[1], np.nan, np.nan], dtype='float32')
-            self.disc.cache_param_nnorms(None)
+            info.param_sqnorms = None
         else:
-            self.disc.cache_param_nnorms(host[4:])
+            info.param_sqnorms = host[4:].copy()     # of the critic as THIS step left it; handed to the recorder when the record is
+        self.disc.cache_param_nnorms(info.param_sqnorms)
         ctx.snapshot = None
         info.gen_out = ctx.gen_out
         info.xd, info.xg, info.xp = ctx.xd, ctx.xg, ctx.xp
@@ -658,6 +659,8 @@ class ConditionalBPTTWassersteinGAN(object):
             if held is not None:
                 if held.accuracy_pending:
                     held.accuracy, held.accuracy_pending = ctx.arrived_accuracy, False
+                # (a held record is yielded after the NEXT step was read: the recorder must see its own norms, not that step's)
+                self.disc.cache_param_nnorms(held.param_sqnorms)
                 yield held
                 held = None
             if info.accuracy_pending:
@@ -665,6 +668,7 @@ class ConditionalBPTTWassersteinGAN(object):
             else:
                 if ctx.acc_deferred:
                     self._acc_carry = None      # (a skipped step has no accuracy: nothing to carry)
+                self.disc.cache_param_nnorms(info.param_sqnorms)
                 yield info
             ctx = nxt
         disc_info = info
@@ -677,6 +681,7 @@ class ConditionalBPTTWassersteinGAN(object):
                      disc_info.accuracy, disc_info.disc_loss, info.gen_loss, self.gen_forward_watch.mean(),
                      self.disc_train_watch.mean(), self.gen_train_watch.mean())
         if held is not None:
+            self.disc.cache_param_nnorms(held.param_sqnorms)
             yield held
         yield info
 

@@ -33,7 +33,7 @@ def _train(n_gen_steps=2, z_device_seed=None):
     data = np.random.RandomState(4).rand(9, 4 * 2 * 2 * 2) * 10
     gan.set_dataset(data)
     it = gan.learning()
-    losses, accs, order = [], [], []
+    losses, accs, order, norms = [], [], [], []
     done = 0
     while done < n_gen_steps:
         info = next(it)
@@ -41,12 +41,16 @@ def _train(n_gen_steps=2, z_device_seed=None):
             losses.append(info.disc_loss)
             accs.append(info.accuracy)
             order.append((info.gen_step, info.disc_step))
+            # what DiscParamStatsRecorder.record writes for this record (disc_param_stats): the norms of the critic as THIS step
+            # left it, from the one-shot cache the loop fills -- and, beside them, the norms read back from the parameters now
+            norms.append(gan.disc.param_nnorms())
         else:
             losses.append(info.gen_loss)
             order.append((info.gen_step, -1))
             done += 1
     # [collectives issued, records in the reference's order?] then the accuracies of the critic steps
     extra = np.array([gan.reducer.calls, float(order == sorted(order, key=lambda t: (t[0], t[1] < 0, t[1])))] + accs)
+    _train.norms = np.asarray(norms, dtype='float64')
     return np.concatenate([np.ravel(p) for p in gan.get_gen_param()]), gan.disc.get_flat(), np.array(losses), extra
 
 
@@ -119,6 +123,8 @@ def _worker(rank, world, port, out, what='gan'):
     res = {'gan': _train, 'gan_devnoise': lambda: _train(z_device_seed=31), 'moments': _train_moments,
            'find': _find_fixed_points, 'wgan': _train_unconditional,
            'wgan_fused': lambda: _train_unconditional(gen_kernel='duo-fused')}[what]()
+    if what == 'gan':
+        res = res + (_train.norms,)
     out.put((rank,) + res)
     dist.barrier()
     dist.destroy_process_group()
@@ -151,6 +157,12 @@ def test_two_ranks_follow_the_single_process_run():
         assert res[r][4][0] == 6 and res[r][4][1] == 1
         np.testing.assert_allclose(res[r][4][2:], extra1[2:], atol=1e-6)
     np.testing.assert_array_equal(res[0][4], res[1][4])
+    # disc_param_stats: every critic record carries the norms of the critic as ITS step left it (the records of a
+    # data-parallel run are handed over one collective late and used to pick up the next step's norms)
+    norms1 = _train.norms
+    assert norms1.shape[0] == 4 and np.abs(np.diff(norms1, axis=0)).max() > 1e-4 * np.abs(norms1).max()   # (steps differ: a shift would show)
+    for r in range(2):
+        np.testing.assert_allclose(res[r][5], norms1, rtol=1e-3)
 
 
 def test_two_ranks_with_device_noise_follow_the_single_process_run():

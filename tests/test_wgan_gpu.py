@@ -102,9 +102,20 @@ def test_unconditional_critic_vs_fp64_autograd(layers, norm):
     np.testing.assert_allclose(acc, float(og.critic_forward(ps, og.t64(xg), None, **kw).mean()
                                           - og.critic_forward(ps, og.t64(xd), None, **kw).mean()), rtol=1e-4, atol=1e-5)
     # conditions for some inputs of a call and not for others are refused, not guessed
-    from tc_gan_amd import clib
-    with pytest.raises(clib.SSNLibraryError):
+    # (the Python layer refuses first -- ADVICE r4: a condition the critic was not built for never reaches the library, which
+    # reads a NULL `cond` as "no condition columns" and would mis-stride x)
+    with pytest.raises(ValueError):
         disc.loss_grad(xg, np.zeros((n, 3)), xd, None, xp, None, 10.0)
+    with pytest.raises(ValueError):
+        disc.forward(xg, np.zeros((n, 3)))
+    with pytest.raises(ValueError):
+        disc.input_grad(xg[:, :-1], None, 1.0)
+    from tc_gan_amd.critic import Critic
+    cdisc = Critic(nx=nx, layers=[8], conditional=True)
+    for call in (lambda: cdisc.forward(xg, None), lambda: cdisc.input_grad(xg, None, 1.0), lambda: cdisc.accuracy_device(xg, None, xd, None),
+                 lambda: cdisc.loss_grad(xg, None, xd, None, xp, None, 10.0)):
+        with pytest.raises(ValueError):
+            call()
 
 
 def test_one_critic_and_generator_update_vs_oracle():
