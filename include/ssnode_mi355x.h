@@ -368,6 +368,29 @@ int ssn_critic_input_grad_norm(const float *params, const int *dims, const int *
                                const float *x, const float *cond, int batch, int hide_cell_type, float scale,
                                float *gx, float *stats, float *workspace, int precision, void *stream);
 
+/* The same passes for the critic in its general form (simple_discriminator.py:57-75, 139-152; `--disc-nonlinearity`,
+ * run/bptt_wgan.py:153): hidden nonlinearity act = 0 rectify, 1 leaky_rectify (0.01), 2 very_leaky_rectify (1/3), 3 linear,
+ * 4 tanh, 5 sigmoid, 6 softplus, 7 elu (lasagne.nonlinearities); layer_flags: HOST int[L] or NULL, per hidden layer 0 = plain
+ * Dense + bias, 1 = Dense(no bias) -> LayerNorm -> Bias, 3 = Dense(no bias) -> LayerNorm -> ScaleLayer -> Bias (the reference
+ * inserts the learnable per-unit scale for every nonlinearity but rectify).  Parameter layout per layer: W [in][out],
+ * scales [out] (flag 3 only), b [out]; then w_out -- lasagne's get_all_params order.  The gradient penalty's double backward
+ * carries the curvature f'' of the smooth nonlinearities and the scales' gradients.  Workspace: ssn_critic_norm_workspace_floats. */
+long ssn_critic_num_params_act(const int *dims, const int *layer_flags, int nlayers);
+int ssn_critic_forward_act(const float *params, const int *dims, const int *layer_flags, int nlayers, int act,
+                           const float *x, const float *cond, int batch, int hide_cell_type, float *out,
+                           float *workspace, int precision, void *stream);
+int ssn_critic_loss_grad_act(const float *params, const int *dims, const int *layer_flags, int nlayers, int act,
+                             const float *xg, const float *cg, const float *xd, const float *cd,
+                             const float *xp, const float *cp, int ng, int nd, int np, float lmd,
+                             int hide_cell_type, float *grads, float *stats, float *dvals,
+                             float *workspace, int precision, void *stream);
+int ssn_critic_input_grad_act(const float *params, const int *dims, const int *layer_flags, int nlayers, int act,
+                              const float *x, const float *cond, int batch, int hide_cell_type, float scale,
+                              float *gx, float *stats, float *workspace, int precision, void *stream);
+int ssn_critic_accuracy_act(const float *params, const int *dims, const int *layer_flags, int nlayers, int act,
+                            const float *xg, const float *cg, const float *xd, const float *cd, int ng, int nd,
+                            int hide_cell_type, float *acc, float *dvals, float *workspace, int precision, void *stream);
+
 typedef struct ssn_opt_params {
     int kind;                 /* 0 sgd, 1 adam, 2 rmsprop (lasagne.updates) */
     int step;                 /* 1-based update count (adam bias correction) */

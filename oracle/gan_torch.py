@@ -124,30 +124,55 @@ def layer_norm(x, eps=1e-4):
     return (x - mean) / torch.sqrt(var + eps)
 
 
-def critic_forward(params, x, cond, normalization='none', nonlinearity='rectify'):
+ACTIVATIONS = {     # lasagne.nonlinearities by name (leaky_rectify = LeakyRectify(0.01), very_leaky_rectify = LeakyRectify(1 / 3))
+    'rectify': torch.relu, 'tanh': torch.tanh, 'linear': lambda t: t, 'identity': lambda t: t,
+    'leaky_rectify': lambda t: torch.nn.functional.leaky_relu(t, 0.01),
+    'very_leaky_rectify': lambda t: torch.nn.functional.leaky_relu(t, 1.0 / 3.0),
+    'sigmoid': torch.sigmoid,
+    'softplus': torch.nn.functional.softplus,                # theano.tensor.nnet.softplus: log1p(exp(x))
+    'elu': torch.nn.functional.elu,                          # switch(x > 0, x, expm1(x))
+}
+
+
+def critic_layer_scales(normalization, nonlinearity, nlayers, use_scale='auto'):
+    """simple_discriminator.py:57-75: a layer-normalised layer has a ScaleLayer iff `use_scale` (auto: every nonlinearity but
+    rectify).  Returns one bool per hidden layer."""
+    norms = normalization if isinstance(normalization, (list, tuple)) else [normalization] * nlayers
+    auto = nonlinearity != 'rectify'
+    return [n == 'layer' and (auto if use_scale == 'auto' else bool(use_scale)) for n in norms]
+
+
+def critic_forward(params, x, cond, normalization='none', nonlinearity='rectify', use_scale='auto'):
     """cwgan.py:123-175 + simple_discriminator.py:51-75, 139-165.
 
-    params: list of tensors.  'none': [W1, b1, ..., WL, bL, Wout];
-    'layer': [W1, b1, ...] with Dense(no bias) -> LayerNorm -> Bias -> nonlinearity.
+    params: list of tensors in lasagne's get_all_params order.  'none' layer: W, b;  'layer': W, [scales,] b with
+    Dense(no bias) -> LayerNorm -> [ScaleLayer] -> Bias -> nonlinearity; last: Wout.
     Input = concat(x, [contrast, |norm_probe|, cell_type]) (cwgan.py:164-170)."""
     if cond is None:           # UnConditionalDiscriminator (wgan.py:66-97): the tuning curve alone
         h = x
     else:
         c = torch.stack([cond[:, 0], cond[:, 1].abs(), cond[:, 2]], dim=1)
         h = torch.cat([x, c], dim=1)
-    nl = len(params) // 2
+    act = ACTIVATIONS[nonlinearity]
+    # number of hidden layers from the parameter count: 2 per layer + 1 per scaled layer + the output W
+    nl = 0
+    while True:
+        scales = critic_layer_scales(normalization if not isinstance(normalization, (list, tuple)) else list(normalization)[:nl],
+                                     nonlinearity, nl, use_scale)
+        if 2 * nl + sum(scales) + 1 == len(params):
+            break
+        nl += 1
+        assert nl < 64, 'parameter list does not match the layer description'
     norms = normalization if isinstance(normalization, (list, tuple)) else [normalization] * nl
-    # (lasagne.nonlinearities: leaky_rectify = LeakyRectify(0.01), very_leaky_rectify = LeakyRectify(1 / 3))
-    act = {'rectify': torch.relu, 'tanh': torch.tanh, 'linear': lambda t: t, 'identity': lambda t: t,
-           'leaky_rectify': lambda t: torch.nn.functional.leaky_relu(t, 0.01),
-           'very_leaky_rectify': lambda t: torch.nn.functional.leaky_relu(t, 1.0 / 3.0)}[nonlinearity]
+    it = iter(params)
     for l in range(nl):
-        Wl, bl = params[2 * l], params[2 * l + 1]
-        pre = h @ Wl
+        pre = h @ next(it)
         if norms[l] == 'layer':
             pre = layer_norm(pre)
-        h = act(pre + bl)
-    return h @ params[-1]          # (batch, 1), linear, no bias
+            if scales[l]:
+                pre = pre * next(it)
+        h = act(pre + next(it))
+    return h @ next(it)          # (batch, 1), linear, no bias
 
 
 def critic_loss(params, xg, xd, xp, cg, cd, cp, lmd, **kw):

@@ -348,7 +348,22 @@ DECLARED_SYMBOLS = (
     'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_critic_step_gated_run', 'ssn_gen_grads_ws_doubles', 'ssn_gen_grads_f32', 'ssn_gen_apply_f32',
     'ssn_gen_inputs_philox_f32',
     'ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64', 'ssn_mt19937_jump_poly',
+    'ssn_critic_num_params_act', 'ssn_critic_forward_act', 'ssn_critic_loss_grad_act', 'ssn_critic_input_grad_act',
+    'ssn_critic_accuracy_act',
 )
+
+libssnode.ssn_critic_num_params_act.argtypes = [c_void_p, c_void_p, c_int]
+libssnode.ssn_critic_num_params_act.restype = c_long
+libssnode.ssn_critic_forward_act.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                             c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_loss_grad_act.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 6 + [c_int] * 3 + \
+    [c_float, c_int] + [c_void_p] * 4 + [c_int, c_void_p]
+libssnode.ssn_critic_input_grad_act.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                                c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
+libssnode.ssn_critic_accuracy_act.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_int] * 3 + \
+    [c_void_p] * 3 + [c_int, c_void_p]
+for _name in ('ssn_critic_forward_act', 'ssn_critic_loss_grad_act', 'ssn_critic_input_grad_act', 'ssn_critic_accuracy_act'):
+    getattr(libssnode, _name).restype = c_int
 
 for _name in ('ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64'):
     getattr(libssnode, _name).argtypes = [c_void_p, POINTER(c_int), ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong,

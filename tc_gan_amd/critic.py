@@ -23,6 +23,9 @@ def _stream():
 
 # lasagne.nonlinearities names -> slope below zero (rectify, LeakyRectify(0.01), LeakyRectify(1/3), identity)
 LEAK = {'rectify': 0.0, 'leaky_rectify': 0.01, 'very_leaky_rectify': 1.0 / 3.0, 'linear': 1.0, 'identity': 1.0}
+# ... -> activation code of the general entry points (`ssn_critic_*_act`, include/ssnode_mi355x.h)
+ACT = {'rectify': 0, 'leaky_rectify': 1, 'very_leaky_rectify': 2, 'linear': 3, 'identity': 3, 'tanh': 4, 'sigmoid': 5,
+       'softplus': 6, 'elu': 7}
 
 
 class _NoCond(object):
@@ -39,23 +42,37 @@ class Critic(object):
     networks/wgan.py:66-97: every `cond` argument is then None)."""
 
     def __init__(self, nx, layers, seed=0, hide_cell_type=False, precision='fp32',
-                 normalization='none', nonlinearity='rectify', device=None, conditional=True):
+                 normalization='none', nonlinearity='rectify', device=None, conditional=True, net_options=None):
         norms = list(normalization) if isinstance(normalization, (list, tuple)) else [normalization] * len(layers)
         if len(norms) != len(layers) or any(n not in ('none', 'layer') for n in norms):
             raise ValueError('normalization must be none/layer (or one per layer): {!r}'.format(normalization))
         self.normalization = norms
         # hidden nonlinearity (simple_discriminator.py:139-152 takes any name of lasagne.nonlinearities): the piecewise-linear
-        # ones are x > 0 ? x : leak * x and keep the hand-derived double backward of the gradient penalty (fixed slopes
-        # instead of fixed masks); a smooth one would add second-derivative terms to every layer of that chain.
-        if nonlinearity not in LEAK:
-            raise NotImplementedError('critic nonlinearity {!r}: the GPU path has the piecewise-linear ones {}'.format(
-                nonlinearity, sorted(LEAK)))
+        # ones are x > 0 ? x : leak * x and keep the rectify fast paths (fixed slopes instead of fixed masks); the smooth ones
+        # (tanh, sigmoid, softplus, elu) run on the general layer-by-layer path, whose gradient-penalty double backward
+        # carries their curvature.
+        if nonlinearity not in ACT:
+            raise NotImplementedError('critic nonlinearity {!r}: the GPU path has {}'.format(nonlinearity, sorted(ACT)))
         self.nonlinearity = nonlinearity
-        self.leak = LEAK[nonlinearity]
-        if self.leak and 'layer' in norms:
-            # (with a non-rectify nonlinearity the reference's layer-normalised layer gains a learnable ScaleLayer,
-            # simple_discriminator.py:57-75: another parameter set, not built)
-            raise NotImplementedError('layer normalization with nonlinearity {!r} (needs the ScaleLayer)'.format(nonlinearity))
+        self.act = ACT[nonlinearity]
+        self.leak = LEAK.get(nonlinearity, 0.0)
+        # simple_discriminator.py:57-75: a layer-normalised layer gains a learnable ScaleLayer (one factor per unit, after the
+        # normalisation, before the bias) for every nonlinearity but rectify (`use_scale='auto'`); `net_options` =
+        # {'layer': {'use_scale': True / False / 'auto'}} (or one dict per layer) overrides, as the reference's `options` do
+        opts = self._layer_options(net_options, norms)
+        self.scaled = []
+        for n, o in zip(norms, opts):
+            unknown = set(o) - {'use_scale'}
+            if unknown:
+                raise NotImplementedError('critic layer options {}'.format(sorted(unknown)))
+            use = o.get('use_scale', 'auto')
+            if use not in (True, False, 'auto'):
+                raise ValueError('use_scale must be True, False or "auto": {!r}'.format(use))
+            if n != 'layer' and 'use_scale' in o:
+                raise ValueError('use_scale is an option of layer-normalised layers')
+            self.scaled.append(n == 'layer' and (nonlinearity != 'rectify' if use == 'auto' else bool(use)))
+        # the general entry points: a smooth nonlinearity anywhere, or a scale (the rectify / leaky fast paths have neither)
+        self.general = self.act >= 4 or any(self.scaled)
         clib.require_gpu()
         self.nx = int(nx)
         self.layers = [int(w) for w in layers]
@@ -67,7 +84,13 @@ class Critic(object):
         self._dims_c = (ctypes.c_int * len(self.dims))(*self.dims)
         self.layer_norm = any(n == 'layer' for n in norms)
         self._norm_c = (ctypes.c_int * max(len(norms), 1))(*[int(n == 'layer') for n in norms])
-        self.num_params = int(libssnode.ssn_critic_num_params(self._dims_c, self.nlayers))
+        # (flags of the general entry points: 1 = layer normalisation, 3 = with the learnable scale after it)
+        self._flags_c = (ctypes.c_int * max(len(norms), 1))(*[int(n == 'layer') + 2 * int(sc) for n, sc in zip(norms, self.scaled)])
+        if self.leak and self.layer_norm and not self.general:
+            self.general = True              # (leaky + layer normalisation without its scale: no fast path for that either)
+        self.num_params = int(libssnode.ssn_critic_num_params_act(self._dims_c, self._flags_c, self.nlayers) if self.general
+                              else libssnode.ssn_critic_num_params(self._dims_c, self.nlayers))
+        assert self.num_params == sum(int(np.prod(shape)) for _, shape in self.param_shapes())
         self.device = device or torch.device('cuda', torch.cuda.current_device())
         self.params = torch.empty(self.num_params, device=self.device, dtype=torch.float32)
         self.grads = torch.zeros_like(self.params)
@@ -76,11 +99,30 @@ class Critic(object):
         self._ws_key = None
         self.init_params(np.random.RandomState(seed))
 
+    @staticmethod
+    def _layer_options(options, norms):
+        """simple_discriminator.py:90-97 (`_validate_options`): None, a dict keyed by normalisation type, or one dict per layer."""
+        if options is None:
+            return [{}] * len(norms)
+        if isinstance(options, dict):
+            if not set(options) <= {'none', 'layer'}:
+                raise ValueError('net_options keys must be normalisation types: {!r}'.format(sorted(options)))
+            return [dict(options.get(n, {})) for n in norms]
+        options = [dict(o) for o in options]
+        if len(options) != len(norms):
+            raise ValueError('net_options: one dict per hidden layer')
+        return options
+
+    has_step = property(lambda self: not self.general)     # `step`: the one-call critic update of the rectify / leaky fast paths
+
     # -- parameters ------------------------------------------------------------------
     def param_shapes(self):
+        """(name, shape) in lasagne's get_all_params order: W, [scales,] b per hidden layer, then the output W."""
         shapes = []
         for l in range(self.nlayers):
             shapes.append(('W', (self.dims[l], self.dims[l + 1])))
+            if self.scaled[l]:
+                shapes.append(('scales', (self.dims[l + 1],)))
             shapes.append(('b', (self.dims[l + 1],)))
         shapes.append(('W', (self.dims[-1], 1)))
         return shapes
@@ -90,16 +132,19 @@ class Critic(object):
         simple_discriminator.py:53), hidden b ~ Normal(std=.01) (149-150), linear output layer without bias
         (160-161)."""
         flat = []
-        for i, (kind, shape) in enumerate(self.param_shapes()):
+        layer = 0
+        for kind, shape in self.param_shapes():
             if kind == 'W':
-                layer = i // 2
                 if layer < self.nlayers and self.normalization[layer] == 'layer':
                     flat.append(rng.normal(0.0, 1.0, size=shape).ravel())
                 else:
                     a = np.sqrt(6.0 / (shape[0] + shape[1]))
                     flat.append(rng.uniform(-a, a, size=shape).ravel())
+            elif kind == 'scales':
+                flat.append(np.ones(shape).ravel())            # lasagne.layers.ScaleLayer: scales = init.Constant(1)
             else:
                 flat.append(rng.normal(0.0, 0.01, size=shape).ravel())
+                layer += 1
         self.set_flat(np.concatenate(flat))
 
     def set_flat(self, flat):
@@ -162,7 +207,8 @@ class Critic(object):
         key = (bgd, bp)
         need = self.__dict__.setdefault('_ws_need', {}).get(key)
         if need is None:
-            fn = libssnode.ssn_critic_norm_workspace_floats if self.layer_norm else libssnode.ssn_critic_workspace_floats
+            fn = (libssnode.ssn_critic_norm_workspace_floats if self.layer_norm or self.general
+                  else libssnode.ssn_critic_workspace_floats)
             need = self._ws_need[key] = int(fn(self._dims_c, self.nlayers, int(bgd), int(bp)))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, device=self.device, dtype=torch.float32)
@@ -196,6 +242,11 @@ class Critic(object):
         batch = x.shape[0]
         out = torch.empty(batch, device=self.device, dtype=torch.float32)
         ws = self._workspace(batch, 0)
+        if self.general:
+            clib.check(libssnode.ssn_critic_forward_act(
+                self.params.data_ptr(), self._dims_c, self._flags_c, self.nlayers, self.act, x.data_ptr(), cond.data_ptr(), batch,
+                self.hide_cell_type, out.data_ptr(), ws.data_ptr(), self.precision, _stream()), 'ssn_critic_forward_act')
+            return out
         if self.layer_norm:
             clib.check(libssnode.ssn_critic_forward_norm(
                 self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
@@ -217,6 +268,13 @@ class Critic(object):
         ng, nd, npn = xg.shape[0], xd.shape[0], xp.shape[0]
         ws = self._workspace(ng + nd, npn)
         self._dvals = torch.empty(ng + nd, device=self.device, dtype=torch.float32)
+        if self.general:
+            clib.check(libssnode.ssn_critic_loss_grad_act(
+                self.params.data_ptr(), self._dims_c, self._flags_c, self.nlayers, self.act, xg.data_ptr(), cg.data_ptr(),
+                xd.data_ptr(), cd.data_ptr(), xp.data_ptr(), cp.data_ptr(), ng, nd, npn, float(lmd), self.hide_cell_type,
+                self.grads.data_ptr(), self.stats.data_ptr(), self._dvals.data_ptr(), ws.data_ptr(), self.precision,
+                _stream()), 'ssn_critic_loss_grad_act')
+            return self.stats
         if self.layer_norm:
             clib.check(libssnode.ssn_critic_loss_grad_norm(
                 self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, xg.data_ptr(), cg.data_ptr(),
@@ -253,6 +311,12 @@ class Critic(object):
         batch = x.shape[0]
         gx = torch.empty((batch, self.nx), device=self.device, dtype=torch.float32)
         ws = self._workspace(batch, batch)
+        if self.general:
+            clib.check(libssnode.ssn_critic_input_grad_act(
+                self.params.data_ptr(), self._dims_c, self._flags_c, self.nlayers, self.act, x.data_ptr(), cond.data_ptr(), batch,
+                self.hide_cell_type, float(scale), gx.data_ptr(), self.stats.data_ptr(), ws.data_ptr(), self.precision,
+                _stream()), 'ssn_critic_input_grad_act')
+            return gx, self.stats[0]
         if self.layer_norm:
             clib.check(libssnode.ssn_critic_input_grad_norm(
                 self.params.data_ptr(), self._dims_c, self._norm_c, self.nlayers, x.data_ptr(), cond.data_ptr(), batch,
@@ -283,6 +347,12 @@ class Critic(object):
         dv = self.__dict__.get('_acc_dvals')
         if dv is None or dv.numel() < ng + nd:
             dv = self._acc_dvals = torch.empty(ng + nd, device=self.device, dtype=torch.float32)
+        if self.general:
+            clib.check(libssnode.ssn_critic_accuracy_act(
+                self.params.data_ptr(), self._dims_c, self._flags_c, self.nlayers, self.act, xg.data_ptr(), cg.data_ptr(),
+                xd.data_ptr(), cd.data_ptr(), ng, nd, self.hide_cell_type, out.data_ptr(), dv.data_ptr(), ws.data_ptr(),
+                self.precision, _stream()), 'ssn_critic_accuracy_act')
+            return out
         clib.check(libssnode.ssn_critic_accuracy(
             self.params.data_ptr(), self._dims_c, self._norm_c if self.layer_norm else None, self.nlayers, float(self.leak),
             xg.data_ptr(), cg.data_ptr(), xd.data_ptr(), cd.data_ptr(), ng, nd, self.hide_cell_type, out.data_ptr(),
@@ -298,6 +368,8 @@ class Critic(object):
         `interpolate`, `loss_grad`, `Updater.__call__` (plain clip-free form), `accuracy_device`, `param_sqnorms_device` in
         that order, so the same numbers.  Returns (xp, tail): tail = [penalties (2, from `pens64`), loss, accuracy, sums of
         squares] on the device."""
+        if self.general:
+            raise NotImplementedError('Critic.step is the one-call update of the rectify / leaky fast paths (has_step)')
         xg, xd, cond = self._f32(xg), self._f32(xd), self._f32(cond)
         eps = self._f32(eps).reshape(-1)
         n = xg.shape[0]

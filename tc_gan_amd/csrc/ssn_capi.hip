@@ -653,9 +653,59 @@ int ssn_critic_input_grad_leaky(const float* params, const int* dims, int nlayer
                                    precision == 0, (hipStream_t)stream, leak));
     return 0;
 }
+// ---- the general layer-by-layer critic: any lasagne nonlinearity, learnable scale after a layer normalisation ----------------
+static bool act_flags_ok(const int* flags, int nlayers, int act) {
+    if (act < 0 || act > 7 || nlayers < 0 || nlayers > 8) return false;
+    for (int l = 0; flags && l < nlayers; ++l) if (flags[l] != 0 && flags[l] != 1 && flags[l] != 3) return false;
+    return true;
+}
+long ssn_critic_num_params_act(const int* dims, const int* layer_flags, int nlayers) {
+    if (!dims || !act_flags_ok(layer_flags, nlayers, 0)) return -1;
+    return ssn::critic_act_num_params(dims, layer_flags, nlayers);
+}
+int ssn_critic_forward_act(const float* params, const int* dims, const int* layer_flags, int nlayers, int act, const float* x,
+                           const float* cond, int batch, int hide_cell_type, float* out, float* workspace, int precision,
+                           void* stream) {
+    if (!act_flags_ok(layer_flags, nlayers, act)) { g_last_error = "ssn_critic_forward_act: invalid layer flags / activation"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_norm_forward(params, dims, layer_flags, nlayers, x, cond, batch, hide_cell_type, out, workspace,
+                                     precision == 0, (hipStream_t)stream, act));
+    return 0;
+}
+int ssn_critic_loss_grad_act(const float* params, const int* dims, const int* layer_flags, int nlayers, int act, const float* xg,
+                             const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
+                             int nd, int np, float lmd, int hide_cell_type, float* grads, float* stats, float* dvals,
+                             float* workspace, int precision, void* stream) {
+    if (!act_flags_ok(layer_flags, nlayers, act)) { g_last_error = "ssn_critic_loss_grad_act: invalid layer flags / activation"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::critic_norm_loss_grad(params, dims, layer_flags, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd,
+                                       hide_cell_type, grads, stats, dvals, workspace, precision == 0, (hipStream_t)stream, act));
+    return 0;
+}
+int ssn_critic_input_grad_act(const float* params, const int* dims, const int* layer_flags, int nlayers, int act, const float* x,
+                              const float* cond, int batch, int hide_cell_type, float scale, float* gx, float* stats,
+                              float* workspace, int precision, void* stream) {
+    if (!act_flags_ok(layer_flags, nlayers, act)) { g_last_error = "ssn_critic_input_grad_act: invalid layer flags / activation"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    if (batch == 0) return 0;
+    SSN_TRY(ssn::critic_norm_input_grad(params, dims, layer_flags, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,
+                                        workspace, precision == 0, (hipStream_t)stream, act));
+    return 0;
+}
+int ssn_critic_accuracy_act(const float* params, const int* dims, const int* layer_flags, int nlayers, int act, const float* xg,
+                            const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type, float* acc,
+                            float* dvals, float* workspace, int precision, void* stream) {
+    if (int rc = ssn_critic_forward_act(params, dims, layer_flags, nlayers, act, xg, cg, ng, hide_cell_type, dvals, workspace, precision, stream)) return rc;
+    if (int rc = ssn_critic_forward_act(params, dims, layer_flags, nlayers, act, xd, cd, nd, hide_cell_type, dvals + ng, workspace, precision, stream)) return rc;
+    SSN_TRY(ssn::launch_mean_diff(dvals, ng, nd, acc, (hipStream_t)stream));
+    return 0;
+}
+static bool norm_flags_plain(const int* layer_norm, int nlayers) {
+    for (int l = 0; layer_norm && l < nlayers; ++l) if (layer_norm[l] != 0 && layer_norm[l] != 1) return false;
+    return true;
+}
 int ssn_critic_forward_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* x,
                             const float* cond, int batch, int hide_cell_type, float* out, float* workspace, int precision,
                             void* stream) {
+    if (!norm_flags_plain(layer_norm, nlayers)) { g_last_error = "ssn_critic_forward_norm: layer_norm flags are 0 / 1 (scaled layers: ssn_critic_forward_act)"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     if (batch == 0) return 0;
     if (cond && fused_ok(dims, nlayers, batch)) {
         SSN_TRY(ssn::critic_fused_forward(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, out, workspace, (hipStream_t)stream));
@@ -669,6 +719,7 @@ int ssn_critic_loss_grad_norm(const float* params, const int* dims, const int* l
                               const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
                               int nd, int np, float lmd, int hide_cell_type, float* grads, float* stats, float* dvals,
                               float* workspace, int precision, void* stream) {
+    if (!norm_flags_plain(layer_norm, nlayers)) { g_last_error = "ssn_critic_loss_grad_norm: layer_norm flags are 0 / 1 (scaled layers: ssn_critic_loss_grad_act)"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     if (cg && cd && cp && fused_ok(dims, nlayers, (long)ng + nd + np)) {
         SSN_TRY(ssn::critic_fused_loss_grad(params, dims, layer_norm, nlayers, xg, cg, xd, cd, xp, cp, ng, nd, np, lmd, hide_cell_type,
                                             grads, stats, dvals, workspace, (hipStream_t)stream));
@@ -681,6 +732,7 @@ int ssn_critic_loss_grad_norm(const float* params, const int* dims, const int* l
 int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* layer_norm, int nlayers, const float* x,
                                const float* cond, int batch, int hide_cell_type, float scale, float* gx, float* stats,
                                float* workspace, int precision, void* stream) {
+    if (!norm_flags_plain(layer_norm, nlayers)) { g_last_error = "ssn_critic_input_grad_norm: layer_norm flags are 0 / 1 (scaled layers: ssn_critic_input_grad_act)"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     if (batch == 0) return 0;
     if (cond && fused_ok(dims, nlayers, batch)) {
         SSN_TRY(ssn::critic_fused_input_grad(params, dims, layer_norm, nlayers, x, cond, batch, hide_cell_type, scale, gx, stats,

@@ -158,15 +158,18 @@ hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, 
 hipError_t optimizer_step(const OptArgs& o, hipStream_t st);
 // ssn_critic_ln.hip (per-layer LayerNorm flags; norm == nullptr -> all plain layers)
 size_t critic_norm_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);
+// (norm[l]: bit 0 layer normalisation, bit 1 learnable scale after it; act: 0 rectify, 1 leaky_rectify, 2 very_leaky_rectify,
+// 3 linear, 4 tanh, 5 sigmoid, 6 softplus, 7 elu)
+long critic_act_num_params(const int* dims, const int* flags, int nlayers);
 hipError_t critic_norm_forward(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
-                               const float* cond, int batch, int hide, float* out, float* ws, bool bf16, hipStream_t st);
+                               const float* cond, int batch, int hide, float* out, float* ws, bool bf16, hipStream_t st, int act = 0);
 hipError_t critic_norm_input_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* x,
                                   const float* cond, int batch, int hide, float scale, float* gx, float* stats, float* ws,
-                                  bool bf16, hipStream_t st);
+                                  bool bf16, hipStream_t st, int act = 0);
 hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int* norm, int nlayers, const float* xg,
                                  const float* cg, const float* xd, const float* cd, const float* xp, const float* cp, int ng,
                                  int nd, int np, float lmd, int hide, float* grads, float* stats, float* dvals, float* ws,
-                                 bool bf16, hipStream_t st);
+                                 bool bf16, hipStream_t st, int act = 0);
 
 // ssn_critic_fused.hip: critics whose layer widths are all <= 128 (3 launches per update; fp32 arithmetic)
 bool critic_fused_supported(const int* dims, int nlayers);

@@ -375,7 +375,7 @@ class ConditionalBPTTWassersteinGAN(object):
         ctx.snapshot = None
         ctx.gated = False
         ctx.acc_deferred = False
-        if not self.reducer.on and xg.dtype == torch.float32:
+        if not self.reducer.on and xg.dtype == torch.float32 and self.disc.has_step:
             # single process: the whole step is one library call (same kernels, same order); the skip rule of cwgan.py:493-498
             # is honoured by the optimizer kernel itself, which reads the rate penalty where the forward left it
             ctx.gated = self.disc_rate_penalty_bound > 0
@@ -821,8 +821,7 @@ def make_gan(config):
                   nonlinearity=disc_cfg.pop('nonlinearity', 'rectify'),
                   hide_cell_type=take('hide_cell_type'),
                   precision=disc_cfg.pop('precision', 'fp32'),
-                  seed=disc_cfg.pop('init_seed', seed))
-    disc_cfg.pop('net_options', None)
+                  seed=disc_cfg.pop('init_seed', seed), net_options=disc_cfg.pop('net_options', None))
 
     def updater_from(cfg):
         return Updater(**{k: cfg.pop(k) for k in ('learning_rate', 'update_name', 'update_config', 'reg_l2_penalty',

@@ -23,12 +23,12 @@ from .ssn import TuningCurveGenerator
 
 def UnConditionalDiscriminator(shape, layers, normalization='none', nonlinearity='rectify', loss_type='WD',
                                net_options=None, precision='fp32', seed=0):
-    """wgan.py:66-97: critic on the `shape[1]` columns of a tuning-curve batch, no conditions.  (`net_options` is accepted
-    and ignored like in `make_gan` of the conditional GAN; `loss_type` must be the Wasserstein one.)"""
+    """wgan.py:66-97: critic on the `shape[1]` columns of a tuning-curve batch, no conditions.  (`net_options`: the layer
+    options of simple_discriminator.py, i.e. `use_scale`; `loss_type` must be the Wasserstein one.)"""
     if loss_type != 'WD':
         raise ValueError('the BPTT GANs are Wasserstein GANs (loss_type WD), got {!r}'.format(loss_type))
     return Critic(nx=int(shape[1]), layers=layers, normalization=normalization, nonlinearity=nonlinearity,
-                  precision=precision, seed=seed, conditional=False)
+                  precision=precision, seed=seed, conditional=False, net_options=net_options)
 
 
 class UnconditionalMinibatch(object):

@@ -72,12 +72,124 @@ def test_piecewise_linear_nonlinearities(nonlinearity, batch, nx, layers):
     want = torch.autograd.grad(-og.critic_forward(params_o, x, tc, nonlinearity=nonlinearity).mean(), x)[0].numpy()
     gx, _ = c.input_grad(xg, cond, -1.0 / batch)
     np.testing.assert_allclose(gx.cpu().numpy(), want, rtol=1e-3, atol=2e-5 * np.abs(want).max())
-    # and what stays out: smooth nonlinearities, LayerNorm with a non-rectify nonlinearity (the reference adds a ScaleLayer)
     with pytest.raises(NotImplementedError):
-        Critic(nx, layers, nonlinearity='tanh')
-    if layers:
-        with pytest.raises(NotImplementedError):
-            Critic(nx, layers, nonlinearity=nonlinearity, normalization='layer')
+        Critic(nx, layers, nonlinearity='softmax')            # (a name of lasagne.nonlinearities that is not a hidden-layer choice here)
+
+
+def _assert_close(got, want, rtol, atol, kinked=False, err_msg='', loose=None):
+    """allclose; for a nonlinearity whose f'' jumps (elu at 0: 1 -> 0) a unit whose pre-activation rounds to the other side of
+    the kink in fp32 moves one sample's share of a whole weight column, so there a few thousandths of the elements may miss the
+    tight bound -- by no more than 1e-3 of the largest element."""
+    if not kinked:
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=err_msg)
+        return
+    bad = np.abs(got - want) > atol + rtol * np.abs(want)
+    assert bad.mean() <= 4e-3, (err_msg, bad.mean())
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=max(atol, 1e-3 * np.abs(want).max(), loose or 0.0), err_msg=err_msg)
+
+
+def _general_case(nonlinearity, norm, batch, nx, layers, precision='fp32', net_options=None, use_scale='auto', conditional=True, seed=0):
+    from tc_gan_amd.critic import Critic
+    rs = np.random.RandomState(batch + len(nonlinearity) + seed)
+    c = Critic(nx, layers, seed=batch, precision=precision, nonlinearity=nonlinearity, normalization=norm,
+               net_options=net_options, conditional=conditional)
+    # scales away from their initial 1 and biases away from ~0: every term of the double backward carries weight
+    flat = c.get_flat()
+    off = 0
+    for kind, shape in c.param_shapes():
+        n = int(np.prod(shape))
+        if kind == 'scales':
+            flat[off:off + n] = rs.uniform(0.5, 1.5, n)
+        elif kind == 'b':
+            flat[off:off + n] = rs.normal(0, 0.3, n)
+        off += n
+    c.set_flat(flat)
+    params_o = [og.t64(p) for p in c.get_param_values()]
+    xg, xd = rs.rand(batch, nx) * 5, rs.rand(batch, nx) * 5
+    eps = rs.rand(batch, 1)
+    xp = eps * xd + (1 - eps) * xg
+    cond = np.stack([np.full(batch, 20.), rs.rand(batch) * 2 - 1, rs.randint(0, 2, batch)], axis=1) if conditional else None
+    kw = dict(nonlinearity=nonlinearity, normalization=norm, use_scale=use_scale)
+    return c, params_o, xg, xd, xp, cond, kw
+
+
+@pytest.mark.parametrize('nonlinearity', ['tanh', 'sigmoid', 'softplus', 'elu'])
+@pytest.mark.parametrize('norm', ['none', 'layer', ['none', 'layer', 'layer']])
+@pytest.mark.parametrize('batch,nx,layers', [(7, 4, [9, 6, 5]), (130, 8, [128, 128, 128]), (256, 8, [512, 512, 512])])
+def test_smooth_nonlinearities_and_scale_layers_vs_fp64_autograd(nonlinearity, norm, batch, nx, layers):
+    """`--disc-nonlinearity tanh / sigmoid / softplus / elu` (simple_discriminator.py:139-152) with and without layer
+    normalisation -- whose layers then carry the reference's learnable ScaleLayer (:57-75) -- against torch autograd on the
+    fp64 restatement: loss, EVERY parameter gradient through the gradient penalty (the curvature f'' of the nonlinearity at
+    every layer, the scales, the normalisation), critic values, the generator-side input gradient, the accuracy.  Same
+    tolerances as the rectify cases: 2e-5 on the loss, 1e-3 / 2e-5 of the largest element on gradients."""
+    c, params_o, xg, xd, xp, cond, kw = _general_case(nonlinearity, norm, batch, nx, layers)
+    assert c.general and not c.has_step
+    names = c.get_param_names()
+    assert ('scales' in names) == (norm != 'none') and len(names) == len(params_o)
+    ps = [p.clone().requires_grad_(True) for p in params_o]
+    tg, td, tp, tc = (og.t64(a) for a in (xg, xd, xp, cond))
+    loss_o = og.critic_loss(ps, tg, td, tp, tc, tc, tc, 10.0, **kw)
+    grads_o = torch.autograd.grad(loss_o, ps)
+    flat_o = np.concatenate([g.numpy().ravel() for g in grads_o])
+    stats = c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(loss_o), rtol=2e-5, atol=1e-5)
+    got = c.grads.cpu().numpy()
+    kinked = nonlinearity == 'elu'
+    _assert_close(got, flat_o, 1e-3, 2e-5 * np.abs(flat_o).max(), kinked)
+    off = 0
+    for (kind, shape), g in zip(c.param_shapes(), grads_o):          # ... and tensor by tensor (small tensors hide in a flat comparison)
+        n = int(np.prod(shape))
+        w = g.numpy().ravel()
+        _assert_close(got[off:off + n], w, 2e-3, 1e-4 * max(np.abs(w).max(), 1e-30), kinked, err_msg=kind,
+                      loose=1e-3 * np.abs(flat_o).max())
+        off += n
+    np.testing.assert_allclose(c.forward(xg, cond).cpu().numpy(), og.critic_forward(params_o, tg, tc, **kw)[:, 0].numpy(),
+                               rtol=1e-4, atol=1e-5)
+    x = tg.clone().requires_grad_(True)
+    want = torch.autograd.grad(-og.critic_forward(params_o, x, tc, **kw).mean(), x)[0].numpy()
+    gx, dmean = c.input_grad(xg, cond, -1.0 / batch)
+    np.testing.assert_allclose(gx.cpu().numpy(), want, rtol=1e-3, atol=2e-5 * np.abs(want).max())
+    acc = c.accuracy(xg, cond, xd, cond)
+    assert abs(acc - (stats[0] - stats[1])) < 1e-5
+
+
+@pytest.mark.parametrize('nonlinearity,use_scale', [('leaky_rectify', 'auto'), ('linear', 'auto'), ('rectify', True), ('tanh', False)])
+def test_scale_layer_rule_and_option(nonlinearity, use_scale):
+    """simple_discriminator.py:57-60: `use_scale='auto'` = every nonlinearity but rectify; the layer option overrides it either
+    way (`net_options={'layer': {'use_scale': ...}}`, the reference's `options`).  Piecewise-linear nonlinearities with a
+    scale, rectify with a forced scale, tanh with the scale switched off -- all against fp64 autograd."""
+    opts = None if use_scale == 'auto' else {'layer': {'use_scale': use_scale}}
+    c, params_o, xg, xd, xp, cond, kw = _general_case(nonlinearity, ['none', 'layer'], 40, 6, [24, 16], net_options=opts, use_scale=use_scale)
+    want_scale = (nonlinearity != 'rectify') if use_scale == 'auto' else use_scale
+    assert ('scales' in c.get_param_names()) == want_scale
+    ps = [p.clone().requires_grad_(True) for p in params_o]
+    tg, td, tp, tc = (og.t64(a) for a in (xg, xd, xp, cond))
+    loss_o = og.critic_loss(ps, tg, td, tp, tc, tc, tc, 10.0, **kw)
+    flat_o = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(loss_o, ps)])
+    stats = c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(loss_o), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(c.grads.cpu().numpy(), flat_o, rtol=1e-3, atol=2e-5 * np.abs(flat_o).max())
+
+
+def test_smooth_unconditional_critic_and_bf16():
+    """The general path without condition columns (UnConditionalDiscriminator) and with bf16 GEMM operands (bf16 tolerance)."""
+    c, params_o, xg, xd, xp, cond, kw = _general_case('tanh', 'layer', 64, 8, [32, 32], conditional=False)
+    ps = [p.clone().requires_grad_(True) for p in params_o]
+    tg, td, tp = (og.t64(a) for a in (xg, xd, xp))
+    loss_o = og.critic_loss(ps, tg, td, tp, None, None, None, 10.0, **kw)
+    flat_o = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(loss_o, ps)])
+    stats = c.loss_grad(xg, None, xd, None, xp, None, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(loss_o), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(c.grads.cpu().numpy(), flat_o, rtol=1e-3, atol=2e-5 * np.abs(flat_o).max())
+    cb, params_o, xg, xd, xp, cond, kw = _general_case('elu', 'layer', 256, 8, [128, 128], precision='bf16')
+    ps = [p.clone().requires_grad_(True) for p in params_o]
+    tg, td, tp, tc = (og.t64(a) for a in (xg, xd, xp, cond))
+    loss_o = og.critic_loss(ps, tg, td, tp, tc, tc, tc, 10.0, **kw)
+    flat_o = np.concatenate([g.numpy().ravel() for g in torch.autograd.grad(loss_o, ps)])
+    stats = cb.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()
+    np.testing.assert_allclose(stats[3], float(loss_o), rtol=3e-2, atol=3e-2)
+    err = np.abs(cb.grads.cpu().numpy() - flat_o).max() / np.abs(flat_o).max()
+    assert err < 5e-2, err
 
 
 @pytest.mark.parametrize('layers,norm,nonlin,precision', [([128, 128, 128, 128], ['none', 'layer', 'layer', 'layer'], 'rectify', 'fp32'),

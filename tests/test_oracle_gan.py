@@ -115,3 +115,26 @@ def test_optimizer_steps_against_closed_forms():
     st = {}
     p2 = og.rmsprop_step(p, g, st, lr=0.01)
     np.testing.assert_allclose(p2, p - 0.01 * g / np.sqrt(0.1 * g * g + 1e-6))
+
+
+def test_oracle_critic_scale_layers_and_smooth_nonlinearities():
+    """oracle/gan_torch.critic_forward in its general form against a direct numpy restatement of
+    simple_discriminator.py:57-75 (Dense(no bias) -> LayerNorm eps 1e-4 -> ScaleLayer -> Bias -> nonlinearity):
+    parameter order W, scales, b; the ScaleLayer only for non-rectify nonlinearities (`use_scale='auto'`)."""
+    import torch
+    from oracle import gan_torch as og
+    rs = np.random.RandomState(0)
+    x = rs.rand(5, 4)
+    W1, s1, b1, Wo = rs.randn(4, 6), rs.uniform(0.5, 1.5, 6), rs.randn(6) * 0.1, rs.randn(6, 1)
+    a = x @ W1
+    y = (a - a.mean(1, keepdims=True)) / np.sqrt(a.var(1, keepdims=True) + 1e-4)
+    for name, f in (('tanh', np.tanh), ('sigmoid', lambda t: 1 / (1 + np.exp(-t))), ('softplus', lambda t: np.log1p(np.exp(t))),
+                    ('elu', lambda t: np.where(t > 0, t, np.expm1(t)))):
+        want = f(y * s1 + b1) @ Wo
+        got = og.critic_forward([og.t64(p) for p in (W1, s1, b1, Wo)], og.t64(x), None, normalization='layer', nonlinearity=name)
+        np.testing.assert_allclose(got.numpy(), want, rtol=1e-12, atol=1e-12)
+    want = np.maximum(y + b1, 0) @ Wo                     # rectify: no scale
+    got = og.critic_forward([og.t64(p) for p in (W1, b1, Wo)], og.t64(x), None, normalization='layer', nonlinearity='rectify')
+    np.testing.assert_allclose(got.numpy(), want, rtol=1e-12, atol=1e-12)
+    assert og.critic_layer_scales(['none', 'layer'], 'tanh', 2) == [False, True]
+    assert og.critic_layer_scales('layer', 'rectify', 2) == [False, False]

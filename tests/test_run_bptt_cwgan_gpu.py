@@ -31,6 +31,8 @@ def _load_tables(directory, store):
     ['--contrasts', '5, 20'],
     ['--include-inhibitory-neurons', '--dataset-provider', 'fixedtime'],
     ['--disc-normalization', 'layer'],
+    ['--disc-nonlinearity', 'tanh'],
+    ['--disc-nonlinearity', 'elu', '--disc-normalization', 'layer'],
     ['--ssn-type', 'heteroin', '--dataset-provider', 'fixedtime'],
     ['--ssn-type', 'deg-heteroin', '--dataset-provider', 'fixedtime', '--include-inhibitory-neurons'],
 ])
@@ -64,7 +66,10 @@ def test_single_g_step(args, tmp_path, monkeypatch):
     assert os.path.exists(out / 'TC_mean.csv')
     assert os.path.exists(out / 'disc_param' / 'last.npz')
     npz = np.load(out / 'disc_param' / 'last.npz')
-    assert int(npz['version']) == 1 and list(npz['param_names']) == ['W', 'b', 'W']
+    # (a layer-normalised layer with a non-rectify nonlinearity carries the reference's ScaleLayer: simple_discriminator.py:57-75)
+    scaled = '--disc-normalization' in args and '--disc-nonlinearity' in args
+    assert int(npz['version']) == 1 and list(npz['param_names']) == (['W', 'scales', 'b', 'W'] if scaled else ['W', 'b', 'W'])
+    assert len(tables['disc_param_stats'].dtype.names) == 2 + (4 if scaled else 3)
 
 
 def test_known_error_exit_code(tmp_path, monkeypatch):
