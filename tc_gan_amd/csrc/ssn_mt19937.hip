@@ -10,6 +10,9 @@
 // 2^24 blocks, 63 polynomials per level (digit d = 1..63 times the stride), so that any segment state is at most one jump per
 // level away and all states of a level are computed by ONE launch from the states of the level above.
 //
+// The states (expand + jump) are computed on a stream of the library's own into the library's buffers, beside whatever the
+// caller's stream is still running; the caller's stream waits for them and runs the generation kernel alone.
+//
 //   mt_expand_kernel one workgroup per parent state: the 20608 words x[] its children's taps can reach, to memory.
 //   mt_jump_kernel   one workgroup per (state, quarter of the polynomial's tap range): its window of the parent's x[] in LDS,
 //                    twice (the second copy shifted by one word, so that every tap is ONE aligned 8-byte read per lane: words
@@ -438,6 +441,19 @@ struct DeviceTables {
     uint32_t* pinned = nullptr;      // [624]
     uint32_t* chain = nullptr;       // [kSoloParts][624] partial states + the arrival counter
     std::mutex chain_mu;             // one set per device: calls on a device take turns in it
+    // Segment states are computed on the side stream too, into buffers of the library's own: that work needs nothing of the
+    // caller's (no output buffer, none of its stream's results), so it starts when the call is made and runs beside whatever
+    // the caller's stream is still busy with; the caller's stream waits for `ready` and runs the generation kernel only.  A
+    // ring of sets: a set is reused once the generation kernel that read it has finished (`consumed`).
+    struct BulkSet {
+        uint32_t* states[kLevels] = {}; size_t states_cap[kLevels] = {};
+        uint32_t* xseq[kLevels] = {}; size_t xseq_cap[kLevels] = {};
+        hipEvent_t ready = nullptr, consumed = nullptr;
+        bool used = false;
+    };
+    static constexpr int kBulkSets = 3;
+    BulkSet bulk[kBulkSets];
+    unsigned next_bulk = 0;
     // exact polynomials by jump length in blocks (a run draws the same shapes over and over: two lengths per shape)
     struct Exact { uint16_t* codes; int* counts; };
     std::map<long, Exact> exact;
@@ -583,27 +599,52 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
         if ((e = hipEventRecord(t->done, t->side)) != hipSuccess) return e;
     }
 
-    // (2) the wanted doubles, on the caller's stream: the states of every level between the root and the segments, top down
+    // (2) the wanted doubles: the states of every level between the root and the segments, top down, on the side stream (behind
+    // the launch above) into a set of the library's buffers; then, on the caller's stream, the generation kernel
     if (count) {
+        if (!chain_lock.owns_lock()) chain_lock.lock();
+        DeviceTables::BulkSet& bs = t->bulk[t->next_bulk++ % DeviceTables::kBulkSets];
+        if (!bs.ready) {
+            if ((e = hipEventCreateWithFlags(&bs.ready, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&bs.consumed, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        if (bs.used && (e = hipStreamWaitEvent(t->side, bs.consumed, 0)) != hipSuccess) return e;
         const uint32_t* parent = nullptr; long parent_cnt = 1; int parent_parts = 1;
-        uint32_t* bufs[kLevels] = {};
-        uint32_t* xbufs[kLevels] = {};
-        for (int l = top_b; l >= kSegLevel; --l) {
+        for (int l = top_b; l >= kSegLevel && e == hipSuccess; --l) {
             const int sh = level_shift(l) - level_shift(kSegLevel);
             // level 0: the segment starts (every step-th state); above: every state between the first and the last one's ancestors
             const int lstep = l == kSegLevel ? step : 1;
             const long lo = (s_lo * step) >> sh, hi = (s_hi * step) >> sh, cnt = (hi - lo) / lstep + 1;
-            if ((e = hipMallocAsync((void**)&xbufs[l], sizeof(uint32_t) * (size_t)parent_cnt * kXSeq, st)) != hipSuccess) break;
             const int sub = sub_for(cnt);
-            if ((e = hipMallocAsync((void**)&bufs[l], sizeof(uint32_t) * (size_t)cnt * kShares * sub * kN, st)) != hipSuccess) break;
-            xa.states = parent; xa.nparts = parent_parts; xa.xseq = xbufs[l];
-            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)parent_cnt), dim3(256), xlds, st, xa);
-            ja.xseq = xbufs[l]; ja.parent_lo = lo >> kRadixLog2;
-            ja.dst = bufs[l]; ja.lo = lo; ja.step = lstep; ja.sub = sub;
+            const size_t need_x = sizeof(uint32_t) * (size_t)parent_cnt * kXSeq, need_s = sizeof(uint32_t) * (size_t)cnt * kShares * sub * kN;
+            if (need_x > bs.xseq_cap[l] || need_s > bs.states_cap[l]) {
+                // (grow: rare -- a larger draw than any before.  The set may still be read by the kernels of an earlier draw)
+                if (bs.used && (e = hipEventSynchronize(bs.consumed)) != hipSuccess) break;
+                if ((e = hipStreamSynchronize(t->side)) != hipSuccess) break;
+                if (need_x > bs.xseq_cap[l]) {
+                    if (bs.xseq[l]) (void)hipFree(bs.xseq[l]);
+                    bs.xseq[l] = nullptr; bs.xseq_cap[l] = 0;
+                    if ((e = hipMalloc((void**)&bs.xseq[l], need_x + need_x / 4)) != hipSuccess) break;
+                    bs.xseq_cap[l] = need_x + need_x / 4;
+                }
+                if (need_s > bs.states_cap[l]) {
+                    if (bs.states[l]) (void)hipFree(bs.states[l]);
+                    bs.states[l] = nullptr; bs.states_cap[l] = 0;
+                    if ((e = hipMalloc((void**)&bs.states[l], need_s + need_s / 4)) != hipSuccess) break;
+                    bs.states_cap[l] = need_s + need_s / 4;
+                }
+            }
+            xa.states = parent; xa.nparts = parent_parts; xa.xseq = bs.xseq[l];
+            hipLaunchKernelGGL(mt_expand_kernel, dim3((unsigned)parent_cnt), dim3(256), xlds, t->side, xa);
+            ja.xseq = bs.xseq[l]; ja.parent_lo = lo >> kRadixLog2;
+            ja.dst = bs.states[l]; ja.lo = lo; ja.step = lstep; ja.sub = sub;
             ja.codes = t->codes[l]; ja.counts = t->counts[l];
-            hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt, kShares * sub), dim3(320), kJumpLds, st, ja);
-            parent = bufs[l]; parent_cnt = cnt; parent_parts = kShares * sub;
+            hipLaunchKernelGGL(mt_jump_kernel, dim3((unsigned)cnt, kShares * sub), dim3(320), kJumpLds, t->side, ja);
+            parent = bs.states[l]; parent_cnt = cnt; parent_parts = kShares * sub;
         }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(bs.ready, t->side);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, bs.ready, 0);
         if (e == hipSuccess) {
             const unsigned nseg = (unsigned)(s_hi - s_lo + 1);
             const bool odd = pos & 1;
@@ -617,10 +658,7 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
                 else hipLaunchKernelGGL((mt_gen_kernel<double, false>), dim3(nseg), dim3(256), 0, st, ga);
             }
             e = hipGetLastError();
-        }
-        for (int l = 0; l < kLevels; ++l) {
-            if (bufs[l]) { const hipError_t fe = hipFreeAsync(bufs[l], st); if (e == hipSuccess) e = fe; }
-            if (xbufs[l]) { const hipError_t fe = hipFreeAsync(xbufs[l], st); if (e == hipSuccess) e = fe; }
+            if (e == hipSuccess) { e = hipEventRecord(bs.consumed, st); bs.used = true; }
         }
     }
 
