@@ -205,7 +205,7 @@ Z_MODES = {'philox': 'device-side z (Philox)',
            'numpy': "z = rng.rand drawn by numpy on the host, as the reference does (--z-host-draw)"}
 
 
-def run_c3(args, rank, world, local_rank, paper=False, z_mode='philox', comparisons=True):
+def run_c3(args, rank, world, local_rank, paper=False, z_mode='refstream', comparisons=True):
     """``paper=True``: the shape of the reference's published run (scripts/fig4/gan/run.json): 2N=202, 128 models,
     seqlen 240 / skip 200, tau_E=2, deg-heteroin SSN, 4x128 critic with LayerNorm on layers 2-4, rmsprop.
     Default: BASELINE config 3/4: the bptt_cwgan loop.  One step = one GAN iteration = critic_iters (5) critic
@@ -215,7 +215,7 @@ def run_c3(args, rank, world, local_rank, paper=False, z_mode='philox', comparis
     value = N x iterations/s, i.e. 1024-model GAN iterations per second over the whole job."""
     import torch
     import torch.distributed as dist
-    def timed_loop(gen_kernel):
+    def timed_loop(gen_kernel, z_mode=z_mode):
         """warm-up + `steps` GAN iterations of a FRESH GAN (same seeds), barrier + synchronize on both sides, MAX over ranks."""
         gan, shape, bandwidths = make_c3_gan(world, rank, paper=paper, disc_precision=args.disc_precision, gen_kernel=gen_kernel,
                                              z_mode=z_mode)
@@ -279,6 +279,11 @@ def run_c3(args, rank, world, local_rank, paper=False, z_mode='philox', comparis
     fused_ms = None
     if comparisons and args.steps >= 2 and gan.gen.forward_variant(models) == 8:
         fused_ms = timed_loop('duo-fused')[3] / args.steps * 1e3
+    # the same loop with z from a Philox stream (--z-device-seed: another noise stream than the reference's; no generator state
+    # to hand back to the host, W straight from the counter)
+    philox_ms = None
+    if comparisons and z_mode == 'refstream' and args.steps >= 2:
+        philox_ms = timed_loop(os.environ.get('BENCH_GEN_KERNEL', 'auto'), z_mode='philox')[3] / args.steps * 1e3
     # dominant kernel: gen_forward_kernel, timed alone with HIP events on the launch stream
     bw = np.tile(np.asarray(bandwidths, dtype='float32')[None], (models, 1))
     kw = dict(stimulator_bandwidths=bw, stimulator_contrasts=np.full_like(bw, 20.0), prober_norm_probes=np.zeros(models),
@@ -340,6 +345,10 @@ def run_c3(args, rank, world, local_rank, paper=False, z_mode='philox', comparis
         out['fused_backward'] = {'ms_per_step': fused_ms, 'value': world * 1e3 / fused_ms, 'steps': args.steps, 'warmup': args.warmup,
                                  'note': 'same loop on a fresh GAN with the same seeds, generator backward as ONE launch (gen_kernel '
                                          'duo-fused: ssn_gen_backward_fused_f32) instead of adjoint sweep + dL/dW product'}
+    if philox_ms is not None:
+        out['philox_z'] = {'ms_per_step': philox_ms, 'value': world * 1e3 / philox_ms, 'steps': args.steps, 'warmup': args.warmup,
+                           'note': 'same loop on a fresh GAN, z from one Philox4x32-10 stream sharded over the ranks (--z-device-seed): '
+                                   "NOT the reference's noise stream; the difference to ms_per_step is what continuing the RandomState costs"}
     if phases is not None:
         out['phases'] = phases
     out['world_size'] = world
@@ -497,13 +506,13 @@ def main():
                     '8 fp16-split MFMA with two draws per workgroup')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample', type=int, default=0, help='weight draws in the CPU baseline sample (0 = auto)')
-    ap.add_argument('--secondary-steps', type=int, default=5,
+    ap.add_argument('--secondary-steps', type=int, default=10,
                     help='GAN iterations of the C3 run whose line rides along as `secondary` with the default (C2) '
                          'workload, so that one command covers both halves of BASELINE.json.metric (0 = off)')
     ap.add_argument('--no-extras', dest='extras', action='store_false',
                     help='default (C2) workload on one GPU: skip the short c2nb8 / c5 / c1-dropin / c3paper runs that ride along '
                          'as `extras`')
-    ap.add_argument('--z-mode', default='philox', choices=sorted(Z_MODES),
+    ap.add_argument('--z-mode', default='refstream', choices=sorted(Z_MODES),
                     help="c3 / c3paper: where z comes from (see make_c3_gan)")
     ap.add_argument('--disc-precision', default='bf16', choices=['bf16', 'fp32'],
                     help='c3: critic GEMM operand precision (BASELINE config 3 names bf16 MFMA)')
@@ -564,12 +573,12 @@ def main():
         if args.workload == 'c2' and args.secondary_steps > 0:
             # the second half of BASELINE.json.metric ("GAN iters/sec"): a short C3 run in the same job
             sub = argparse.Namespace(**vars(args))
-            sub.steps, sub.warmup = args.secondary_steps, 2
+            sub.steps, sub.warmup = args.secondary_steps, 3
             sec = run_c3(sub, rank, world, local_rank)
             out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                                                     'higher_is_better', 'scaling', 'dtype', 'data', 'config', 'roofline',
                                                     'last_gen_loss')}
-            for key in ('fp32_mfma', 'fused_backward', 'phases', 'gen_kernel', 'forward_variant'):
+            for key in ('fp32_mfma', 'fused_backward', 'philox_z', 'phases', 'gen_kernel', 'forward_variant', 'z_mode', 'host_draw_ms'):
                 if key in sec:
                     out['secondary'][key] = sec[key]
         if args.workload == 'c2' and args.extras and world == 1:
@@ -577,21 +586,25 @@ def main():
             # them too: C2 with the 8 bandwidths every real caller uses, C5, C1 through the drop-in symbols, the paper's shape.
             out['extras'] = {}
             keep = ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
-                    'gen_kernel', 'forward_variant', 'last_gen_loss', 'fused_backward', 'z_mode', 'host_draw_ms', 'numpy_host_draw_ms')
+                    'gen_kernel', 'forward_variant', 'last_gen_loss', 'fused_backward', 'philox_z', 'z_mode', 'host_draw_ms', 'numpy_host_draw_ms')
             for name, workload, steps, warmup, kw in (('c2nb8', 'c2nb8', 3, 1, {}), ('c5', 'c5', 5, 1, {}),
                                                       ('c1_dropin', 'c1', 1, 0, dict(via='dropin', cpu_sample=128)),
                                                       ('c3paper', 'c3paper', 20, 5, {}),
-                                                      ('c3_refstream', 'c3', max(args.secondary_steps, 3), 2, {}),
-                                                      ('c3paper_refstream', 'c3paper', 20, 5, {})):
+                                                      ('c3_refstream', 'c3', max(args.secondary_steps, 3), 3, {})):
                 sub = argparse.Namespace(**dict(vars(args), workload=workload, steps=steps, warmup=warmup, variant=-1,
                                                 no_cpu_baseline=(name != 'c1_dropin'), **kw))
                 t_extra = time.perf_counter()
-                if name.endswith('_refstream'):
-                    # the C3 loop WITHOUT --z-device-seed: the reference's noise stream (RandomState seed 0), z on the device
-                    res = run_c3(sub, rank, world, local_rank, paper=workload == 'c3paper', z_mode='refstream', comparisons=False)
+                if name == 'c3_refstream':
+                    # the C3 loop WITHOUT --z-device-seed -- the reference's noise stream (RandomState seed 0), z continued on the
+                    # device -- is what `secondary` holds since round 5; repeated here under the name VERDICT r4 asked for, with
+                    # what numpy takes to draw one iteration's six z tensors on this host beside it
+                    if 'secondary' in out and out['secondary'].get('z_mode') == 'refstream':
+                        res = dict(out['secondary'], config=dict(out['secondary']['config'], note='= `secondary` of this line'))
+                    else:
+                        res = run_c3(sub, rank, world, local_rank, z_mode='refstream', comparisons=False)
                     rs_t = np.random.RandomState(0)
                     t_np = time.perf_counter()
-                    rs_t.rand(*((128, 202, 202) if workload == 'c3paper' else (1024, 200, 200)))
+                    rs_t.rand(1024, 200, 200)
                     res['numpy_host_draw_ms'] = (time.perf_counter() - t_np) * 1e3 * 6     # six z draws per iteration on this host
                 elif workload == 'c3paper':
                     res = run_c3(sub, rank, world, local_rank, paper=True)

@@ -639,6 +639,15 @@ int ssn_mt19937_random_sample_f32(unsigned int *key, int *pos, unsigned long lon
 int ssn_mt19937_random_sample_f64(unsigned int *key, int *pos, unsigned long long total, unsigned long long skip,
                                   unsigned long long count, double *out, void *stream);
 int ssn_mt19937_jump_poly(unsigned long long nblocks, unsigned long long *bits);
+/* The same draw in two halves, for a caller that has launches to queue before it next needs its generator: _begin launches
+ * everything (key / pos are read, not written) and returns a ticket at once; _finish(ticket) waits for the state after the
+ * draw -- one small launch on the library's own stream -- and writes it to key / pos.  A ticket is finished at most once
+ * (a second time: invalid argument) and may be finished any time later, after any number of other draws.  ssn_mt19937_random_sample_* = _begin followed by _finish. */
+int ssn_mt19937_random_sample_begin_f32(const unsigned int *key, int pos, unsigned long long total, unsigned long long skip,
+                                        unsigned long long count, float *out, void *stream, int *ticket);
+int ssn_mt19937_random_sample_begin_f64(const unsigned int *key, int pos, unsigned long long total, unsigned long long skip,
+                                        unsigned long long count, double *out, void *stream, int *ticket);
+int ssn_mt19937_random_sample_finish(int ticket, unsigned int *key, int *pos);
 
 #ifdef __cplusplus
 }

@@ -348,6 +348,7 @@ DECLARED_SYMBOLS = (
     'ssn_critic_forward_leaky', 'ssn_critic_loss_grad_leaky', 'ssn_critic_input_grad_leaky', 'ssn_critic_accuracy', 'ssn_critic_step_run', 'ssn_critic_step_gated_run', 'ssn_gen_grads_ws_doubles', 'ssn_gen_grads_f32', 'ssn_gen_apply_f32',
     'ssn_gen_inputs_philox_f32',
     'ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64', 'ssn_mt19937_jump_poly',
+    'ssn_mt19937_random_sample_begin_f32', 'ssn_mt19937_random_sample_begin_f64', 'ssn_mt19937_random_sample_finish',
     'ssn_critic_num_params_act', 'ssn_critic_forward_act', 'ssn_critic_loss_grad_act', 'ssn_critic_input_grad_act',
     'ssn_critic_accuracy_act',
 )
@@ -371,6 +372,12 @@ for _name in ('ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64'):
     getattr(libssnode, _name).restype = c_int
 libssnode.ssn_mt19937_jump_poly.argtypes = [ctypes.c_ulonglong, c_void_p]
 libssnode.ssn_mt19937_jump_poly.restype = c_int
+for _name in ('ssn_mt19937_random_sample_begin_f32', 'ssn_mt19937_random_sample_begin_f64'):
+    getattr(libssnode, _name).argtypes = [c_void_p, c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong,
+                                          c_void_p, c_void_p, POINTER(c_int)]
+    getattr(libssnode, _name).restype = c_int
+libssnode.ssn_mt19937_random_sample_finish.argtypes = [c_int, c_void_p, POINTER(c_int)]
+libssnode.ssn_mt19937_random_sample_finish.restype = c_int
 
 libssnode.ssn_set_operand_precision.argtypes = [c_int]
 libssnode.ssn_set_operand_precision.restype = c_int

@@ -1211,6 +1211,25 @@ int ssn_mt19937_random_sample_f64(unsigned int* key, int* pos, unsigned long lon
     SSN_TRY(ssn::mt19937_draw(key, pos, total, skip, count, out, 8, (hipStream_t)stream));
     return 0;
 }
+int ssn_mt19937_random_sample_begin_f32(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip,
+                                        unsigned long long count, float* out, void* stream, int* ticket) {
+    if (!key || !ticket) { g_last_error = "ssn_mt19937_random_sample_begin: null state / ticket"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    *ticket = -1;
+    SSN_TRY(ssn::mt19937_begin(key, pos, total, skip, count, out, 4, (hipStream_t)stream, ticket));
+    return 0;
+}
+int ssn_mt19937_random_sample_begin_f64(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip,
+                                        unsigned long long count, double* out, void* stream, int* ticket) {
+    if (!key || !ticket) { g_last_error = "ssn_mt19937_random_sample_begin: null state / ticket"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    *ticket = -1;
+    SSN_TRY(ssn::mt19937_begin(key, pos, total, skip, count, out, 8, (hipStream_t)stream, ticket));
+    return 0;
+}
+int ssn_mt19937_random_sample_finish(int ticket, unsigned int* key, int* pos) {
+    if (!key || !pos) { g_last_error = "ssn_mt19937_random_sample_finish: null state"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::mt19937_finish(ticket, key, pos));
+    return 0;
+}
 int ssn_gen_inputs_philox_f32(const ssn_gen_inputs* a, void* stream) {
     if (!a || !a->J || !a->D || !a->S || !a->bw || !a->con || !a->W || !a->ext || a->B < 0 || a->NB < 0 || a->N <= 0 ||
         (a->v && (!a->zin || !a->amp))) {

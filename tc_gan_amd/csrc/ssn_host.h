@@ -230,5 +230,8 @@ template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int 
 int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits);
 hipError_t mt19937_draw(unsigned int* key, int* pos, unsigned long long total, unsigned long long skip, unsigned long long count,
                         void* out, int elem, hipStream_t st);
+hipError_t mt19937_begin(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
+                         void* out, int elem, hipStream_t st, int* ticket);
+hipError_t mt19937_finish(int ticket, unsigned int* key, int* pos);
 
 }  // namespace ssn

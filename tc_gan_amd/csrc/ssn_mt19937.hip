@@ -437,8 +437,16 @@ struct DeviceTables {
     bool lds_attr = false;
     // side stream, pinned state buffer and workspace of the kernel that computes the state after the draw
     hipStream_t side = nullptr;
-    hipEvent_t done = nullptr;
-    uint32_t* pinned = nullptr;      // [624]
+    // the state after a draw is handed over through a ticket (a draw may return before that state is known: the host does
+    // the waiting when it next needs its generator): pinned key buffer + event per ticket
+    static constexpr int kTickets = 8;
+    struct Ticket { hipEvent_t done = nullptr; uint32_t* pinned = nullptr; bool busy = false, computed = false; int pos = 0; unsigned gen = 0; uint32_t key[kN]; };
+    Ticket tickets[kTickets];
+    unsigned next_ticket = 0;
+    // states of draws whose slot was needed again before their owner asked (a generator that sat idle while others drew):
+    // fetched at takeover and kept here by ticket
+    struct Parked { int pos; uint32_t key[kN]; };
+    std::map<int, Parked> parked;
     uint32_t* chain = nullptr;       // [kSoloParts][624] partial states + the arrival counter
     std::mutex chain_mu;             // one set per device: calls on a device take turns in it
     // Segment states are computed on the side stream too, into buffers of the library's own: that work needs nothing of the
@@ -506,8 +514,10 @@ static hipError_t device_tables(int need_level, DeviceTables** out) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
         if ((e = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, hi)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&t->done, hipEventDisableTiming)) != hipSuccess) return e;
-        if ((e = hipHostMalloc((void**)&t->pinned, sizeof(uint32_t) * kN, hipHostMallocDefault)) != hipSuccess) return e;
+        for (auto& tk : t->tickets) {
+            if ((e = hipEventCreateWithFlags(&tk.done, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipHostMalloc((void**)&tk.pinned, sizeof(uint32_t) * kN, hipHostMallocDefault)) != hipSuccess) return e;
+        }
         if ((e = hipMalloc((void**)&t->chain, sizeof(uint32_t) * ((size_t)kSoloParts * kN + 16))) != hipSuccess) return e;
         if ((e = hipMemset(t->chain, 0, sizeof(uint32_t) * ((size_t)kSoloParts * kN + 16))) != hipSuccess) return e;
     }
@@ -543,14 +553,40 @@ int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits) {
     return 0;
 }
 
-// The draw.  key / pos: numpy's RandomState state (host, in/out).  The next `total` doubles of the stream are consumed; doubles
-// [skip, skip + count) of them are written to out (device; elem = 4: float, 8: double) on `st`.
-hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, unsigned long long skip, unsigned long long count,
-                        void* out, int elem, hipStream_t st) {
+// The state after a draw begun with mt19937_begin: waits for that draw's one launch on the library's stream, nothing else.
+hipError_t mt19937_finish(int ticket, uint32_t* key, int* pos) {
     using namespace mt;
-    const int pos = *pos_io;
-    if (pos < 0 || pos > kN || skip + count > total || (count && !out) || (elem != 4 && elem != 8)) return hipErrorInvalidValue;
-    if (total == 0) return hipSuccess;
+    const int dev = (ticket >> 8) & 255, slot = ticket & 255;
+    if (ticket < 0 || dev >= 64 || slot >= DeviceTables::kTickets || !g_dev[dev]) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(g_dev[dev]->chain_mu);
+    DeviceTables::Ticket& tk = g_dev[dev]->tickets[slot];
+    if (!tk.busy || (int)(tk.gen & 0x7fffu) != (ticket >> 16)) {
+        auto it = g_dev[dev]->parked.find(ticket);           // its slot was taken over: the state was fetched then
+        if (it == g_dev[dev]->parked.end()) return hipErrorInvalidValue;      // (finished before, or never begun)
+        std::memcpy(key, it->second.key, sizeof(uint32_t) * kN);
+        *pos = it->second.pos;
+        g_dev[dev]->parked.erase(it);
+        return hipSuccess;
+    }
+    if (tk.computed) {
+        const hipError_t e = hipEventSynchronize(tk.done);
+        if (e != hipSuccess) return e;
+        std::memcpy(key, tk.pinned, sizeof(uint32_t) * kN);
+    } else {
+        std::memcpy(key, tk.key, sizeof(uint32_t) * kN);
+    }
+    *pos = tk.pos;
+    tk.busy = false;
+    return hipSuccess;
+}
+
+// The draw.  key / pos: numpy's RandomState state (host).  The next `total` doubles of the stream are consumed; doubles
+// [skip, skip + count) of them are written to out (device; elem = 4: float, 8: double) on `st`.  Returns a ticket for the state
+// after the draw (mt19937_finish).
+hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
+                         void* out, int elem, hipStream_t st, int* ticket) {
+    using namespace mt;
+    if (pos < 0 || pos > kN || skip + count > total || (count && !out) || (elem != 4 && elem != 8) || !ticket) return hipErrorInvalidValue;
     if (total > (1ull << 40)) return hipErrorInvalidValue;
     const long p_end = (long)pos + 2 * (long)total;              // position of the first unconsumed word, from block 0
     const long b_f = p_end <= kN ? 0 : (p_end - 1) / kN;         // block of the state after the draw
@@ -585,24 +621,46 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
     JumpArgs ja;
 
     // (1) the state after the draw, on the side stream: block b_f - 1 by the exact polynomial, then one regeneration
-    std::unique_lock<std::mutex> chain_lock(t->chain_mu, std::defer_lock);
+    std::unique_lock<std::mutex> chain_lock(t->chain_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int slot = (int)(t->next_ticket++ % DeviceTables::kTickets);
+    DeviceTables::Ticket& tk = t->tickets[slot];
+    // a slot still marked busy after the ring has come round: its owner has not asked for the state yet (a generator that sat
+    // idle while others drew, or one that was dropped).  The state is fetched now (its launch is long over) and parked.
+    if (tk.busy) {
+        DeviceTables::Parked pk;
+        pk.pos = tk.pos;
+        if (tk.computed) {
+            if ((e = hipEventSynchronize(tk.done)) != hipSuccess) return e;
+            std::memcpy(pk.key, tk.pinned, sizeof pk.key);
+        } else {
+            std::memcpy(pk.key, tk.key, sizeof pk.key);
+        }
+        if (t->parked.size() >= 4096) t->parked.erase(t->parked.begin());       // (dropped generators: do not grow for ever)
+        t->parked[(int)((tk.gen & 0x7fffu) << 16) | (dev << 8) | slot] = pk;
+        tk.busy = false;
+    }
+    ++tk.gen;
+    tk.busy = true; tk.computed = b_f >= 1;
+    tk.pos = b_f >= 1 ? (int)(p_end - b_f * kN) : (int)p_end;
+    if (b_f < 1) std::memcpy(tk.key, key, sizeof tk.key);
+    *ticket = (int)((tk.gen & 0x7fffu) << 16) | (dev << 8) | slot;
     if (b_f >= 1) {
-        chain_lock.lock();
         DeviceTables::Exact ex{};
         if ((e = exact_poly(t, b_f - 1, &ex)) != hipSuccess) return e;
         SoloArgs sa;
         std::memcpy(sa.root.w, key, sizeof sa.root.w);
         sa.codes = ex.codes; sa.counts = ex.counts;
-        sa.partials = t->chain; sa.counter = (unsigned*)(t->chain + (size_t)kSoloParts * kN); sa.out = t->pinned;
+        sa.partials = t->chain; sa.counter = (unsigned*)(t->chain + (size_t)kSoloParts * kN); sa.out = tk.pinned;
         hipLaunchKernelGGL(mt_solo_kernel, dim3(1, kSoloParts), dim3(320), kJumpLds, t->side, sa);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        if ((e = hipEventRecord(t->done, t->side)) != hipSuccess) return e;
+        if ((e = hipGetLastError()) != hipSuccess) { tk.busy = false; return e; }
+        if ((e = hipEventRecord(tk.done, t->side)) != hipSuccess) { tk.busy = false; return e; }
     }
 
     // (2) the wanted doubles: the states of every level between the root and the segments, top down, on the side stream (behind
     // the launch above) into a set of the library's buffers; then, on the caller's stream, the generation kernel
     if (count) {
-        if (!chain_lock.owns_lock()) chain_lock.lock();
         DeviceTables::BulkSet& bs = t->bulk[t->next_bulk++ % DeviceTables::kBulkSets];
         if (!bs.ready) {
             if ((e = hipEventCreateWithFlags(&bs.ready, hipEventDisableTiming)) != hipSuccess) return e;
@@ -662,18 +720,17 @@ hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, un
         }
     }
 
-    // (3) the new state: wait for the side chain only
-    if (b_f >= 1) {
-        const hipError_t we = hipEventSynchronize(t->done);
-        if (we != hipSuccess) return we;
-        if (e != hipSuccess) return e;
-        std::memcpy(key, t->pinned, sizeof(uint32_t) * kN);
-        *pos_io = (int)(p_end - b_f * kN);
-    } else {
-        if (e != hipSuccess) return e;
-        *pos_io = (int)p_end;
-    }
-    return hipSuccess;
+    return e;
+}
+
+// begin + finish: returns when the state after the draw is known
+hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, unsigned long long skip, unsigned long long count,
+                        void* out, int elem, hipStream_t st) {
+    int ticket = -1;
+    const hipError_t e = mt19937_begin(key, *pos_io, total, skip, count, out, elem, st, &ticket);
+    if (ticket < 0) return e;
+    const hipError_t f = mt19937_finish(ticket, key, pos_io);
+    return e != hipSuccess ? e : f;
 }
 
 }  // namespace ssn

@@ -83,9 +83,24 @@ def device_rand(rng, shape, tdtype, rows=None):
     per_row = int(np.prod(shape[1:], dtype=np.int64))
     lo, hi = (0, shape[0]) if rows is None else (int(rows[0]), int(rows[1]))
     out = torch.empty((hi - lo,) + shape[1:], device='cuda', dtype=tdtype)
+    f32 = tdtype == torch.float32
+    if hasattr(rng, '_defer'):
+        # the state after the draw is fetched when `rng` is next used (utils.DeviceContinuedRandomState): the caller goes on
+        # queuing its launches meanwhile
+        ticket = ctypes.c_int(-1)
+        fn = clib.libssnode.ssn_mt19937_random_sample_begin_f32 if f32 else clib.libssnode.ssn_mt19937_random_sample_begin_f64
+        clib.check(fn(key.ctypes.data, int(pos), shape[0] * per_row, lo * per_row, (hi - lo) * per_row, out.data_ptr(),
+                      clib.stream_ptr(), ctypes.byref(ticket)), 'ssn_mt19937_random_sample_begin')
+
+        def finish(r, ticket=ticket.value, key=key, kind=kind, has_gauss=has_gauss, cached=cached):
+            cpos = ctypes.c_int(0)
+            clib.check(clib.libssnode.ssn_mt19937_random_sample_finish(ticket, key.ctypes.data, ctypes.byref(cpos)),
+                       'ssn_mt19937_random_sample_finish')
+            np.random.RandomState.set_state(r, (kind, key, cpos.value, has_gauss, cached))
+        rng._defer(finish)
+        return out
     cpos = ctypes.c_int(int(pos))
-    fn = (clib.libssnode.ssn_mt19937_random_sample_f32 if tdtype == torch.float32
-          else clib.libssnode.ssn_mt19937_random_sample_f64)
+    fn = clib.libssnode.ssn_mt19937_random_sample_f32 if f32 else clib.libssnode.ssn_mt19937_random_sample_f64
     clib.check(fn(key.ctypes.data, ctypes.byref(cpos), shape[0] * per_row, lo * per_row, (hi - lo) * per_row,
                   out.data_ptr(), clib.stream_ptr()), 'ssn_mt19937_random_sample')
     rng.set_state((kind, key, cpos.value, has_gauss, cached))

@@ -68,9 +68,29 @@ def cartesian_product(*arrays, **kwargs):
     return np.stack([g.reshape(-1) for g in grids]).astype(dtype)
 
 
+class DeviceContinuedRandomState(np.random.RandomState):
+    """``numpy.random.RandomState`` (same stream, same methods) that may be told "your state after the draw the device is
+    making for you will be ready later" (`tc_gan_amd.networks.ssn.device_rand`): the state is fetched -- and waited for -- the
+    next time ANY public attribute of the generator is touched (`choice`, `rand`, `get_state`, pickling ...), not at the end of
+    the draw, so the launches that follow a z draw are queued before the host ever waits."""
+
+    def __getattribute__(self, name):
+        if name not in ('_pending', '__dict__', '__class__'):
+            d = object.__getattribute__(self, '__dict__')
+            pend = d.get('_pending')
+            if pend is not None:
+                d['_pending'] = None
+                pend(self)
+        return object.__getattribute__(self, name)
+
+    def _defer(self, finish):
+        """`finish(rng)` sets the state (``RandomState.set_state(rng, ...)``) before the generator is next used."""
+        object.__getattribute__(self, '__dict__')['_pending'] = finish
+
+
 def as_randomstate(seed):
-    """utils/numerics.py:50-54."""
-    return seed if hasattr(seed, 'seed') else np.random.RandomState(seed)
+    """utils/numerics.py:50-54 (a seed becomes a RandomState that can wait lazily for device draws: same numbers)."""
+    return seed if hasattr(seed, 'seed') else DeviceContinuedRandomState(seed)
 
 
 def random_minibatches(batchsize, data, strict=False, seed=0):

@@ -35,13 +35,20 @@ def test_default_workload_line():
     assert abs(d['value'] - 200 * 4096 * 2000 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     c = d['cpu_baseline']
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(c) and c['kind'] in ('reference', 'port') and c['value'] > 0
+    # the baseline names the box it ran on: every usable core is used
+    assert c['threads'] == c['cores'] == c['affinity_cores'] == len(os.sched_getaffinity(0)) and c['host_cpu_count'] == os.cpu_count()
     # the GAN half of the metric and the other named workloads ride along
     sec = d['secondary']
     assert sec['metric'] == 'GAN iters/sec' and sec['value'] > 0 and sec['gen_kernel'] == 'auto'
     assert sec['forward_variant'] == 8 and 'duo' in sec['roofline']['kernel']         # what the library picked, by its own word
     assert sec['fp32_mfma']['steps'] == sec['steps'] and sec['fp32_mfma']['warmup'] == sec['warmup']
+    # the GAN loop is timed on the REFERENCE's noise stream (the RandomState continued on the device), the Philox loop beside it
+    assert sec['z_mode'] == 'refstream' and 'RandomState' in sec['config']['workload'] and sec['host_draw_ms'] >= 0
+    assert sec['philox_z']['ms_per_step'] > 0 and sec['philox_z']['steps'] == sec['steps']
     ex = d['extras']
-    assert set(ex) == {'c2nb8', 'c5', 'c1_dropin', 'c3paper', 'c3paper_rccl1'}
+    assert set(ex) == {'c2nb8', 'c5', 'c1_dropin', 'c3paper', 'c3_refstream', 'c3paper_rccl1'}
+    assert ex['c3_refstream']['ms_per_step'] == sec['ms_per_step'] and ex['c3_refstream']['numpy_host_draw_ms'] > 0
+    assert ex['c3paper']['z_mode'] == 'refstream'
     rc = ex.pop('c3paper_rccl1')                  # the paper-shape loop as the single rank of an RCCL group
     assert 'error' not in rc, rc
     assert rc['dist_backend'] == 'nccl' and rc['world_size'] == 1 and rc['ms_per_step'] > 0

@@ -134,3 +134,26 @@ def test_gan_loop_device_draw_fp64_generator():
     a = _gan_run(False, gen_dtype='float64', records=6)
     b = _gan_run(True, gen_dtype='float64', records=6)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_deferred_state_survives_any_number_of_other_draws():
+    """`utils.DeviceContinuedRandomState`: the state after a device draw is fetched when the generator is next touched.  One
+    generator left waiting while others make twenty draws (more than the library's ring of tickets), then used: its stream
+    continues exactly like numpy's; each of the others too; a generator that is dropped while waiting costs nothing."""
+    from tc_gan_amd.networks.ssn import device_rand
+    from tc_gan_amd.utils import as_randomstate
+    first, ref = as_randomstate(123), np.random.RandomState(123)
+    want = ref.rand(6, 50, 50).astype('float32')
+    got = device_rand(first, (6, 50, 50), torch.float32)             # state pending from here on
+    others = [(as_randomstate(s), np.random.RandomState(s)) for s in range(20)]
+    for dev, host in others:
+        assert np.array_equal(device_rand(dev, (3, 40, 40), torch.float64).cpu().numpy(), host.rand(3, 40, 40))
+    dropped = as_randomstate(77)
+    device_rand(dropped, (2, 30, 30), torch.float32)
+    del dropped
+    for dev, host in others:
+        assert np.array_equal(dev.choice(1000, 7), host.choice(1000, 7))
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(first.rand(5), ref.rand(5))
+    st, sr = first.get_state(), ref.get_state()
+    assert np.array_equal(st[1], sr[1]) and st[2] == sr[2]
