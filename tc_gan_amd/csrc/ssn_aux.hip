@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(256) interpolate_kernel(const float* __restric
     const long i = blockIdx.x * 256L + threadIdx.x;
     if (i >= n) return;
     const float e = eps[i / cols];
-    xp[i] = e * xd[i] + (1.f - e) * xg[i];
+    xp[i] = __fadd_rn(__fmul_rn(e, xd[i]), __fmul_rn(1.f - e, xg[i]));       // (two products, one sum, each rounded: numpy's bits; critic_step_inputs_kernel forms the same)
 }
 hipError_t launch_interpolate(const float* eps, const float* xd, const float* xg, float* xp, int rows, int cols, hipStream_t st) {
     const long n = (long)rows * cols;

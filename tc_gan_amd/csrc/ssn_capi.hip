@@ -761,6 +761,13 @@ static int critic_accuracy_forwards(const float* params, const int* dims, const 
                                     float* dvals, float* workspace, int precision, void* stream) {
     bool norm = false;
     for (int l = 0; layer_norm && l < nlayers; ++l) norm = norm || layer_norm[l] != 0;
+    if (!norm && !(cg && cd && (fused_ok(dims, nlayers, ng) || fused_ok(dims, nlayers, nd)))) {
+        // plain layers on the layer-by-layer path: ONE pass over the stacked rows [xg; xd] (the values of two separate
+        // forwards, bit for bit; narrow critics keep their single-launch forwards)
+        SSN_TRY(ssn::critic_forward2(params, dims, nlayers, xg, cg, ng, xd, cd, nd, hide_cell_type, dvals, workspace, precision == 0,
+                                     (hipStream_t)stream, leak));
+        return 0;
+    }
     const struct { const float* x; const float* c; int n; float* out; } part[2] = {{xg, cg, ng, dvals}, {xd, cd, nd, dvals + ng}};
     for (int i = 0; i < 2; ++i) {
         int rc;
@@ -849,9 +856,18 @@ static int critic_step_impl(const ssn_critic_step* a, const double* gate, double
     for (int l = 0; a->layer_norm && l < a->nlayers; ++l) norm = norm || a->layer_norm[l] != 0;
     const int n = a->n, nx = a->dims[0] - (a->cond ? 3 : 0);        // cond NULL: the unconditional critic (dims[0] = nx)
     int rc;
-    if ((rc = ssn_interpolate_f32(a->eps, a->xd, a->xg, a->xp, n, nx, stream))) return rc;
+    // plain layers on the layer-by-layer path with the one condition array of the loop: the penalty points and the three input
+    // blocks come from ONE launch inside the loss pass (the bits of ssn_interpolate_f32 + the input kernels)
+    const bool one_launch_inputs = !norm && a->cond && !fused_ok(a->dims, a->nlayers, 3L * n);
+    if (!one_launch_inputs && (rc = ssn_interpolate_f32(a->eps, a->xd, a->xg, a->xp, n, nx, stream))) return rc;
     if (norm) rc = ssn_critic_loss_grad_norm(a->params, a->dims, a->layer_norm, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond,
                                              n, n, n, a->lmd, a->hide_cell_type, a->grads, a->stats, a->dvals, a->workspace, a->precision, stream);
+    else if (one_launch_inputs) {
+        SSN_TRY(ssn::critic_loss_grad(a->params, a->dims, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond, n, n, n, a->lmd,
+                                      a->hide_cell_type, a->grads, a->stats, a->dvals, a->workspace, a->precision == 0,
+                                      (hipStream_t)stream, a->leak, a->eps, a->xp));
+        rc = 0;
+    }
     else if (a->leak != 0.f) rc = ssn_critic_loss_grad_leaky(a->params, a->dims, a->nlayers, a->xg, a->cond, a->xd, a->cond, a->xp, a->cond,
                                                              n, n, n, a->lmd, a->hide_cell_type, a->leak, a->grads, a->stats, a->dvals,
                                                              a->workspace, a->precision, stream);

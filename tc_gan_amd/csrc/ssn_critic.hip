@@ -394,6 +394,33 @@ __global__ void __launch_bounds__(256) critic_input_kernel(const float* __restri
     }
 }
 
+// The inputs of a whole critic step in ONE launch (single-process loop): the penalty points xp = eps xd + (1 - eps) xg
+// (cwgan.py:476-481; the bits of interpolate_kernel) and the three input blocks critic_input_kernel would build from xg, xd and
+// xp with the one condition array they share: h0 = [rows of xg; rows of xd] (2 n rows), hp0 = rows of xp.
+__global__ void __launch_bounds__(256) critic_step_inputs_kernel(const float* __restrict__ xg, const float* __restrict__ xd,
+                                                                 const float* __restrict__ cond, const float* __restrict__ eps,
+                                                                 float* __restrict__ xp, float* __restrict__ h0,
+                                                                 float* __restrict__ hp0, int n, int nx, int hide_cell_type, int nc) {
+    const int n0 = nx + nc;
+    const long total = (long)n * n0;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += gridDim.x * 256L) {
+        const int b = (int)(e / n0), j = (int)(e % n0);
+        if (j < nx) {
+            const long i = (long)b * nx + j;
+            const float g = xg[i], d = xd[i], w = eps[b];
+            const float p = __fadd_rn(__fmul_rn(w, d), __fmul_rn(1.f - w, g));
+            xp[i] = p;
+            h0[e] = g; h0[total + e] = d; hp0[e] = p;
+        } else {
+            float v;
+            if (j == nx) v = cond[b * 3 + 0];
+            else if (j == nx + 1) v = fabsf(cond[b * 3 + 1]);
+            else v = hide_cell_type ? 0.f : cond[b * 3 + 2];
+            h0[e] = v; h0[total + e] = v; hp0[e] = v;
+        }
+    }
+}
+
 // v_L[b][k] = (h_L[b][k] > 0 ? 1 : leak) * w_out[k] * up[b]   (up = per-sample upstream of D; nullptr -> 1)
 __global__ void __launch_bounds__(256) critic_outgrad_kernel(const float* __restrict__ hL, const float* __restrict__ wout,
                                                              const float* __restrict__ up, float* __restrict__ vL,
@@ -619,6 +646,26 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
     return critic_forward_pass(net, h, out, batch, bf16, st);
 }
 
+// D values of TWO batches in one pass over the stacked rows [xa; xb] (the accuracy mean D(xg) - mean D(xd) after every critic
+// update, cwgan.py:505-507): every output row depends on its own input row alone and a forward GEMM is never split over K,
+// so the values are those of two separate forwards, bit for bit, for one chain of launches instead of two.
+// out[na + nb]; ws as critic_forward with batch = na + nb (<= 2 max(na, nb): what the callers reserve).
+hipError_t critic_forward2(const float* params, const int* dims, int nlayers, const float* xa, const float* ca, int na,
+                           const float* xb, const float* cb, int nb, int hide_cell_type, float* out, float* ws, bool bf16,
+                           hipStream_t st, float leak) {
+    CriticNet net;
+    if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
+    if ((ca == nullptr) != (cb == nullptr) && na > 0 && nb > 0) return hipErrorInvalidValue;
+    const int nc = (ca || cb) ? 3 : 0, nx = dims[0] - nc, batch = na + nb;
+    if (batch == 0) return hipSuccess;
+    float* h[10];
+    float* p = ws;
+    for (int l = 0; l <= nlayers; ++l) { h[l] = p; p += (long)batch * dims[l]; }
+    if (na > 0) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)na * dims[0])), dim3(256), 0, st, xa, ca, h[0], na, nx, hide_cell_type, nc);
+    if (nb > 0) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nb * dims[0])), dim3(256), 0, st, xb, cb, h[0] + (long)na * dims[0], nb, nx, hide_cell_type, nc);
+    return critic_forward_pass(net, h, out, batch, bf16, st);
+}
+
 // The two halves of a critic update -- the Wasserstein term on [xg; xd] and the gradient penalty on xp -- are independent
 // chains of ~20 small launches each (forward, backward chain, weight gradients), latency-bound one after the other: the
 // penalty half runs on a second stream beside the first (fork behind the inputs, join in front of the final sums), and the
@@ -666,9 +713,12 @@ static hipStream_t critic_grad_stream(CriticFork* fk, hipStream_t st) { return f
 hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
                             const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
                             float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* ws, bool bf16,
-                            hipStream_t st, float leak) {
+                            hipStream_t st, float leak, const float* eps, float* xp_out) {
+    // eps != nullptr: xp is not an input -- it is formed here, together with the three input blocks, in one launch (xp_out
+    // receives it; ng = nd = np and ONE condition array for the three inputs: the single-process critic step)
     CriticNet net;
     if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
+    if (eps && (!xp_out || ng != nd || nd != np || cg != cd || cd != cp)) return hipErrorInvalidValue;
     hipError_t e;
     const int nc = (cg || cd || cp) ? 3 : 0;
     if (nc && ((ng && !cg) || (nd && !cd) || (np && !cp))) return hipErrorInvalidValue;   // conditions for all inputs or for none
@@ -710,14 +760,19 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
         }
         ~JoinScope() { (void)join(); }
     } join_scope{fk, st};
+    if (eps)        // (in front of the fork: the penalty half reads hp[0])
+        hipLaunchKernelGGL(critic_step_inputs_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, xd, cg, eps, xp_out,
+                           h[0], hp[0], ng, nx, hide_cell_type, nc);
     if (fk) {
         if ((e = hipEventRecord(fk->fork, st)) != hipSuccess) return e;          // behind the memset and everything the caller queued
         join_scope.forked = true;
         if ((e = hipStreamWaitEvent(fk->aux, fk->fork, 0)) != hipSuccess) return e;
         sp = fk->aux;
     }
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type, nc);
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type, nc);
+    if (!eps) {
+        hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type, nc);
+        hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type, nc);
+    }
     if ((e = critic_forward_pass(net, h, dvals, bgd, bf16, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dvals, stats, ng, nd);
     hipLaunchKernelGGL(fill_updown_kernel, dim3(blocks_for(bgd)), dim3(256), 0, st, up, ng, nd);
@@ -735,7 +790,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     if ((e = critic_backward_chain(net, h, v, bgd, grads, false, bf16, st, fk)) != hipSuccess) return e;
 
     // ---------------- (2) gradient penalty on xp ------------------------------------------------
-    hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, sp, xp, cp, hp[0], np, nx, hide_cell_type, nc);
+    if (!eps) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, sp, xp, cp, hp[0], np, nx, hide_cell_type, nc);
     if ((e = critic_forward_pass(net, hp, dp, np, bf16, sp)) != hipSuccess) return e;
     // input gradient g = dD/dh0 per sample: v_L = m_L * w_out, chain down to vp[0]
     hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)np * dims[L])), dim3(256), 0, sp, hp[L], net.wout, (const float*)nullptr, vp[L], np, dims[L], net.leak);

@@ -147,10 +147,13 @@ struct OptArgs {
 size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);
 hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
                           int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st, float leak = 0.f);
+hipError_t critic_forward2(const float* params, const int* dims, int nlayers, const float* xa, const float* ca, int na,
+                           const float* xb, const float* cb, int nb, int hide_cell_type, float* out, float* ws, bool bf16,
+                           hipStream_t st, float leak = 0.f);
 hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
                             const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
                             float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* ws, bool bf16,
-                            hipStream_t st, float leak = 0.f);
+                            hipStream_t st, float leak = 0.f, const float* eps = nullptr, float* xp_out = nullptr);
 // (leak: slope of the hidden nonlinearity below zero -- 0 rectify, 0.01 leaky_rectify, 1/3 very_leaky_rectify, 1 linear)
 hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
                              int hide_cell_type, float scale, float* gx, float* stats, float* ws, bool bf16, hipStream_t st,
