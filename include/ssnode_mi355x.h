@@ -395,7 +395,8 @@ typedef struct ssn_opt_params {
     int kind;                 /* 0 sgd, 1 adam, 2 rmsprop (lasagne.updates) */
     int step;                 /* 1-based update count (adam bias correction) */
     int clip;                 /* clamp the new value to [clip_lo, clip_hi] (wgan.py:244-251) */
-    int reserved;
+    int reserved;             /* bit 0 (ssn_gen_apply_f32 with a record, n <= 64): make NO update when any gradient element is not
+                               * finite -- parameters and optimizer state stay, record = the old values, record[n] = NaN */
     double learning_rate, beta1, beta2, epsilon, rho;
     double reg_l2_penalty, reg_l1_penalty, reg_l2_decay, reg_l1_decay;   /* wgan.py:121-129 */
     double clip_lo, clip_hi;

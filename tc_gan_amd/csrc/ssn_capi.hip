@@ -811,6 +811,7 @@ static int optimizer_step_full(float* p, const float* g, float* s1, float* s2, l
     a.l2_penalty = (float)o->reg_l2_penalty; a.l1_penalty = (float)o->reg_l1_penalty;
     a.l2_decay = (float)o->reg_l2_decay; a.l1_decay = (float)o->reg_l1_decay;
     a.clip = o->clip; a.clip_lo = (float)o->clip_lo; a.clip_hi = (float)o->clip_hi;
+    a.skip_nonfinite = (o->reserved & 1) && n <= 64 && record;        // ssn_opt_params.reserved bit 0 (ssn_gen_apply_f32)
     SSN_TRY(ssn::optimizer_step(a, (hipStream_t)stream));
     return 0;
 }

@@ -900,6 +900,15 @@ __global__ void __launch_bounds__(256) optimizer_kernel(OptArgs o) {
     // (compared in fp32, the precision in which the caller reads the penalty back: host and device take the same decision;
     // NaN compares false: the update is made, as cwgan.py:494 does)
     if (o.gate && (float)*o.gate > (float)o.gate_bound) return;
+    if (o.skip_nonfinite) {                    // (every thread reads the few gradient elements: one verdict for the launch)
+        bool bad = false;
+        for (long e = 0; e < o.n; ++e) bad = bad || !(fabsf(o.g[e]) <= 3.402823466e38f);
+        if (bad) {
+            for (long e = blockIdx.x * 256L + threadIdx.x; e < o.n; e += gridDim.x * 256L)
+                if (o.record) { o.record[e] = o.p[e]; if (e == 0) o.record[o.n] = __builtin_nanf(""); }
+            return;
+        }
+    }
     for (long e = blockIdx.x * 256L + threadIdx.x; e < o.n; e += gridDim.x * 256L) {
         const float p0 = o.p[e];
         float g = o.g[e];

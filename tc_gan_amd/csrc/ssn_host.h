@@ -143,6 +143,10 @@ struct OptArgs {
     // new value, record[n] = *record_tail (the step's loss), written by the thread of element 0
     const float* clip_lo_v = nullptr; const float* clip_hi_v = nullptr;
     float* record = nullptr; const float* record_tail = nullptr;
+    // the whole update is skipped when any of the n gradient elements is not finite (n <= 64: the generator's handful of
+    // parameters): parameters and optimizer state stay, record[e] = the old values, record[n] = NaN -- the caller recomputes
+    // the gradient (a draw whose fp16 adjoint outgrew its scale) and applies that
+    int skip_nonfinite = 0;
 };
 size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);
 hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,

@@ -504,6 +504,7 @@ class ConditionalBPTTWassersteinGAN(object):
             nb = xg.shape[0]
             gx, dmean = self.disc.input_grad(xg, cd, scale=-1.0 / nb)           # d(-mean D)/d tuning curve
             if fused is not None:
+                self._gen_step_now = getattr(info, 'gen_step', '?')
                 host = self._train_generator_tail(fused, gx, dmean)
                 info.gen_loss = float(host[-1])
                 if not np.isfinite(host).all():
@@ -616,18 +617,40 @@ class ConditionalBPTTWassersteinGAN(object):
             if cached is None or cached.shape != value.shape or not np.array_equal(cached, value):
                 self._gparams[name].copy_(to_device(np.ascontiguousarray(value, dtype='float32').ravel()))
         u0 = self.gen_updaters[self._pnames[0]]
-        _, _, opt = u0.begin_step(st['flat'][:self._gparams[self._pnames[0]].numel()])
-        opt.clip = 0
-        clib.check(clib.libssnode.ssn_gen_apply_f32(st['flat'].data_ptr(), gl.data_ptr(), st['m'].data_ptr(), st['v'].data_ptr(),
-                                                    st['n'], ctypes.byref(opt), st['lo'].data_ptr(), st['hi'].data_ptr(),
-                                                    st['record'].data_ptr(), clib.stream_ptr()), 'ssn_gen_apply_f32')
-        for name in self._pnames:
-            self.gen_updaters[name].commit_step(opt)
+
+        def apply(gl, gate):
+            _, _, opt = u0.begin_step(st['flat'][:self._gparams[self._pnames[0]].numel()])
+            opt.clip = 0
+            opt.reserved = int(gate)          # bit 0: no update at all when a gradient element is not finite (record[n] = NaN)
+            clib.check(clib.libssnode.ssn_gen_apply_f32(st['flat'].data_ptr(), gl.data_ptr(), st['m'].data_ptr(), st['v'].data_ptr(),
+                                                        st['n'], ctypes.byref(opt), st['lo'].data_ptr(), st['hi'].data_ptr(),
+                                                        st['record'].data_ptr(), clib.stream_ptr()), 'ssn_gen_apply_f32')
+            return opt
+
+        opt = apply(gl, gate=True)
         tail = [st['record']] + ([carry.to(torch.float32)] if carry is not None else [])
         host = (torch.cat(tail) if len(tail) > 1 else tail[0]).cpu().numpy()
-        self._arrived_with_gen = None
+        arrived = None
         if carry is not None:
-            self._arrived_with_gen, host = float(host[-1]), host[:-1]
+            arrived, host = float(host[-1]), host[:-1]
+        if np.isnan(host[-1]) and np.isfinite(host[:-1]).all() and self.gen.__dict__.get('_retry') is not None:
+            # The update was withheld: the summed gradient is not finite.  With the fp16-split adjoint that is what a draw whose
+            # adjoint grows by more than 2^8 within one Euler step gives (unstable dynamics: NaN by construction, never a
+            # clamped value); the reference's fp32 arithmetic carries such a draw's large finite gradient.  So does the fp32
+            # sweep: the step is made again on it -- forward, adjoint, dL/dW -- and THAT gradient is applied, whatever it is.
+            bad = self.gen.poisoned_draws()
+            logger.warning('generator step %s: %d draws have an adjoint that grew by more than 2^8 within one Euler step, beyond '
+                           'the lagged scale of the fp16-split sweep; the step is recomputed on the fp32 kernels (gen_kernel '
+                           'mfma-fp32 runs every step there)', getattr(self, '_gen_step_now', '?'), bad)
+            pieces = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, raw=True, exact=True)
+            gl = genops.gen_grads(pieces['parts'], dmean, self.gen.last_penalties, self.dynamics_cost, self.rate_cost,
+                                  nv=pieces['nv'], g_ext=pieces.get('g_ext'), ext_base=pieces.get('ext_base'), zin=pieces.get('zin'))
+            self.reducer.mean_(gl)
+            opt = apply(gl, gate=False)
+            host = st['record'].cpu().numpy()
+        for name in self._pnames:
+            self.gen_updaters[name].commit_step(opt)
+        self._arrived_with_gen = arrived
         off = 0
         for name in self._pnames:
             shape = np.shape(getattr(self.gen, name))

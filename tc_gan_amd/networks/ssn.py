@@ -485,10 +485,11 @@ class TuningCurveGenerator(object):
         vals.append(tc)
         out = self.OutType(*vals)
         if save:
-            self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr, zin=self._zin, ext_base=self._ext_base)
+            self._saved = dict(fwd=fwd, W=W, z=z, gp=gp, ids=ids, probes=pr, zin=self._zin, ext_base=self._ext_base, ext=ext,
+                               theta=theta)
         return out
 
-    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False, raw=False):
+    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False, raw=False, exact=False):
         """BPTT: gradient of  sum(g_tuning_curve * tuning_curve) + dynamics_cost * dynamics_penalty
         + rate_cost * rate_penalty  w.r.t. the generator parameters (dict: J, D, S[, V]), for the last
         ``forward(save=True)`` call.  float64 numpy arrays by default; with ``as_tensor=True`` float64 CUDA tensors
@@ -496,6 +497,16 @@ class TuningCurveGenerator(object):
         ``raw=True``: the pieces `genops.gen_grads` turns into the flat gradient vector in one launch -- dict(parts (B, 4, 3)
         float64, nv[, g_ext, ext_base, zin]) -- instead of the sums."""
         sv = self._saved
+        if exact:
+            # the step again on the fp32 kernels, forward included (the split sweep has overwritten f' with its deltas): the
+            # gradient the reference's fp32 arithmetic gives where the fp16-split adjoint refuses (a draw whose adjoint grows
+            # by more than 2^8 within one step -- unstable dynamics -- is NaN there by construction)
+            sv = self._retry
+            gp = genops.make_gen_params(io_type=self.io_type, k=self.k, n=self.n, tau_E=self.tau_E, tau_I=self.tau_I, dt=self.dt,
+                                        seqlen=self.seqlen, skip_steps=self.skip_steps, rate_penalty_threshold=sv['theta'],
+                                        kernel=clib.GEN_KERNELS['mfma-fp32'])
+            probe = (sv['ids'], sv['probes']) if self.conditional else None
+            sv = dict(sv, gp=gp, fwd=genops.gen_forward(sv['W'], sv['ext'], gp, save=True, **({'probe': probe} if probe else {})))
         fwd = sv['fwd']
         g = g_tuning_curve.to(fwd['time_avg'].dtype)
         if self.conditional:
@@ -513,7 +524,7 @@ class TuningCurveGenerator(object):
             g_ta = torch.zeros_like(fwd['time_avg'])
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
         c_dyn, c_rate = dynamics_cost / max(fwd['n_dyn'], 1), rate_cost / fwd['n_rate']
-        if self.fused_backward:
+        if self.fused_backward and not exact:
             B, NB, _, M = fwd['traj'].shape
             xmax = genops.rate_bound(sv['gp'])
             if self.dtype != 'float32' or not genops.gen_backward_fused_supported(B, NB, M, sv['gp'], xmax):
@@ -527,13 +538,16 @@ class TuningCurveGenerator(object):
                                       want_g_ext=self.heteroin, want_dmax=True)
             delta, g_ext, dmax = res if self.heteroin else (res[0], None, res[1])
             # (kept for `poisoned_draws`: a draw whose adjoint outgrew the fp16 sweep's lagged scale has NaN here)
-            self.last_dmax = dmax
+            if not exact:
+                self.last_dmax = dmax
             # (fp16 two-part form of dL/dW where the sweep handed over max |delta| per draw and the rates are bounded)
             gW = genops.weight_grad(delta, fwd['traj'], dmax=dmax, xmax=genops.rate_bound(sv['gp']))
         if raw:
             pieces = dict(parts=genops.jds_grad_parts(gW, sv['z'], self.J, self.D, self.S), nv=0)
             if self.heteroin:
                 pieces.update(nv=2 if self.ssn_type == 'heteroin' else 1, g_ext=g_ext, ext_base=sv['ext_base'], zin=sv['zin'])
+            # (what a second pass on the fp32 kernels needs, should this one turn out poisoned: references, no copies)
+            self._retry = None if exact else {k: sv[k] for k in ('W', 'z', 'ids', 'probes', 'zin', 'ext_base', 'ext', 'theta')}
             self._saved = None
             return pieces
         gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S, as_tensor=as_tensor)

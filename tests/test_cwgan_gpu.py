@@ -342,28 +342,44 @@ def test_conditional_tuning_curves_vs_fixed_point_dataset(truth_size, probes_per
 def test_poisoned_generator_gradient_is_not_hidden_by_the_parameter_bounds(tail, caplog):
     """a draw whose fp16 adjoint outgrows its scale makes the summed gradient NaN; the optimizer's clip used to turn
     the NaN update into the lower bound (fmaxf(NaN, lo) = lo), so the parameters stayed finite, the loss stayed finite and
-    nothing reported.  The clip now keeps NaN as Theano's does (wgan.py:244-251: a switch on comparisons): the generator step
-    returns non-finite parameters, the drivers' NaN guards see them, and the loop says how many draws were poisoned."""
+    nothing reported.  Now: the clip keeps NaN as Theano's does (wgan.py:244-251: a switch on comparisons) -- the
+    parameter-by-parameter tail returns non-finite parameters, the drivers' NaN guards see them, the loop says how many draws
+    were poisoned -- and the default tail withholds the update (device-side gate: parameters and Adam state untouched), makes
+    the step again on the fp32 kernels (forward, adjoint, dL/dW: what `gen_kernel mfma-fp32` runs every step, and what the
+    reference's fp32 arithmetic does with such a draw) and applies THAT gradient."""
     import logging
     from argparse import Namespace
     from tc_gan_amd.networks.cwgan import make_gan
-    cfg = dict(TEST_PARAMS, num_sites=60, num_models=4, probes_per_model=1, seqlen=60, skip_steps=40,
-               bandwidths=[0.0625, 0.125, 0.25, 0.5, 0.75, 1.0, 0.3, 0.4], contrasts=[20.], gen_kernel='duo', critic_iters=0)
-    if tail == 'per-parameter':
-        cfg['gen'] = dict(cfg['gen'], update_name='adam-wgan')
-    gan, _ = make_gan(cfg)
-    if tail == 'per-parameter':
-        gan.gen_updaters['J'].learning_rate *= 2          # updaters out of step with each other: the parameter-by-parameter tail
-    gan.set_dataset(_fake_data(gan, 9, np.random.RandomState(4)))
     from tc_gan_amd.utils import StopWatch
-    gan.gen_forward_watch, gan.gen_train_watch, gan.disc_train_watch = StopWatch(), StopWatch(), StopWatch()
-    batch = gan.next_minibatch()
-    prepared = gan._prepare_gen(batch)
-    assert (gan._gen_tail_fused() is not None) == (tail == 'fused')
-    gan.gen._saved['fwd']['df'][1, :, 50, :] *= 1e5        # one draw's f' at one step: its adjoint grows by 1e5 within a step
-    with caplog.at_level(logging.WARNING):
+
+    def step(kernel, poison):
+        cfg = dict(TEST_PARAMS, num_sites=60, num_models=4, probes_per_model=1, seqlen=60, skip_steps=40,
+                   bandwidths=[0.0625, 0.125, 0.25, 0.5, 0.75, 1.0, 0.3, 0.4], contrasts=[20.], gen_kernel=kernel, critic_iters=0)
+        cfg['gen'] = dict(cfg['gen'], update_name='adam-wgan')
+        gan, _ = make_gan(cfg)
+        if tail == 'per-parameter':
+            gan.gen_updaters['J'].learning_rate *= 2          # updaters out of step with each other: the parameter-by-parameter tail
+        gan.set_dataset(_fake_data(gan, 9, np.random.RandomState(4)))
+        gan.gen_forward_watch, gan.gen_train_watch, gan.disc_train_watch = StopWatch(), StopWatch(), StopWatch()
+        batch = gan.next_minibatch()
+        prepared = gan._prepare_gen(batch)
+        assert (gan._gen_tail_fused() is not None) == (tail == 'fused')
+        if poison:
+            gan.gen._saved['fwd']['df'][1, :, 50, :] *= 1e5        # one draw's f' at one step: its adjoint grows by 1e5 within a step
         info = gan.train_generator(Namespace(gen_step=0), batch, prepared)
+        return gan, info, np.concatenate([np.ravel(getattr(gan.gen, name)) for name in 'JDS'])
+
+    with caplog.at_level(logging.WARNING):
+        gan, info, values = step('duo', poison=True)
     assert gan.gen.poisoned_draws() == 1
-    values = np.concatenate([np.ravel(getattr(gan.gen, name)) for name in 'JDS'])
-    assert not np.isfinite(values).all()                  # ... and not the lower bound 1e-3
-    assert any('adjoint' in rec.getMessage() and '1 of 4 draws' in rec.getMessage() for rec in caplog.records)
+    if tail == 'per-parameter':
+        assert not np.isfinite(values).all()                  # ... and not the lower bound 1e-3
+        assert any('adjoint' in rec.getMessage() and '1 of 4 draws' in rec.getMessage() for rec in caplog.records)
+        return
+    assert any('recomputed on the fp32 kernels' in rec.getMessage() and '1 draws' in rec.getMessage() for rec in caplog.records)
+    # the step that was applied is the fp32 kernels' step on the unpoisoned problem (the second pass recomputes f' from the
+    # forward), Adam state and step count those of ONE update
+    _, info32, want = step('mfma-fp32', poison=False)
+    assert np.isfinite(values).all() and np.isfinite(info.gen_loss)
+    np.testing.assert_allclose(values, want, rtol=1e-5, atol=1e-7)
+    assert all(gan.gen_updaters[name].step == 1 for name in gan._pnames)
