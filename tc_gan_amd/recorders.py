@@ -10,6 +10,33 @@ def _host(x):
     return x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
 
 
+#: The typed tables of a run as DATA (tc_gan/recorders.py:113-362: same table names, column names and dtypes, so that the
+#: reference's loaders read them).  key -> (table name, leading columns, patterns of the tail).  A tail pattern is formatted
+#: once per item of the table's variable part, pattern by pattern: the moment conditions, the bandwidths, the generator's
+#: flat parameter names, the critic's parameter tensors (`table_dtype`).
+TABLES = {
+    'learning': ('learning', [('gen_step', 'uint32'), ('Gloss', 'double'), ('Dloss', 'double'), ('Daccuracy', 'double'),
+                              ('gen_forward_time', 'double'), ('gen_train_time', 'double'), ('disc_time', 'double'),
+                              ('rate_penalty', 'double'), ('dynamics_penalty', 'double')], ()),
+    'mm_learning': ('learning', [('step', 'uint32'), ('loss', 'double'), ('rate_penalty', 'double'),
+                                 ('dynamics_penalty', 'double'), ('train_time', 'double')], ()),
+    'gen_moments': ('gen_moments', [('step', 'uint32')], ('mean_{}', 'var_{}')),
+    'disc_learning': ('disc_learning', [('gen_step', 'uint32'), ('disc_step', 'uint32'), ('Dloss', 'double'),
+                                        ('Daccuracy', 'double'), ('SSsolve_time', 'double'), ('gradient_time', 'double'),
+                                        ('model_convergence', 'uint32'), ('model_unused', 'uint32')], ()),
+    'generator': ('generator', [('gen_step', 'uint32')], ('{}',)),
+    'disc_param_stats': ('disc_param_stats', [('gen_step', 'uint32'), ('disc_step', 'uint32')], ('{}',)),
+    'tc_stats': ('tc_stats', [('gen_step', 'uint32'), ('is_fake', 'b'), ('contrast', 'double'), ('norm_probe', 'double'),
+                              ('cell_type', 'uint16'), ('count', 'uint32')], ('mean_{}', 'var_{}')),
+}
+
+
+def table_dtype(key, items=()):
+    """The numpy dtype of table `key`: its leading columns, then one 'double' column per (tail pattern, item)."""
+    _, lead, tail = TABLES[key]
+    return np.dtype(list(lead) + [(pat.format(it), 'double') for pat in tail for it in items])
+
+
 class HDF5Recorder(object):
     """recorders.py:62-110."""
 
@@ -47,10 +74,8 @@ class HDF5Recorder(object):
 class LearningRecorder(HDF5Recorder):
     """recorders.py:113-147."""
 
-    tablename = 'learning'
-    dtype = np.dtype([('gen_step', 'uint32'), ('Gloss', 'double'), ('Dloss', 'double'), ('Daccuracy', 'double'),
-                      ('gen_forward_time', 'double'), ('gen_train_time', 'double'), ('disc_time', 'double'),
-                      ('rate_penalty', 'double'), ('dynamics_penalty', 'double')])
+    tablename = TABLES['learning'][0]
+    dtype = table_dtype('learning')
 
     def record(self, gen_step, update_result):
         info, disc_info = update_result.info, update_result.disc_info
@@ -65,9 +90,8 @@ class LearningRecorder(HDF5Recorder):
 class MMLearningRecorder(HDF5Recorder):
     """recorders.py:150-172."""
 
-    tablename = 'learning'
-    dtype = np.dtype([('step', 'uint32'), ('loss', 'double'), ('rate_penalty', 'double'),
-                      ('dynamics_penalty', 'double'), ('train_time', 'double')])
+    tablename = TABLES['mm_learning'][0]
+    dtype = table_dtype('mm_learning')
 
     def record(self, gen_step, update_result):
         self._saverow([gen_step, update_result.loss, update_result.rate_penalty, update_result.dynamics_penalty,
@@ -81,15 +105,13 @@ class MMLearningRecorder(HDF5Recorder):
 class GenMomentsRecorder(HDF5Recorder):
     """recorders.py:175-199: minibatch mean and variance of every moment condition."""
 
-    tablename = 'gen_moments'
+    tablename = TABLES['gen_moments'][0]
     dedicated = True
 
     def __init__(self, datastore, num_mom_conds):
         super(GenMomentsRecorder, self).__init__(datastore)
         self.num_mom_conds = num_mom_conds
-        self.dtype = np.dtype([('step', 'uint32')] +
-                              [('mean_{}'.format(i), 'double') for i in range(num_mom_conds)] +
-                              [('var_{}'.format(i), 'double') for i in range(num_mom_conds)])
+        self.dtype = table_dtype('gen_moments', range(num_mom_conds))
 
     def record(self, gen_step, update_result):
         self._saverow([gen_step] + list(np.asarray(update_result.gen_moments).flat))
@@ -102,21 +124,19 @@ class GenMomentsRecorder(HDF5Recorder):
 class DiscLearningRecorder(HDF5Recorder):
     """recorders.py:202-214."""
 
-    tablename = 'disc_learning'
-    dtype = np.dtype([('gen_step', 'uint32'), ('disc_step', 'uint32'), ('Dloss', 'double'), ('Daccuracy', 'double'),
-                      ('SSsolve_time', 'double'), ('gradient_time', 'double'), ('model_convergence', 'uint32'),
-                      ('model_unused', 'uint32')])
+    tablename = TABLES['disc_learning'][0]
+    dtype = table_dtype('disc_learning')
 
 
 class FlexGenParamRecorder(HDF5Recorder):
     """recorders.py:243-272: one column per flat generator parameter."""
 
-    tablename = 'generator'
+    tablename = TABLES['generator'][0]
 
     def __init__(self, datastore, gan):
         self.gan = gan
         super(FlexGenParamRecorder, self).__init__(datastore)
-        self.dtype = np.dtype([('gen_step', 'uint32')] + [(n, 'double') for n in gan.gen.get_flat_param_names()])
+        self.dtype = table_dtype('generator', gan.gen.get_flat_param_names())
 
     def record(self, gen_step):
         self._saverow([gen_step] + list(self.gan.gen.get_flat_param_values()))
@@ -130,14 +150,12 @@ class FlexGenParamRecorder(HDF5Recorder):
 class DiscParamStatsRecorder(HDF5Recorder):
     """recorders.py:275-311: normalised norm of every critic parameter tensor per critic step."""
 
-    tablename = 'disc_param_stats'
+    tablename = TABLES['disc_param_stats'][0]
 
     def __init__(self, datastore, discriminator):
         self.discriminator = discriminator
         super(DiscParamStatsRecorder, self).__init__(datastore)
-        self.dtype = np.dtype([('gen_step', 'uint32'), ('disc_step', 'uint32')] +
-                              [(name, 'double') for name in
-                               self.disc_param_unique_names(discriminator.get_param_names())])
+        self.dtype = table_dtype('disc_param_stats', self.disc_param_unique_names(discriminator.get_param_names()))
 
     @staticmethod
     def disc_param_unique_names(names):
@@ -162,16 +180,13 @@ class DiscParamStatsRecorder(HDF5Recorder):
 class ConditionalTuningCurveStatsRecorder(HDF5Recorder):
     """recorders.py:314-362: per condition mean/variance of real and generated tuning curves."""
 
-    tablename = 'tc_stats'
+    tablename = TABLES['tc_stats'][0]
     dedicated = True
 
     def __init__(self, datastore, num_bandwidths):
         super(ConditionalTuningCurveStatsRecorder, self).__init__(datastore)
         self.num_bandwidths = num_bandwidths
-        self.dtype = np.dtype([('gen_step', 'uint32'), ('is_fake', 'b'), ('contrast', 'double'),
-                               ('norm_probe', 'double'), ('cell_type', 'uint16'), ('count', 'uint32')] +
-                              [('mean_{}'.format(i), 'double') for i in range(num_bandwidths)] +
-                              [('var_{}'.format(i), 'double') for i in range(num_bandwidths)])
+        self.dtype = table_dtype('tc_stats', range(num_bandwidths))
 
     @staticmethod
     def analyze(tuning_curves, conditions):

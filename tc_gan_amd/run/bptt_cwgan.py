@@ -6,7 +6,6 @@ Mirror of ``tc_gan/run/bptt_cwgan.py``: same options, same config flow
 """
 from logging import getLogger
 
-from . import bptt_wgan
 from .. import utils
 from ..drivers import BPTTcWGANDriver
 from ..networks.cwgan import make_gan
@@ -16,21 +15,9 @@ logger = getLogger(__name__)
 
 
 def make_parser():
-    import argparse
-
-    class CustomFormatter(argparse.RawDescriptionHelpFormatter, argparse.ArgumentDefaultsHelpFormatter):
-        pass
-
-    parser = argparse.ArgumentParser(formatter_class=CustomFormatter, description=__doc__)
-    parser.add_argument('--num-models', default=15, type=int, help='Number of SSN to be instantiated (aka NZ).')
-    parser.add_argument('--probes-per-model', default=1, type=int)
-    parser.add_argument('--norm-probes', '--sample-sites', default=[0], type=utils.csv_line(float),
-                        help='Probe offsets in [-1, 1] "bandwidth coordinate".')
-    parser.add_argument('--tc-stats-record-interval', default=100, type=int)
-    bptt_wgan.add_bptt_common_options(parser)
-    bptt_wgan.add_learning_options(parser)
-    parser.set_defaults(datastore_template='logfiles/BPTT_CWGAN_{layers_str}')
-    return parser
+    """bptt_cwgan.py:17-53: the option table lives in `run/options.py` (rows marked 'c')."""
+    from . import options
+    return options.build_parser('c', __doc__)
 
 
 def init_driver(datastore, iterations, quit_JDS_threshold, quiet, tc_stats_record_interval,

@@ -9,7 +9,7 @@ from logging import getLogger
 
 import numpy as np
 
-from .. import clib, execution, ssnode, utils
+from .. import execution, ssnode, utils
 from ..networks.dataset import generate_dataset
 from ..networks.fixed_time_sampler import new_JDS
 from ..drivers import BPTTWGANDriver
@@ -35,93 +35,9 @@ def learn(driver, **generate_dataset_kwargs):
 
 
 def make_parser():
-    """bptt_wgan.py:46-72."""
-    import argparse
-
-    class CustomFormatter(argparse.RawDescriptionHelpFormatter, argparse.ArgumentDefaultsHelpFormatter):
-        pass
-
-    parser = argparse.ArgumentParser(formatter_class=CustomFormatter, description=__doc__)
-    parser.add_argument('--batchsize', '--n_samples', default=15, type=eval,
-                        help='Number of samples to draw from G each step (aka NZ, minibatch size).')
-    parser.add_argument('--sample-sites', default=[0], type=utils.csv_line(float),
-                        help='Locations (offsets) of neurons to be sampled from SSN in the "bandwidth" space [-1, 1].  '
-                             '0 means the center of the network.')
-    add_bptt_common_options(parser)
-    add_learning_options(parser)
-    parser.set_defaults(datastore_template='logfiles/BPTT_WGAN_{layers_str}')
-    return parser
-
-
-def add_bptt_common_options(parser):
-    """bptt_wgan.py:75-172."""
-    parser.add_argument('--truth_size', default=1000, type=int,
-                        help='Number of SSNs used to generate ground truth data (default: %(default)s)')
-    parser.add_argument('--truth_seed', default=42, type=int, help='Seed for the ground truth data')
-    parser.add_argument('--dataset-provider', default='ssnode', choices=('ssnode', 'fixedtime'),
-                        help='How the ground truth is generated (networks.dataset.generate_dataset)')
-    for prefix in ['gen', 'disc']:
-        parser.add_argument('--{}-learning-rate'.format(prefix), '--{}-learn-rate'.format(prefix), default=0.01,
-                            type=float, help='{} learning rate (default: %(default)s)'.format(prefix))
-        parser.add_argument('--{}-update-name'.format(prefix), default='adam-wgan',
-                            help='{} update method (default: %(default)s)'.format(prefix))
-    parser.add_argument('--seqlen', default=DEFAULT_PARAMS['seqlen'], type=int, help='Total time steps for SSN.')
-    parser.add_argument('--skip-steps', default=DEFAULT_PARAMS['skip_steps'], type=int,
-                        help='First time steps excluded from tuning curve and dynamics penalty.')
-    parser.add_argument('--contrasts', '--contrast', default=[20], type=utils.csv_line(float))
-    parser.add_argument('--include-inhibitory-neurons', action='store_true')
-    parser.add_argument('--unroll-scan', action='store_true', help='Accepted for compatibility; no effect.')
-    for name in 'JDS':
-        parser.add_argument('--gen-{}-min'.format(name), default=1e-3, type=float)
-        parser.add_argument('--gen-{}-max'.format(name), default=10, type=float)
-        parser.add_argument('--{}0'.format(name), default=0.01, type=eval,
-                            help='Initial value of the generator parameter {}.'.format(name))
-    parser.add_argument('--gen-dynamics-cost', type=float, default=1)
-    parser.add_argument('--disc-layers', '--layers', default=[], type=eval)
-    parser.add_argument('--disc-normalization', default='none', choices=('none', 'layer'))
-    parser.add_argument('--disc-nonlinearity', default='rectify')
-    parser.add_argument('--disc-precision', default='fp32', choices=('bf16', 'fp32'),
-                        help='MFMA operand precision of the critic GEMMs (new).  fp32 (default) keeps the reference\'s '
-                             'floatX arithmetic; bf16 is the explicit fast mode (fp32 accumulation, ~1e-2 relative on '
-                             'the critic loss and gradients)')
-    parser.add_argument('--lipschitz-cost', '--WGAN_lambda', default=10.0, type=float)
-    parser.add_argument('--critic-iters-init', '--WGAN_n_critic0', default=50, type=int)
-    parser.add_argument('--critic-iters', '--WGAN_n_critic', default=5, type=int)
-    parser.add_argument('--ssn-type', default='default', choices=('default', 'heteroin', 'deg-heteroin'),
-                        help='SSN variant (the reference sets it through --load-config)')
-    parser.add_argument('--gen-kernel', default='auto', choices=tuple(clib.GEN_KERNELS),
-                        help='Kernel family of the generator forward / adjoint (new; recorded in info.json).  auto (default): '
-                             'the library\'s choice -- for float32 with >= 4 bandwidths and enough models the fp16-split '
-                             'matrix-core kernels (W and the state enter the products with 23 significant bits, exact '
-                             'products, fp32 accumulation: within the fp32 kernels\' own distance from fp64); mfma-fp32 or '
-                             'tile: fp32 operands (the reference\'s floatX arithmetic); the others name one kernel.  '
-                             'The fp16-split adjoint scales each step by the previous step\'s largest |delta|; a draw whose '
-                             'adjoint grows more than 2^8 within one step makes its gradient NaN (never a clamped finite value) '
-                             'and the run logs how many draws did -- mfma-fp32 has no such limit')
-    parser.add_argument('--z-device-seed', default=None, type=int,
-                        help='Draw z from a Philox4x32-10 stream of this seed (sharded over the ranks) instead of the '
-                             'RandomState the reference draws it from (new; ANOTHER noise stream, no host round trip at all)')
-    parser.add_argument('--z-host-draw', action='store_true',
-                        help='Draw z = rng.rand(batch, 2N, 2N) with numpy on the host, as the reference does.  Default: the '
-                             'same RandomState stream continued on the device, bit for bit (ssn_mt19937_random_sample_*)')
-
-
-def add_learning_options(parser):
-    """run/gan.py:1109-1152."""
-    parser.add_argument('--iterations', default=100000, type=int)
-    parser.add_argument('--quit-JDS-threshold', default=-1, type=float)
-    parser.add_argument('--quiet', action='store_true')
-    parser.add_argument('--disc-param-save-interval', default=5, type=int)
-    parser.add_argument('--disc-param-template', default='last.npz')
-    parser.add_argument('--disc-param-save-on-error', action='store_true')
-    parser.add_argument('--checkpoint-interval', default=-1, type=int,
-                        help='Write <datastore>/checkpoint.pkl (parameters, optimizer states, RNG states) every given '
-                             'generator step; -1 never (new)')
-    parser.add_argument('--resume-from', default=None,
-                        help='checkpoint.pkl of an earlier run to continue from: --iterations stays the TOTAL count (new)')
-    parser.add_argument('--n_bandwidths', default=4, type=int, choices=(1, 4, 5, 8))
-    parser.add_argument('--load-gen-param', help='generator.csv whose last row is the starting point.')
-    execution.add_base_learning_options(parser)
+    """bptt_wgan.py:46-172 + run/gan.py:1109-1152: the option table lives in `run/options.py` (rows marked 'w')."""
+    from . import options
+    return options.build_parser('w', __doc__)
 
 
 _BANDWIDTHS = {1: [0.0625], 4: [0.0625, 0.125, 0.25, 0.75], 5: [0.0625, 0.125, 0.25, 0.5, 0.75],
