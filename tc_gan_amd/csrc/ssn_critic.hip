@@ -190,6 +190,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(SplitKReduceArgs a) 
 // flight per thread), LDS is double buffered and an iteration has one barrier.
 // ---------------------------------------------------------------------------------
 typedef float gf4 __attribute__((ext_vector_type(4)));
+#ifndef SSN_GEMM_NO_XCD_DEAL
+#define SSN_GEMM_NO_XCD_DEAL 0     // 1: tiles in launch order (A/B builds)
+#endif
 // operand modes: 0 = k contiguous (16-byte vectors along k), 1 = m / n contiguous (vectors along m / n), 2 = any strides
 // (scalar loads, k fastest: the 11-wide input side of the first layer, whose extents are not multiples of four)
 template <int AMODE, int BMODE>
@@ -197,7 +200,19 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
     constexpr int BM = 64, BN = 64, BK = 64, LDK = BK + 8, NST = 3;
     __shared__ __align__(16) unsigned short As[2][BM][LDK];
     __shared__ __align__(16) unsigned short Bs[2][BN][LDK];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // Workgroups go to the 8 XCDs round robin by their linear id, and each XCD has an L2 of its own.  With x (the column tile)
+    // running fastest and 8 column tiles, XCD k would compute column k of EVERY row tile: all of A through every L2.  The tiles
+    // are dealt so that an XCD gets a contiguous run of them (whole row tiles: 1 / 8 of A, all of B, once).  Same tiles, same
+    // arithmetic: the results do not change by a bit.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, tiles = gx * (int)gridDim.y;
+        if ((tiles & 7) == 0 && !SSN_GEMM_NO_XCD_DEAL) {
+            const int lin = by * gx + bx, t = (lin & 7) * (tiles >> 3) + (lin >> 3);
+            by = t / gx; bx = t - by * gx;
+        }
+    }
+    const int m0 = by * BM, n0 = bx * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int kbeg = blockIdx.z * g.kchunk;

@@ -61,3 +61,26 @@ def test_jump_polynomials_compose():
     once = mt.apply_jump(key, poly(4 * 5 + 256 * 3))
     twice = mt.apply_jump(mt.apply_jump(key, poly(256 * 3)), poly(4 * 5))
     assert (once[1:] == twice[1:]).all() and (once[0] ^ twice[0]) & np.uint32(0x80000000) == 0
+
+
+def test_device_continued_randomstate_resolves_a_pending_state_on_first_touch():
+    """`utils.DeviceContinuedRandomState` (what `as_randomstate(seed)` builds): same stream as numpy's RandomState; a deferred
+    state (the one a device draw will hand back) is installed the first time ANY public attribute is used, exactly once."""
+    from tc_gan_amd.utils import DeviceContinuedRandomState, as_randomstate
+    r, q = as_randomstate(5), np.random.RandomState(5)
+    assert isinstance(r, DeviceContinuedRandomState) and isinstance(r, np.random.RandomState)
+    assert as_randomstate(q) is q                      # an existing generator is passed through (cwgan.py:452 shares one)
+    assert (r.rand(4) == q.rand(4)).all()
+    calls = []
+    q.rand(1000)                                       # what the device draw consumes
+
+    def finish(rr):
+        calls.append(1)
+        np.random.RandomState.set_state(rr, q.get_state())
+    r._defer(finish)
+    assert not calls
+    assert (r.choice(100, 5) == q.choice(100, 5)).all() and calls == [1]
+    assert (r.rand(3) == q.rand(3)).all() and calls == [1]
+    r._defer(finish)                                   # get_state (checkpoints) resolves too
+    st = r.get_state()
+    assert calls == [1, 1] and (st[1] == q.get_state()[1]).all() and st[2] == q.get_state()[2]
