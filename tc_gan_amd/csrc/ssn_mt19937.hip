@@ -5,10 +5,11 @@
 // host RandomState is numpy's own after the same draw.
 //
 // MT19937 is one sequential recurrence (x[k+624] = x[k+397] ^ twist(x[k], x[k+1])).  The stream is cut into SEGMENTS of
-// 64 * step blocks of 624 words (step = 1, 2, 4, 8 by the size of the draw); a segment starts from a state so many blocks ahead of
-// the caller's, which is reached by jump-ahead polynomials (ssn_mt19937_poly.h): a ladder of levels with strides 64, 4096, 2^18,
-// 2^24 blocks, 63 polynomials per level (digit d = 1..63 times the stride), so that any segment state is at most one jump per
-// level away and all states of a level are computed by ONE launch from the states of the level above.
+// 128 * step blocks of 624 words (step = 1, 2, 4, 8 by the size of the draw); a segment starts from a state so many blocks ahead of
+// the caller's, which is reached by jump-ahead polynomials (ssn_mt19937_poly.h): a ladder of levels with strides 128, 2^15, 2^23
+// blocks, 255 polynomials per level (digit d = 1..255 times the stride; 0.15 s of host arithmetic and 10.7 MB of device memory per
+// level, at first use), so that any segment state is at most one jump per level away and all states of a level are computed by
+// ONE launch from the states of the level above: one round for draws up to 10 M doubles per unit of `step`, two beyond.
 //
 // The states (expand + jump) are computed on a stream of the library's own into the library's buffers, beside whatever the
 // caller's stream is still running; the caller's stream waits for them and runs the generation kernel alone.
@@ -38,10 +39,11 @@
 namespace ssn {
 namespace mt {
 
-constexpr int kLevels = 4;                 // strides 64 * 64^l blocks
-constexpr int kStride0Log2 = 6;
-constexpr int kRadixLog2 = 6;
-constexpr int kSegLevel = 0;               // segments start at states of level 0: every `step`-th one, 64 * step blocks long
+constexpr int kLevels = 3;                 // strides 128 * 256^l blocks
+constexpr int kStride0Log2 = 7;
+constexpr int kRadixLog2 = 8;              // 255 polynomials per level: up to 255 * 128 * step blocks (10 M doubles x step) in ONE round of jumps
+constexpr int kDigits = (1 << kRadixLog2) - 1;
+constexpr int kSegLevel = 0;               // segments start at states of level 0: every `step`-th one, 128 * step blocks long
 constexpr int kSoloParts = 16;             // workgroups of the kernel that computes the state after the draw
 // a polynomial's taps are cut into kShares index ranges of kShareSpan; one workgroup accumulates one share of one state
 constexpr int kShares = 4;
@@ -113,8 +115,8 @@ struct JumpArgs {
     long lo;                    // index (in units of this level's stride) of dst[0]; dst[k] is state lo + k * step
     int step;
     int sub;                    // workgroups per share (1, 2 or 4: few states -> more workgroups each)
-    const uint16_t* codes;      // this level: [63][kShares][kCodeCap] LDS byte offsets of the taps, padded with kZeroOff
-    const int* counts;          // [63][kShares], multiples of 128
+    const uint16_t* codes;      // this level: [kDigits][kShares][kCodeCap] LDS byte offsets of the taps, padded with kZeroOff
+    const int* counts;          // [kDigits][kShares], multiples of 128
 };
 
 // Two taps: the codes of a group of 128 sit in the wave's lanes (one dword = two uint16 LDS byte offsets per lane, fetched by a
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(320) void mt_jump_kernel(const JumpArgs a) {
     const int tid = threadIdx.x;
     const long n = a.lo + (long)blockIdx.x * a.step;
     const int f = blockIdx.y / a.sub, sb = blockIdx.y % a.sub;
-    const int d = (int)(n & 63);
+    const int d = (int)(n & kDigits);
     const uint32_t* xs = a.xseq + (size_t)((n >> kRadixLog2) - a.parent_lo) * kXSeq;
     uint32_t* out = a.dst + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * kN;
     if (d == 0) {            // the parent's own state: part 0 carries it (exact, low bits of word 0 included), the others nothing
@@ -398,8 +400,8 @@ struct HostTables {
     bool field_ok = false, field_tried = false;
     Poly base[kLevels];                                  // t^(624 * stride_l)
     bool have[kLevels] = {};
-    std::vector<uint16_t> codes[kLevels];                // [63][kShares][kCodeCap]
-    std::vector<int> counts[kLevels];                    // [63][kShares]
+    std::vector<uint16_t> codes[kLevels];                // [kDigits][kShares][kCodeCap]
+    std::vector<int> counts[kLevels];                    // [kDigits][kShares]
     bool ensure_field() {
         if (!field_tried) { field_tried = true; field_ok = field.init(); }
         return field_ok;
@@ -417,10 +419,10 @@ struct HostTables {
                 base[q] = base[q - 1];
                 for (int s = 0; s < kRadixLog2; ++s) base[q] = field.sqr(base[q]);
             }
-            codes[q].assign((size_t)63 * kShares * kCodeCap, (uint16_t)kZeroOff);
-            counts[q].assign(63 * kShares, 0);
+            codes[q].assign((size_t)kDigits * kShares * kCodeCap, (uint16_t)kZeroOff);
+            counts[q].assign(kDigits * kShares, 0);
             Poly p = base[q];
-            for (int d = 1; d <= 63; ++d) {
+            for (int d = 1; d <= kDigits; ++d) {
                 if (d > 1) p = field.mul(p, base[q]);
                 pack_codes(p, codes[q].data() + (size_t)(d - 1) * kShares * kCodeCap, counts[q].data() + (d - 1) * kShares);
             }
@@ -595,22 +597,23 @@ hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total,
     if (count) {
         const long b_lo = ((long)pos + 2 * (long)skip) / kN;
         b_hi = ((long)pos + 2 * (long)(skip + count) - 1) / kN;
-        // segment length 64 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
+        // segment length 128 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
         // workgroups per state, 768 at a time, ~70 us a round; a segment's workgroup generates a block in ~0.5 us
         double best = 1e30;
         for (int c = 1; c <= 8; c *= 2) {
-            const long nseg = (b_hi - b_lo + 64 * c) / (64 * c);
-            const double cost = 70.0 * (double)((4 * nseg + 767) / 768) + 0.5 * 64 * c;
+            const long len = (long)c << kStride0Log2;
+            const long nseg = (b_hi - b_lo + len) / len;
+            const double cost = 70.0 * (double)((4 * nseg + 767) / 768) + 0.5 * (double)len;
             if (cost < best) { best = cost; step = c; }
         }
         const long seg_blocks = (long)step << kStride0Log2;
         s_lo = b_lo >= 1 ? (b_lo - 1) / seg_blocks : 0;
         s_hi = b_hi >= 1 ? (b_hi - 1) / seg_blocks : 0;
     }
-    // levels needed: the top digit of the last segment must be < 64
+    // levels needed: the top digit of the last segment must be <= kDigits
     int top_b = count ? kSegLevel : -1;
     if (count)
-        while (((s_hi * step) >> (level_shift(top_b) - level_shift(kSegLevel))) >= 64) if (++top_b >= kLevels) return hipErrorInvalidValue;
+        while (((s_hi * step) >> (level_shift(top_b) - level_shift(kSegLevel))) > kDigits) if (++top_b >= kLevels) return hipErrorInvalidValue;
     DeviceTables* t = nullptr;
     hipError_t e = device_tables(top_b, &t);
     if (e != hipSuccess) return e;

@@ -45,8 +45,8 @@ def test_small_draws_bit_equal_numpy(seed, warm, shape):
 
 @pytest.mark.parametrize('warm', [0, 777])
 def test_segment_and_level_boundaries(warm):
-    # 64 * step blocks of 312 doubles per segment (step 1, 2, 4 by size); 64 states per stride of the level above: cross them
-    for n in (64 * 312 - 1, 64 * 312, 64 * 312 + 1, 3 * 64 * 312 + 17, 65 * 64 * 312 + 5, 256 * 312 + 1, 65 * 256 * 312 + 5, 2 * 64 * 64 * 312 + 77):
+    # 128 * step blocks of 312 doubles per segment (step 1, 2, 4, 8 by size); 256 states per stride of the level above: cross them
+    for n in (128 * 312 - 1, 128 * 312, 128 * 312 + 1, 3 * 128 * 312 + 17, 65 * 128 * 312 + 5, 256 * 312 + 1, 255 * 128 * 312 - 3, 256 * 128 * 312 + 77, 257 * 256 * 312 + 9):
         _check(5, warm, (n,), torch.float64)
 
 

@@ -3,10 +3,11 @@ mkdir -p gpurun_out
 rm -rf gpurun_out/soak
 python - <<'PY'
 import subprocess, sys, time, os, resource
+ZMODE = os.environ.get('ZMODE', '').split()      # default: the reference's noise stream continued on the device
 t0 = time.time()
 p = subprocess.run([sys.executable, 'run.py', 'tc_gan.run.bptt_cwgan', '--', '--datastore', 'gpurun_out/soak', '--iterations', '3000',
                     '--num-models', '32', '--n_bandwidths', '8', '--seqlen', '120', '--skip-steps', '100', '--disc-layers', '[64,64]',
-                    '--dataset-provider', 'fixedtime', '--truth_size', '256', '--z-device-seed', '7', '--disc-precision', 'bf16', '--critic-iters-init', '5', '--quiet',
+                    '--dataset-provider', 'fixedtime', '--truth_size', '256', *ZMODE, '--disc-precision', 'bf16', '--critic-iters-init', '5', '--quiet',
                     '--disc-param-save-interval', '500'], capture_output=True, text=True)
 print('rc', p.returncode, 'wall %.1f s' % (time.time() - t0))
 print(p.stderr[-600:])

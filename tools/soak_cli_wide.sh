@@ -6,10 +6,11 @@ mkdir -p gpurun_out
 rm -rf gpurun_out/soak_wide
 python - <<'PY'
 import subprocess, sys, time, os, resource
+ZMODE = os.environ.get('ZMODE', '').split()      # default: the reference's noise stream continued on the device
 t0 = time.time()
 p = subprocess.run([sys.executable, 'run.py', 'tc_gan.run.bptt_cwgan', '--', '--datastore', 'gpurun_out/soak_wide', '--iterations', '600',
                     '--num-models', '256', '--n_bandwidths', '8', '--seqlen', '120', '--skip-steps', '100', '--disc-layers', '[512,512,512]',
-                    '--dataset-provider', 'fixedtime', '--truth_size', '512', '--z-device-seed', '7', '--disc-precision', 'bf16', '--critic-iters-init', '5', '--quiet',
+                    '--dataset-provider', 'fixedtime', '--truth_size', '512', *ZMODE, '--disc-precision', 'bf16', '--critic-iters-init', '5', '--quiet',
                     '--disc-param-save-interval', '200'], capture_output=True, text=True)
 print('rc', p.returncode, 'wall %.1f s' % (time.time() - t0))
 print(p.stderr[-600:])
