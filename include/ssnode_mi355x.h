@@ -649,6 +649,10 @@ int ssn_mt19937_random_sample_begin_f32(const unsigned int *key, int pos, unsign
 int ssn_mt19937_random_sample_begin_f64(const unsigned int *key, int pos, unsigned long long total, unsigned long long skip,
                                         unsigned long long count, double *out, void *stream, int *ticket);
 int ssn_mt19937_random_sample_finish(int ticket, unsigned int *key, int *pos);
+/* Host arithmetic of a draw alone (no device): out[7] = {pos after the draw, regenerations of the key up to then, blocks per
+ * segment, first and last segment this call generates, first and last block that holds a wanted word} for the given pos /
+ * total / skip / count -- what the CPU tests check against numpy's own positions, rank by rank. */
+int ssn_mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long *out);
 
 #ifdef __cplusplus
 }

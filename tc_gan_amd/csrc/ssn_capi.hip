@@ -1242,6 +1242,10 @@ int ssn_mt19937_random_sample_begin_f64(const unsigned int* key, int pos, unsign
     SSN_TRY(ssn::mt19937_begin(key, pos, total, skip, count, out, 8, (hipStream_t)stream, ticket));
     return 0;
 }
+int ssn_mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out) {
+    if (!out || !ssn::mt19937_plan(pos, total, skip, count, out)) { g_last_error = "ssn_mt19937_plan: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    return 0;
+}
 int ssn_mt19937_random_sample_finish(int ticket, unsigned int* key, int* pos) {
     if (!key || !pos) { g_last_error = "ssn_mt19937_random_sample_finish: null state"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::mt19937_finish(ticket, key, pos));

@@ -240,5 +240,6 @@ hipError_t mt19937_draw(unsigned int* key, int* pos, unsigned long long total, u
 hipError_t mt19937_begin(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
                          void* out, int elem, hipStream_t st, int* ticket);
 hipError_t mt19937_finish(int ticket, unsigned int* key, int* pos);
+bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out);
 
 }  // namespace ssn

@@ -540,6 +540,35 @@ static hipError_t device_tables(int need_level, DeviceTables** out) {
 }
 
 static inline int level_shift(int l) { return kStride0Log2 + kRadixLog2 * l; }
+
+// Block 0 is the caller's key (words pos.. of it are still unused), block b its b-th regeneration; segment s starts from the
+// state of block s * seg_blocks and regenerates blocks s * seg_blocks + 1 .. (s + 1) * seg_blocks (segment 0 also emits the
+// rest of block 0).
+struct Plan { long p_end, b_f, b_lo, b_hi, s_lo, s_hi; int step; };
+static bool make_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, Plan& pl) {
+    if (pos < 0 || pos > kN || skip + count > total || total > (1ull << 40)) return false;
+    pl.p_end = (long)pos + 2 * (long)total;                      // position of the first unconsumed word, from block 0
+    pl.b_f = pl.p_end <= kN ? 0 : (pl.p_end - 1) / kN;           // block of the state after the draw
+    pl.b_lo = pl.b_hi = pl.s_lo = pl.s_hi = 0;
+    pl.step = 1;
+    if (count) {
+        pl.b_lo = ((long)pos + 2 * (long)skip) / kN;
+        pl.b_hi = ((long)pos + 2 * (long)(skip + count) - 1) / kN;
+        // segment length 128 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
+        // workgroups per state, 768 at a time, ~70 us a round; a segment's workgroup generates a block in ~0.5 us
+        double best = 1e30;
+        for (int c = 1; c <= 8; c *= 2) {
+            const long len = (long)c << kStride0Log2;
+            const long nseg = (pl.b_hi - pl.b_lo + len) / len;
+            const double cost = 70.0 * (double)((4 * nseg + 767) / 768) + 0.5 * (double)len;
+            if (cost < best) { best = cost; pl.step = c; }
+        }
+        const long seg_blocks = (long)pl.step << kStride0Log2;
+        pl.s_lo = pl.b_lo >= 1 ? (pl.b_lo - 1) / seg_blocks : 0;
+        pl.s_hi = pl.b_hi >= 1 ? (pl.b_hi - 1) / seg_blocks : 0;
+    }
+    return true;
+}
 // workgroups per share of a round with `count` states: enough to put a workgroup on most CUs when the states are few
 static inline int sub_for(long count) { return count * kShares * 4 <= 512 ? 4 : (count * kShares * 2 <= 512 ? 2 : 1); }
 
@@ -553,6 +582,18 @@ int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits) {
     const mt::Poly p = h.field.block_jump(nblocks);
     std::memcpy(bits, p.w, sizeof p.w);
     return 0;
+}
+
+// Where a draw lands in the block / segment grid (host arithmetic only: tests check it against numpy's positions)
+bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out) {
+    mt::Plan pl;
+    if (!mt::make_plan(pos, total, skip, count, pl)) return false;
+    out[0] = pl.p_end - pl.b_f * mt::kN;   // pos after the draw
+    out[1] = pl.b_f;                       // regenerations between the caller's key and the key after the draw
+    out[2] = (long)pl.step << mt::kStride0Log2;    // blocks per segment
+    out[3] = pl.s_lo; out[4] = pl.s_hi;    // segments this call generates
+    out[5] = pl.b_lo; out[6] = pl.b_hi;    // first / last block holding a wanted word
+    return true;
 }
 
 // The state after a draw begun with mt19937_begin: waits for that draw's one launch on the library's stream, nothing else.
@@ -588,28 +629,11 @@ hipError_t mt19937_finish(int ticket, uint32_t* key, int* pos) {
 hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
                          void* out, int elem, hipStream_t st, int* ticket) {
     using namespace mt;
-    if (pos < 0 || pos > kN || skip + count > total || (count && !out) || (elem != 4 && elem != 8) || !ticket) return hipErrorInvalidValue;
-    if (total > (1ull << 40)) return hipErrorInvalidValue;
-    const long p_end = (long)pos + 2 * (long)total;              // position of the first unconsumed word, from block 0
-    const long b_f = p_end <= kN ? 0 : (p_end - 1) / kN;         // block of the state after the draw
-    long b_hi = 0, s_lo = 0, s_hi = 0;
-    int step = 1;
-    if (count) {
-        const long b_lo = ((long)pos + 2 * (long)skip) / kN;
-        b_hi = ((long)pos + 2 * (long)(skip + count) - 1) / kN;
-        // segment length 128 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
-        // workgroups per state, 768 at a time, ~70 us a round; a segment's workgroup generates a block in ~0.5 us
-        double best = 1e30;
-        for (int c = 1; c <= 8; c *= 2) {
-            const long len = (long)c << kStride0Log2;
-            const long nseg = (b_hi - b_lo + len) / len;
-            const double cost = 70.0 * (double)((4 * nseg + 767) / 768) + 0.5 * (double)len;
-            if (cost < best) { best = cost; step = c; }
-        }
-        const long seg_blocks = (long)step << kStride0Log2;
-        s_lo = b_lo >= 1 ? (b_lo - 1) / seg_blocks : 0;
-        s_hi = b_hi >= 1 ? (b_hi - 1) / seg_blocks : 0;
-    }
+    if ((count && !out) || (elem != 4 && elem != 8) || !ticket) return hipErrorInvalidValue;
+    Plan pl;
+    if (!make_plan(pos, total, skip, count, pl)) return hipErrorInvalidValue;
+    const long p_end = pl.p_end, b_f = pl.b_f, b_hi = pl.b_hi, s_lo = pl.s_lo, s_hi = pl.s_hi;
+    const int step = pl.step;
     // levels needed: the top digit of the last segment must be <= kDigits
     int top_b = count ? kSegLevel : -1;
     if (count)

@@ -35,8 +35,10 @@ def test_default_workload_line():
     assert abs(d['value'] - 200 * 4096 * 2000 / (d['ms_per_step'] * 1e-3)) / d['value'] < 1e-6
     c = d['cpu_baseline']
     assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(c) and c['kind'] in ('reference', 'port') and c['value'] > 0
-    # the baseline names the box it ran on: every usable core is used
-    assert c['threads'] == c['cores'] == c['affinity_cores'] == len(os.sched_getaffinity(0)) and c['host_cpu_count'] == os.cpu_count()
+    # the baseline names the box it ran on: the host's CPUs, this process's share of them, and the pool size
+    # that ran the reference fastest among the candidates (no fixed cap)
+    assert c['threads'] == c['cores'] <= c['affinity_cores'] == len(os.sched_getaffinity(0)) and c['host_cpu_count'] == os.cpu_count()
+    assert 'cgroup_quota_cores' in c and isinstance(c['thread_probe_seconds'], dict)
     # the GAN half of the metric and the other named workloads ride along
     sec = d['secondary']
     assert sec['metric'] == 'GAN iters/sec' and sec['value'] > 0 and sec['gen_kernel'] == 'auto'

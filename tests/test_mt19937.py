@@ -84,3 +84,37 @@ def test_device_continued_randomstate_resolves_a_pending_state_on_first_touch():
     r._defer(finish)                                   # get_state (checkpoints) resolves too
     st = r.get_state()
     assert calls == [1, 1] and (st[1] == q.get_state()[1]).all() and st[2] == q.get_state()[2]
+
+
+@pytest.mark.parametrize('world', [1, 2, 8])
+@pytest.mark.parametrize('pos', [0, 1, 311, 623, 624])
+def test_draw_plan_positions_and_rank_segments(world, pos):
+    """`ssn_mt19937_plan` (the host arithmetic of a device draw, no GPU): the position after the draw and the number of
+    regenerations equal numpy's own (`get_state()` before / after `random_sample`), and the segments the ranks of a
+    data-parallel job generate cover every block that holds one of their rows' words -- SURVEY 8e: each rank its own rows of the
+    GLOBAL draw, all ranks the same state afterwards."""
+    from tc_gan_amd import clib
+    B, M = 64, 100
+    total = B * M * M
+    rs = np.random.RandomState(5)
+    rs.randint(0, 2 ** 31, size=1000)                     # away from the seed state
+    st = rs.get_state()
+    rs.set_state((st[0], st[1], pos, st[3], st[4]))
+    rs.random_sample(total)
+    want_pos = rs.get_state()[2]
+    ends = set()
+    for rank in range(world):
+        per = B // world
+        skip, count = rank * per * M * M, per * M * M
+        out = np.zeros(7, dtype=np.int64)
+        assert clib.libssnode.ssn_mt19937_plan(pos, total, skip, count, out.ctypes.data) == 0
+        new_pos, b_f, seg_blocks, s_lo, s_hi, b_lo, b_hi = (int(v) for v in out)
+        ends.add((new_pos, b_f))
+        assert new_pos == want_pos and b_f == max(0, (pos + 2 * total - 1) // 624) * (pos + 2 * total > 624)
+        # the rank's words: stream words [2 skip, 2 (skip + count)) sit at positions pos + w of the block grid
+        assert b_lo == (pos + 2 * skip) // 624 and b_hi == (pos + 2 * (skip + count) - 1) // 624
+        assert seg_blocks in (128, 256, 512, 1024)
+        # segment s regenerates blocks s * seg_blocks + 1 .. (s + 1) * seg_blocks (segment 0 also holds block 0)
+        first = 0 if s_lo == 0 else s_lo * seg_blocks + 1
+        assert first <= b_lo and b_hi <= (s_hi + 1) * seg_blocks and (s_lo == 0 or b_lo > (s_lo - 1) * seg_blocks + seg_blocks)
+    assert len(ends) == 1                                  # every rank hands back the same generator state
