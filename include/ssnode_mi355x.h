@@ -649,6 +649,12 @@ int ssn_mt19937_random_sample_begin_f32(const unsigned int *key, int pos, unsign
 int ssn_mt19937_random_sample_begin_f64(const unsigned int *key, int pos, unsigned long long total, unsigned long long skip,
                                         unsigned long long count, double *out, void *stream, int *ticket);
 int ssn_mt19937_random_sample_finish(int ticket, unsigned int *key, int *pos);
+/* ssn_mt19937_random_sample_begin_f32 with W = make_W_with_x(z; J, D, S) (ssn_build_w_f32's arithmetic, the same bits) formed in
+ * the generation kernel itself: the draw is z[B_total][2N][2N] of the caller's stream, models b0 .. b0 + nb - 1 of it are this
+ * call's (a rank's rows), W: device [nb][2N][2N]; z: device [nb][2N][2N] to keep the numbers (the generator update's chain rule
+ * reads them) or NULL -- then they never touch memory.  J, D, S: HOST float[4].  Finish with ssn_mt19937_random_sample_finish. */
+int ssn_build_w_mt19937_begin_f32(const unsigned int *key, int pos, int B_total, int b0, int nb, const float *J, const float *D,
+                                  const float *S, float *W, float *z, int N, void *stream, int *ticket);
 /* Host arithmetic of a draw alone (no device): out[7] = {pos after the draw, regenerations of the key up to then, blocks per
  * segment, first and last segment this call generates, first and last block that holds a wanted word} for the given pos /
  * total / skip / count -- what the CPU tests check against numpy's own positions, rank by rank. */

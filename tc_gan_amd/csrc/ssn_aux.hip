@@ -19,7 +19,6 @@ __global__ void __launch_bounds__(256) build_w_kernel(const T* __restrict__ z, T
         const long e0 = v * VEC;
         const int col0 = (int)(e0 % M);
         const int row = (int)((e0 / M) % M);
-        const int pp = row >= N, i = row - pp * N;
         T zin[VEC], wout[VEC];
         if constexpr (VEC == 4) {
             using V4 = T __attribute__((ext_vector_type(4)));
@@ -29,15 +28,7 @@ __global__ void __launch_bounds__(256) build_w_kernel(const T* __restrict__ z, T
             zin[0] = z[e0];
         }
 #pragma unroll
-        for (int t = 0; t < VEC; ++t) {
-            const int col = col0 + t;
-            const int qq = col >= N, j = col - qq * N;
-            const int pq = pp * 2 + qq;
-            const T dx = (T)(i - j) * inv_nm1;
-            const T g = exp(-(dx * dx) * p.inv2s2[pq]);
-            const T sgn = qq ? (T)-1 : (T)1;
-            wout[t] = g * (sgn * p.J[pq] + sgn * p.D[pq] * zin[t]);
-        }
+        for (int t = 0; t < VEC; ++t) wout[t] = w_from_z<T>(p, N, inv_nm1, row, col0 + t, zin[t]);
         if constexpr (VEC == 4) {
             using V4 = T __attribute__((ext_vector_type(4)));
             V4 q; q.x = wout[0]; q.y = wout[1]; q.z = wout[2]; q.w = wout[3];
@@ -283,14 +274,8 @@ __device__ __forceinline__ void build_w_philox_body(unsigned long long seed, uns
         for (int t = 0; t < 4; ++t) {
             const unsigned bits = mis == 0 ? w[t] : (mis == 1 ? w[t + 1] : (mis == 2 ? w[t + 2] : w[t + 3]));
             zin[t] = (T)((float)(bits >> 8) * (1.0f / 16777216.0f));
-            const int pp = row >= N, i = row - pp * N;
-            const int qq = col >= N, j = col - qq * N;
-            const int pq = pp * 2 + qq;
-            const T dx = (T)(i - j) * inv_nm1;
-            const T g = exp(-(dx * dx) * p.inv2s2[pq]);
-            const T sgn = qq ? (T)-1 : (T)1;
+            wout[t] = w_from_z<T>(p, N, inv_nm1, row, col, zin[t]);
             if (++col == M) { col = 0; if (++row == M) row = 0; }
-            wout[t] = g * (sgn * p.J[pq] + sgn * p.D[pq] * zin[t]);
         }
         using V4 = T __attribute__((ext_vector_type(4)));
         V4 q; q.x = wout[0]; q.y = wout[1]; q.z = wout[2]; q.w = wout[3];

@@ -1242,6 +1242,19 @@ int ssn_mt19937_random_sample_begin_f64(const unsigned int* key, int pos, unsign
     SSN_TRY(ssn::mt19937_begin(key, pos, total, skip, count, out, 8, (hipStream_t)stream, ticket));
     return 0;
 }
+int ssn_build_w_mt19937_begin_f32(const unsigned int* key, int pos, int B_total, int b0, int nb, const float* J, const float* D,
+                                  const float* S, float* W, float* z, int N, void* stream, int* ticket) {
+    if (!key || !ticket || !J || !D || !S || !W || N < 1 || B_total < 0 || b0 < 0 || nb < 0 || b0 + nb > B_total) {
+        g_last_error = "ssn_build_w_mt19937_begin: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    *ticket = -1;
+    float jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    const unsigned long long mm = 4ull * N * N;
+    SSN_TRY(ssn::mt19937_begin(key, pos, mm * B_total, mm * b0, mm * nb, z, 4, (hipStream_t)stream, ticket, nb ? W : nullptr, jds, N));
+    return 0;
+}
 int ssn_mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out) {
     if (!out || !ssn::mt19937_plan(pos, total, skip, count, out)) { g_last_error = "ssn_mt19937_plan: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     return 0;

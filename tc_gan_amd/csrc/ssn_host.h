@@ -56,6 +56,35 @@ template <typename T>
 struct JDSv { T J[4], D[4], inv2s2[4], inv_s3[4]; };
 template <typename T>
 struct JDS { T J[4], D[4], inv2s2[4]; };
+// One element of make_W_with_x (gradient_expressions/make_w_batch.py:8-34; weight_gen.py:13-26) from its z:
+// W[pN + i][qN + j] = exp(-(x_i - x_j)^2 / (2 S_pq^2)) (+-J_pq +- D_pq z), x = linspace(-.5, .5, N), sign + for q = E, - for q = I.
+// ONE definition for every kernel that forms W (build_w_kernel, the Philox and MT19937 forms that draw z in the same launch):
+// products and sums rounded one by one (no contraction), so the same z gives the same bits wherever W is built.
+// (in two halves, so that a kernel may keep the Gaussian factors of a launch in a table: the factor depends on the block pq and
+// on |i - j| alone -- dx enters squared)
+template <typename T>
+__device__ __forceinline__ T w_gauss(const JDS<T>& p, T inv_nm1, int pq, int i_minus_j) {
+#pragma clang fp contract(off)
+    const T dx = (T)i_minus_j * inv_nm1;
+    return exp(-(dx * dx) * p.inv2s2[pq]);
+}
+template <typename T>
+__device__ __forceinline__ T w_combine_vals(T Jpq, T Dpq, int qq, T g, T z) {
+#pragma clang fp contract(off)
+    const T sgn = qq ? (T)-1 : (T)1;
+    return g * (sgn * Jpq + sgn * Dpq * z);
+}
+template <typename T>
+__device__ __forceinline__ T w_combine(const JDS<T>& p, int pq, int qq, T g, T z) {
+    return w_combine_vals<T>(p.J[pq], p.D[pq], qq, g, z);
+}
+template <typename T>
+__device__ __forceinline__ T w_from_z(const JDS<T>& p, int N, T inv_nm1, int row, int col, T z) {
+    const int pp = row >= N, i = row - pp * N;
+    const int qq = col >= N, j = col - qq * N;
+    const int pq = pp * 2 + qq;
+    return w_combine<T>(p, pq, qq, w_gauss<T>(p, inv_nm1, pq, i - j), z);
+}
 // inputs of a device-noise forward in one launch (ssn_aux.hip: gen_inputs_kernel)
 struct GenInputsArgs {
     unsigned long long seed, off_z, off_zin;
@@ -238,7 +267,7 @@ int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits);
 hipError_t mt19937_draw(unsigned int* key, int* pos, unsigned long long total, unsigned long long skip, unsigned long long count,
                         void* out, int elem, hipStream_t st);
 hipError_t mt19937_begin(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
-                         void* out, int elem, hipStream_t st, int* ticket);
+                         void* out, int elem, hipStream_t st, int* ticket, float* W = nullptr, const float* jds12 = nullptr, int N = 0);
 hipError_t mt19937_finish(int ticket, unsigned int* key, int* pos);
 bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out);
 

@@ -273,7 +273,12 @@ struct GenArgs {
     long b_hi;                  // last block whose words are wanted
     int pos;                    // position in block 0 of stream word 0
     long skip, count;           // doubles [skip, skip + count) of the draw go to out[0 .. count)
-    T* out;
+    T* out;                     // the numbers themselves (nullptr: not wanted -- only with W below)
+    // W of make_W_with_x straight from the numbers (T = float): out[e] is element e of z[B][M][M], M = 2 N
+    T* W = nullptr;
+    JDS<float> p = {};
+    int N = 0;
+    unsigned long long magic_m = 0;   // ceil(2^40 / M): e / M = (e * magic_m) >> 40 for e < 2^28 (count is checked)
 };
 
 constexpr int kBufStride = kN + 32;        // (words 624.. of a buffer: where the twelve idle lanes of a pass put their stores)
@@ -318,9 +323,9 @@ __device__ __forceinline__ void gen_block(uint32_t* flat, int lane) {
     gen_store<5>(flat, neww, lane, act, r1);
 }
 
-template <typename T, bool ODD>
+template <typename T, bool ODD, bool BUILDW>
 __device__ __forceinline__ void emit_pass(const GenArgs<T>& a, const uint32_t* blk, const uint32_t* carry_in,
-                                          int c, int lane, long qb) {
+                                          int c, int lane, long qb, const float* gtab) {
     const bool act = lane < 52;
     const int i = 104 * c + 2 * (act ? lane : 51);
     uint32_t w0, w1;
@@ -338,20 +343,50 @@ __device__ __forceinline__ void emit_pass(const GenArgs<T>& a, const uint32_t* b
     if (act && (unsigned long)qq < (unsigned long)a.count) {
         // randomkit rk_double: (a >> 5, b >> 6) -> (a * 2^26 + b) / 2^53, exact in double
         const double v = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);
-        a.out[qq] = (T)v;          // T = float: round to nearest even, as numpy's astype(float32)
+        const T z = (T)v;          // T = float: round to nearest even, as numpy's astype(float32)
+        if constexpr (BUILDW) {
+            // the element's place in its draw: e = (b M + row) M + col
+            const unsigned e = (unsigned)qq, M = 2u * (unsigned)a.N;
+            const unsigned er = (unsigned)(((unsigned long long)e * a.magic_m) >> 40);       // e / M
+            const unsigned col = e - er * M;
+            const unsigned row = er - (unsigned)(((unsigned long long)er * a.magic_m) >> 40) * M;
+            // the Gaussian factor from the launch's table (w_gauss of (pq, |i - j|), the bits w_from_z computes), the rest as there
+            const int pp = (int)row >= a.N, i = (int)row - pp * a.N;
+            const int cq = (int)col >= a.N, j = (int)col - cq * a.N;
+            const int pq = pp * 2 + cq, dij = i > j ? i - j : j - i;
+            // (J, D of the block by selects on uniform values: indexing the argument struct by a per-lane pq is a vector load
+            // from the argument segment for every number, with its full latency in a wave that has one pass to hide it behind)
+            const float Jpq = cq ? (pp ? a.p.J[3] : a.p.J[1]) : (pp ? a.p.J[2] : a.p.J[0]);
+            const float Dpq = cq ? (pp ? a.p.D[3] : a.p.D[1]) : (pp ? a.p.D[2] : a.p.D[0]);
+            a.W[qq] = w_combine_vals<float>(Jpq, Dpq, cq, gtab[pq * a.N + dij], (float)z);
+            if (a.out) a.out[qq] = z;
+        } else {
+            a.out[qq] = z;
+        }
     }
 }
 
-template <typename T, bool ODD>
-__global__ __launch_bounds__(256) void mt_gen_kernel(const GenArgs<T> a) {
+template <typename T, bool ODD, bool BUILDW>
+__global__ __launch_bounds__(BUILDW ? 576 : 256) void mt_gen_kernel(const GenArgs<T> a) {
+    // waves: 0 regenerates; three emit two passes of a block each -- or, with W formed here (twice the work per number), six emit
+    // one pass each.  Waves w and w + 4 of a workgroup share a SIMD: in the nine-wave form waves 4 and 8 do nothing but keep the
+    // barrier, so that the regenerating wave -- the launch's critical path -- has its SIMD to itself, as in the four-wave form.
+    constexpr int EW = BUILDW ? 6 : 3, PASSES = 6 / EW, NTHR = BUILDW ? 576 : 256;
     __shared__ __align__(16) uint32_t buf[2 * kBufStride];
     __shared__ uint32_t carry[2];          // raw last word of the block emitted in the round before (ODD)
+    extern __shared__ __align__(16) float gtab_dyn[];     // BUILDW: [4][N] Gaussian factors of make_W_with_x (w_gauss)
+    const float* gtab = nullptr;
+    if constexpr (BUILDW) {
+        const float inv_nm1 = a.N > 1 ? 1.f / (float)(a.N - 1) : 0.f;
+        for (int t = threadIdx.x; t < 4 * a.N; t += NTHR) gtab_dyn[t] = w_gauss<float>(a.p, inv_nm1, t / a.N, t % a.N);
+        gtab = gtab_dyn;            // (the barriers below order it before the first emission)
+    }
     uint32_t* flat = buf;
     uint32_t* vcarry = carry;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long seg = a.s_lo + (long)blockIdx.x;
     const uint32_t* src = a.states + (size_t)blockIdx.x * a.nparts * kN;
-    for (int j = tid; j < kN; j += 256) flat[j] = xor_parts(src, a.nparts, j);
+    for (int j = tid; j < kN; j += NTHR) flat[j] = xor_parts(src, a.nparts, j);
     __syncthreads();
     if (tid == 0) { vcarry[0] = flat[kN - 1]; vcarry[1] = 0u; }
     __syncthreads();
@@ -361,6 +396,7 @@ __global__ __launch_bounds__(256) void mt_gen_kernel(const GenArgs<T> a) {
     if (nbl < 0) nbl = 0;
     const int nb = (int)nbl;
     const int first = (seg == 0 && a.pos < kN) ? 0 : 1;     // segment 0 also emits the rest of the caller's current block
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);           // (the regenerating wave is the launch's critical path: ahead of an emitter on its SIMD)
     for (int bb = 0; bb <= nb; ++bb) {
         const int p = bb & 1;
         if (wave == 0) {
@@ -369,10 +405,13 @@ __global__ __launch_bounds__(256) void mt_gen_kernel(const GenArgs<T> a) {
             const long b = b0 + bb;
             const long qb = (b * kN - a.pos - (ODD ? 1 : 0)) >> 1;         // (exact: the numerator is even)
             const uint32_t* blk = flat + p * kBufStride;
-            const int c = 2 * (wave - 1);
-            emit_pass<T, ODD>(a, blk, vcarry + (p ^ 1), c, lane, qb);
-            emit_pass<T, ODD>(a, blk, vcarry + (p ^ 1), c + 1, lane, qb);
-            if (ODD && wave == 3 && lane == 0) vcarry[p] = blk[kN - 1];
+            const int ei = BUILDW ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1;        // emitter 0 .. EW - 1 (waves 4, 8: none)
+            if (!BUILDW || (wave & 3) != 0) {
+                const int c = PASSES * ei;
+                emit_pass<T, ODD, BUILDW>(a, blk, vcarry + (p ^ 1), c, lane, qb, gtab);
+                if constexpr (PASSES == 2) emit_pass<T, ODD, BUILDW>(a, blk, vcarry + (p ^ 1), c + 1, lane, qb, gtab);
+                if (ODD && ei == EW - 1 && lane == 0) vcarry[p] = blk[kN - 1];
+            }
         }
         __syncthreads();
     }
@@ -627,9 +666,11 @@ hipError_t mt19937_finish(int ticket, uint32_t* key, int* pos) {
 // [skip, skip + count) of them are written to out (device; elem = 4: float, 8: double) on `st`.  Returns a ticket for the state
 // after the draw (mt19937_finish).
 hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
-                         void* out, int elem, hipStream_t st, int* ticket) {
+                         void* out, int elem, hipStream_t st, int* ticket, float* W, const float* jds12, int N) {
     using namespace mt;
-    if ((count && !out) || (elem != 4 && elem != 8) || !ticket) return hipErrorInvalidValue;
+    // W != nullptr (elem 4): W of make_W_with_x from the numbers, in the generation kernel itself; `out` (the z) may then be null
+    if ((count && !out && !W) || (elem != 4 && elem != 8) || !ticket) return hipErrorInvalidValue;
+    if (W && (elem != 4 || !jds12 || N < 1 || N > 2048 || count >= (1ull << 28) || (skip % (4ull * N * N)) != 0)) return hipErrorInvalidValue;
     Plan pl;
     if (!make_plan(pos, total, skip, count, pl)) return hipErrorInvalidValue;
     const long p_end = pl.p_end, b_f = pl.b_f, b_hi = pl.b_hi, s_lo = pl.s_lo, s_hi = pl.s_hi;
@@ -735,12 +776,22 @@ hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total,
             const bool odd = pos & 1;
             if (elem == 4) {
                 GenArgs<float> ga{parent, parent_parts, s_lo, s_hi, step << kStride0Log2, b_hi, pos, (long)skip, (long)count, (float*)out};
-                if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true>), dim3(nseg), dim3(256), 0, st, ga);
-                else hipLaunchKernelGGL((mt_gen_kernel<float, false>), dim3(nseg), dim3(256), 0, st, ga);
+                if (W) {
+                    ga.W = W; ga.N = N;
+                    ga.magic_m = ((1ull << 40) + 2ull * N - 1) / (2ull * N);
+                    for (int q = 0; q < 4; ++q) {
+                        ga.p.J[q] = jds12[q]; ga.p.D[q] = jds12[4 + q];
+                        ga.p.inv2s2[q] = 1.f / (2.f * jds12[8 + q] * jds12[8 + q]);
+                    }
+                    const size_t glds = sizeof(float) * 4 * (size_t)N;
+                    if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true, true>), dim3(nseg), dim3(576), glds, st, ga);
+                    else hipLaunchKernelGGL((mt_gen_kernel<float, false, true>), dim3(nseg), dim3(576), glds, st, ga);
+                } else if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true, false>), dim3(nseg), dim3(256), 0, st, ga);
+                else hipLaunchKernelGGL((mt_gen_kernel<float, false, false>), dim3(nseg), dim3(256), 0, st, ga);
             } else {
                 GenArgs<double> ga{parent, parent_parts, s_lo, s_hi, step << kStride0Log2, b_hi, pos, (long)skip, (long)count, (double*)out};
-                if (odd) hipLaunchKernelGGL((mt_gen_kernel<double, true>), dim3(nseg), dim3(256), 0, st, ga);
-                else hipLaunchKernelGGL((mt_gen_kernel<double, false>), dim3(nseg), dim3(256), 0, st, ga);
+                if (odd) hipLaunchKernelGGL((mt_gen_kernel<double, true, false>), dim3(nseg), dim3(256), 0, st, ga);
+                else hipLaunchKernelGGL((mt_gen_kernel<double, false, false>), dim3(nseg), dim3(256), 0, st, ga);
             }
             e = hipGetLastError();
             if (e == hipSuccess) { e = hipEventRecord(bs.consumed, st); bs.used = true; }
@@ -754,7 +805,7 @@ hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total,
 hipError_t mt19937_draw(uint32_t* key, int* pos_io, unsigned long long total, unsigned long long skip, unsigned long long count,
                         void* out, int elem, hipStream_t st) {
     int ticket = -1;
-    const hipError_t e = mt19937_begin(key, *pos_io, total, skip, count, out, elem, st, &ticket);
+    const hipError_t e = mt19937_begin(key, *pos_io, total, skip, count, out, elem, st, &ticket, nullptr, nullptr, 0);
     if (ticket < 0) return e;
     const hipError_t f = mt19937_finish(ticket, key, pos_io);
     return e != hipSuccess ? e : f;

@@ -313,7 +313,7 @@ class ConditionalBPTTWassersteinGAN(object):
     def _local(self, batch):
         return batch.shard(self.reducer.rank, self.reducer.world) if self.reducer.on else batch
 
-    def _draw_noise(self, batch):
+    def _draw_noise(self, batch, keep_z=None):
         """Noise in the reference's stream order (ssn.py:434-439, 764-767: zs, then zs_in): the GLOBAL draw is consumed from
         the shared RandomState, this rank's rows are returned -- a data-parallel run consumes the RandomState exactly like a
         single-GPU run.  z itself is generated on the device (`ssn.device_rand`: only this rank's rows; the host never sees
@@ -330,7 +330,8 @@ class ConditionalBPTTWassersteinGAN(object):
                 self._warned_host_noise = True
                 logger.warning('host-side noise with %d ranks: every rank draws all %d models\' z on the host each step',
                                self.reducer.world, batch.num_models)
-        return self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((batch.num_models, 1)), rows=rows)
+        # keep_z given: the forward follows at once with the current parameters, so W is formed in the draw's own launch
+        return self.gen.gen_noise(self.rng, stimulator_bandwidths=np.empty((batch.num_models, 1)), rows=rows, keep_z=keep_z)
 
     def gen_forward(self, batch, noise=None, save=False):
         local = self._local(batch)
@@ -343,12 +344,14 @@ class ConditionalBPTTWassersteinGAN(object):
     # is already queued on the stream when the host blocks on this step's scalars: `_prepare_disc` draws from the
     # host RNG (same order as the reference: minibatch, eps, zs) and launches the forward; `_finish_disc` runs the
     # critic update and reads loss / accuracy / penalties back with ONE device-to-host copy.
-    def _draw_disc(self):
-        """The host RNG draws of one critic step, in the reference's order (minibatch, eps, zs)."""
+    def _draw_disc(self, early=False):
+        """The RNG draws of one critic step, in the reference's order (minibatch, eps, zs).  `early`: the draws `train_generator`
+        makes ahead of time, BEFORE its parameter update -- zs is drawn as numbers only (W is formed from them at the forward,
+        with the updated parameters); otherwise the forward follows at once and W is formed in the draw's own launch."""
         t0 = time.perf_counter()
         batch = self.next_minibatch()
         eps_full = self.rng.rand(batch.batchsize, 1)
-        noise = self._draw_noise(batch)
+        noise = self._draw_noise(batch, keep_z=None if early else False)
         self.host_draw_seconds = getattr(self, 'host_draw_seconds', 0.0) + (time.perf_counter() - t0)
         return batch, eps_full, noise
 
@@ -483,7 +486,7 @@ class ConditionalBPTTWassersteinGAN(object):
     def _prepare_gen(self, batch):
         """Noise draw + generator forward with the trajectory kept (independent of the critic: may be queued before
         the last critic step of the iteration has finished)."""
-        noise = self._draw_noise(batch)
+        noise = self._draw_noise(batch, keep_z=True)
         with self.gen_train_watch:
             gen_out, local = self.gen_forward(batch, noise, save=True)
         return gen_out, local
@@ -496,7 +499,7 @@ class ConditionalBPTTWassersteinGAN(object):
         # taken in between stores the RandomState from BEFORE these draws (state_dict), so a resumed run repeats them.
         if self.critic_iters > 0 and self._predrawn is None:
             self._rng_before_predraw = self.rng.get_state()
-            self._predrawn = self._draw_disc()
+            self._predrawn = self._draw_disc(early=True)
         fused = self._gen_tail_fused()
         with self.gen_train_watch:
             cd = None if local.conditions is None else to_device(np.ascontiguousarray(local.conditions), torch.float32)

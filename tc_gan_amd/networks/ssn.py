@@ -107,6 +107,49 @@ def device_rand(rng, shape, tdtype, rows=None):
     return out
 
 
+# (A/B switch: TCGAN_MT_FUSE_W=0 keeps the draw and the W build in two launches)
+_FUSE_W = __import__('os').environ.get('TCGAN_MT_FUSE_W', '1') != '0'
+
+
+class MTWeights(object):
+    """W = make_W_with_x(z) of a draw that was made on the device from the caller's RandomState (`device_rand_weights`), with
+    the draw itself (`z`) when it was asked for: what `TuningCurveGenerator._device_inputs` takes in place of z."""
+
+    def __init__(self, z, W):
+        self.z, self.W = z, W
+
+
+def device_rand_weights(rng, num_models, N, J, D, S, rows=None, keep_z=True):
+    """`device_rand(rng, (num_models, 2N, 2N), float32, rows)` and `generate_weight_batch` of it in ONE launch
+    (`ssn_build_w_mt19937_begin_f32`: W is formed where the numbers are, z goes to memory only when `keep_z`): same numbers,
+    same bits, `rng` left as numpy would leave it.  Returns `MTWeights`."""
+    kind, key, pos, has_gauss, cached = rng.get_state()
+    if kind != 'MT19937':
+        raise ValueError('device_rand_weights continues numpy RandomState (MT19937) streams only, got {!r}'.format(kind))
+    clib.require_gpu()
+    key = np.ascontiguousarray(key, dtype=np.uint32)
+    M = 2 * int(N)
+    lo, hi = (0, int(num_models)) if rows is None else (int(rows[0]), int(rows[1]))
+    W = torch.empty((hi - lo, M, M), device='cuda', dtype=torch.float32)
+    z = torch.empty_like(W) if keep_z else None
+    arrs = [(ctypes.c_float * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (J, D, S)]
+    ticket = ctypes.c_int(-1)
+    clib.check(clib.libssnode.ssn_build_w_mt19937_begin_f32(
+        key.ctypes.data, int(pos), int(num_models), lo, hi - lo, arrs[0], arrs[1], arrs[2], W.data_ptr(),
+        z.data_ptr() if keep_z else None, int(N), clib.stream_ptr(), ctypes.byref(ticket)), 'ssn_build_w_mt19937_begin_f32')
+
+    def finish(r, ticket=ticket.value, key=key, kind=kind, has_gauss=has_gauss, cached=cached):
+        cpos = ctypes.c_int(0)
+        clib.check(clib.libssnode.ssn_mt19937_random_sample_finish(ticket, key.ctypes.data, ctypes.byref(cpos)),
+                   'ssn_mt19937_random_sample_finish')
+        np.random.RandomState.set_state(r, (kind, key, cpos.value, has_gauss, cached))
+    if hasattr(rng, '_defer'):
+        rng._defer(finish)            # (fetched when `rng` is next used: utils.DeviceContinuedRandomState)
+    else:
+        finish(rng)
+    return MTWeights(z, W)
+
+
 class PhiloxDraw(object):
     """A slice of a `DeviceNoise` stream that has been reserved but not generated."""
 
@@ -330,11 +373,14 @@ class TuningCurveGenerator(object):
                                       kernel=8 if self.fused_backward else self.kernel)
 
     # -- noise -----------------------------------------------------------------------------
-    def gen_noise(self, rng, stimulator_bandwidths, rows=None, **_):
+    def gen_noise(self, rng, stimulator_bandwidths, rows=None, keep_z=None, **_):
         """ssn.py:434-439: ``zs = rng.rand(batchsize, 2N, 2N)`` of the caller's RandomState -- the reference's stream, generated
         on the device bit for bit and leaving `rng` as numpy would (`device_rand`; `z_host_draw`: numpy draws it on the host) --
         or a device Philox draw when the generator was built with `z_device_seed` (another stream: perf mode).
-        `rows = (lo, hi)`: this rank's models of the global draw (the whole draw is consumed, only these rows are returned)."""
+        `rows = (lo, hi)`: this rank's models of the global draw (the whole draw is consumed, only these rows are returned).
+        `keep_z` = True / False (callers that run the forward right away, with the CURRENT J, D, S): W is formed in the draw's
+        own launch (`device_rand_weights`) and `model_zs` is an `MTWeights`; z itself is written only when kept (the generator
+        update's chain rule reads it)."""
         num_models = np.shape(stimulator_bandwidths)[0]
         M = self.num_neurons
         if self._zgen is not None:
@@ -348,6 +394,8 @@ class TuningCurveGenerator(object):
         sl = slice(None) if rows is None else slice(int(rows[0]), int(rows[1]))
         if self.z_host_draw or not _is_mt19937(rng):
             noise = dict(model_zs=rng.rand(num_models, M, M)[sl])
+        elif keep_z is not None and _FUSE_W and self.tdtype == torch.float32 and num_models * M * M < (1 << 28):
+            noise = dict(model_zs=device_rand_weights(rng, num_models, self.num_sites, self.J, self.D, self.S, rows=rows, keep_z=keep_z))
         else:
             noise = dict(model_zs=device_rand(rng, (num_models, M, M), self.tdtype, rows=rows))
         if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720; small: stays on the host
@@ -425,6 +473,9 @@ class TuningCurveGenerator(object):
         if isinstance(model_zs, PhiloxDraw):
             z, W = model_zs.weights(self.num_sites, self.J, self.D, self.S, keep_z=save)
             return ext, z, W
+        if isinstance(model_zs, MTWeights):            # (W was formed with the draw: `gen_noise(..., keep_z=...)`)
+            assert model_zs.z is not None or not save, 'the generator step keeps z: draw with keep_z=True'
+            return ext, model_zs.z, model_zs.W
         if torch.is_tensor(model_zs):
             z = model_zs.to('cuda', self.tdtype).contiguous()
         else:

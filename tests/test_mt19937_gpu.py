@@ -157,3 +157,31 @@ def test_deferred_state_survives_any_number_of_other_draws():
     assert np.array_equal(first.rand(5), ref.rand(5))
     st, sr = first.get_state(), ref.get_state()
     assert np.array_equal(st[1], sr[1]) and st[2] == sr[2]
+
+
+@pytest.mark.parametrize('N,B,rows,warm', [(10, 5, None, 0), (100, 40, None, 7), (101, 16, (4, 12), 311), (100, 64, (32, 64), 0),
+                                           (102, 9, (0, 9), 624), (3, 2, None, 1)])
+def test_weights_in_the_draw_s_own_launch_bit_equal_draw_then_build(N, B, rows, warm):
+    """`ssn_build_w_mt19937_begin_f32` (z = rng.rand(B, 2N, 2N) and W = make_W_with_x(z) in one launch, z written only when
+    kept) against the two steps it replaces: numpy's draw, downcast, `ssn_build_w_f32`.  Same W, same z, bit for bit; same
+    RandomState afterwards; a rank's rows of the global draw."""
+    from oracle import ssn_numpy as on
+    from tc_gan_amd.networks.ssn import device_rand_weights
+    from tc_gan_amd.weight_gen import generate_weight_batch
+    jds = on.new_JDS()
+    host, dev, dev2 = (np.random.RandomState(3) for _ in range(3))
+    for rs in (host, dev, dev2):
+        if warm:
+            rs.randint(0, 2 ** 31, size=warm)
+    lo, hi = rows or (0, B)
+    z = host.rand(B, 2 * N, 2 * N).astype('float32')[lo:hi]
+    want = generate_weight_batch(N, jds['J'], jds['D'], jds['S'], torch.as_tensor(z).cuda(), dtype='float32')
+    got = device_rand_weights(dev, B, N, jds['J'], jds['D'], jds['S'], rows=rows, keep_z=True)
+    assert torch.equal(got.W, want) and np.array_equal(got.z.cpu().numpy(), z)
+    none = device_rand_weights(dev2, B, N, jds['J'], jds['D'], jds['S'], rows=rows, keep_z=False)
+    assert none.z is None and torch.equal(none.W, want)
+    for rs in (dev, dev2):
+        assert np.array_equal(rs.get_state()[1], host.get_state()[1]) and rs.get_state()[2] == host.get_state()[2]
+    # ... and W itself against the fp64 restatement of weight_gen.generate_weight (the reference's numpy form)
+    ref = np.stack([on.generate_weight(N, jds['J'], jds['D'], jds['S'], zz.astype('float64')) for zz in z[:2]])
+    np.testing.assert_allclose(got.W[:2].cpu().numpy(), ref, rtol=2e-6, atol=1e-9)
