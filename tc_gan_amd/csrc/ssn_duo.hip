@@ -516,6 +516,11 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
         }
         const bool take = live && !((frozen >> st) & 1u);
         const bool ncv = dmax >= a.st.atol;                                      // ssnode.c:84-90 (a NaN difference does not count)
+#if SSN_DUO_TEST_EVERY > 1
+        // TIMING BUILD ONLY (wrong stop steps): the cross-lane part of the stop test every SSN_DUO_TEST_EVERY-th step, to price
+        // what a k-step test with exact replay could save at most
+        if ((it & (SSN_DUO_TEST_EVERY - 1)) == SSN_DUO_TEST_EVERY - 1 || it >= max_iter - 1) {
+#endif
         unsigned long long votes = __builtin_amdgcn_ballot_w64(take && ncv);
         unsigned bits;
         if (a.st.check_hard) {                                                   // (uniform; never with the saturating I/O function)
@@ -535,11 +540,15 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
         const unsigned fbase = (unsigned)(size_t)flags;
         if (WV == 0 && lane == 0) *(LdsW)(size_t)(fbase + 4u * (unsigned)(slot == 2 ? 0 : slot + 1)) = 0u;
         if (lane == 0 && bits) asm volatile("ds_or_b32 %0, %1" : : "v"(fbase + 4u * (unsigned)slot), "v"(bits) : "memory");
+#if SSN_DUO_TEST_EVERY > 1
+        }
+        if (SSN_DUO_TEST_RING && take) store_prev();       // (what a state ring would write per step)
+#endif
         if (take) {
             // r_prev = the state before the LAST applied step.  The last applied step of a stimulus is the one at which all of
             // its rows pass the convergence test (or step max_iter - 1), so a lane whose own rows do not pass it knows that this
             // step is not the last and need not save -- unless a rate-bound test (any row of any lane) can end the solve too.
-            if (!ncv || it >= max_iter - 1 || a.st.check_hard) store_prev();
+            if (SSN_DUO_PREV_ALWAYS || !ncv || it >= max_iter - 1 || a.st.check_hard) store_prev();
 #pragma unroll
             for (int i = 0; i < NE; ++i) rc[i] = r1[i];         // (a row that does not exist steps from 0 to 0: see above)
             store_state();
@@ -582,7 +591,11 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
 #if SSN_DUO_STAMP
             t1 = SSN_SOLVE_NOW();
 #endif
+#if SSN_DUO_TEST_EVERY > 1
+            if (!finished && it >= 1 && (((it - 1) & (SSN_DUO_TEST_EVERY - 1)) == SSN_DUO_TEST_EVERY - 1 || it >= max_iter - 1)) verdict(it - 1, word);
+#else
             if (!finished && it >= 1) verdict(it - 1, word);
+#endif
             if (frozen == 0xffu || it >= max_iter) finished = true;
         } else if (p >= d) {
             if (!finished) serial(it);

@@ -23,6 +23,15 @@
                                 // that tile as well, at the end of the serial phase (3.17-3.22 against 3.13-3.14: they take
                                 // from the partner wave's chain what they save the own one)
 #endif
+#ifndef SSN_DUO_TEST_EVERY
+#define SSN_DUO_TEST_EVERY 1   // > 1 (power of two): TIMING BUILD, wrong stop steps -- see solve serial part in ssn_duo.hip
+#endif
+#ifndef SSN_DUO_PREV_ALWAYS
+#define SSN_DUO_PREV_ALWAYS 0
+#endif
+#ifndef SSN_DUO_TEST_RING
+#define SSN_DUO_TEST_RING 0
+#endif
 #ifndef SSN_DUO_EARLY_SOLVE
 #define SSN_DUO_EARLY_SOLVE 2   // solver: the candidate state of a wave's last row tile behind its own chain: 2 = the four-tile wave only
                                 // (27.4 ms at C2 with 8 stimuli against 28.3 with 1 = every wave and 29.1 with 0 = none, same box)
