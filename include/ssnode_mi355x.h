@@ -655,6 +655,20 @@ int ssn_mt19937_random_sample_finish(int ticket, unsigned int *key, int *pos);
  * reads them) or NULL -- then they never touch memory.  J, D, S: HOST float[4].  Finish with ssn_mt19937_random_sample_finish. */
 int ssn_build_w_mt19937_begin_f32(const unsigned int *key, int pos, int B_total, int b0, int nb, const float *J, const float *D,
                                   const float *S, float *W, float *z, int N, void *stream, int *ticket);
+/* The two draws above followed IN THE SAME CALL by what the reference's heterogeneous-input models draw right behind zs
+ * (tc_gan/networks/ssn.py:710-720, 764-767: `zs_in`), so that the host does not have to fetch the state between the two:
+ *   tail_kind 1      rng.choice(2, n) * 2 - 1: one 32-bit output per element, its low bit (numpy's masked rejection with
+ *                    mask 1 rejects nothing: `_rand_int64` / `random_bounded_uint64_fill` with rng = 1), as -1.f / 1.f
+ *   tail_kind 2      rng.rand(n) * 2 - 1: one double per element, 2 x - 1 exact in double, then rounded to the nearest float
+ *   tail_total       elements the tail consumes; [tail_skip, tail_skip + tail_count) of them go to tail_out (device, fp32)
+ * The ticket's state is the one behind the tail.  ssn_build_w_mt19937_tail_begin_f32: the tail is zs_in[B_total][2N], rows
+ * b0 .. b0 + nb - 1 go to zin: device [nb][2N].  Windows that lie far apart in the stream (a rank's rows) get a launch each. */
+int ssn_mt19937_random_sample_tail_begin_f32(const unsigned int *key, int pos, unsigned long long total, unsigned long long skip,
+                                             unsigned long long count, float *out, int tail_kind, unsigned long long tail_total,
+                                             unsigned long long tail_skip, unsigned long long tail_count, float *tail_out,
+                                             void *stream, int *ticket);
+int ssn_build_w_mt19937_tail_begin_f32(const unsigned int *key, int pos, int B_total, int b0, int nb, const float *J, const float *D,
+                                       const float *S, float *W, float *z, int N, int tail_kind, float *zin, void *stream, int *ticket);
 /* Host arithmetic of a draw alone (no device): out[7] = {pos after the draw, regenerations of the key up to then, blocks per
  * segment, first and last segment this call generates, first and last block that holds a wanted word} for the given pos /
  * total / skip / count -- what the CPU tests check against numpy's own positions, rank by rank. */

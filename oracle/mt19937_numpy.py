@@ -85,6 +85,15 @@ def random_sample(key, pos, n):
     return (a * 67108864.0 + b) / 9007199254740992.0, key, pos
 
 
+def choice2_signs(key, pos, n):
+    """``RandomState.choice(2, n) * 2 - 1`` (zs_in of the reference's heterogeneous-input models, tc_gan/networks/ssn.py:714-715):
+    (signs, key, pos).  `choice(2, n)` is `randint(0, 2, n)`: numpy's masked rejection for the range [0, 1] draws one 32-bit
+    output per element, keeps its low bit (mask 1) and never rejects (`_rand_int64` -> `random_bounded_uint64_fill`, rng = 1;
+    randomkit's `rk_random_uint64` before numpy 1.17 does the same)."""
+    w, key, pos = words(key, pos, n)
+    return (w & np.uint32(1)).astype(np.int64) * 2 - 1, key, pos
+
+
 def advance_blocks(key, nblocks):
     """key after nblocks refills (sequential; the jump-ahead of the device generator is checked against this)."""
     key = np.asarray(key, dtype=np.uint32)

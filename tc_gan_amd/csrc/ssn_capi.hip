@@ -1255,6 +1255,34 @@ int ssn_build_w_mt19937_begin_f32(const unsigned int* key, int pos, int B_total,
     SSN_TRY(ssn::mt19937_begin(key, pos, mm * B_total, mm * b0, mm * nb, z, 4, (hipStream_t)stream, ticket, nb ? W : nullptr, jds, N));
     return 0;
 }
+int ssn_mt19937_random_sample_tail_begin_f32(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip,
+                                             unsigned long long count, float* out, int tail_kind, unsigned long long tail_total,
+                                             unsigned long long tail_skip, unsigned long long tail_count, float* tail_out, void* stream,
+                                             int* ticket) {
+    if (!key || !ticket) { g_last_error = "ssn_mt19937_random_sample_tail_begin: null state / ticket"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    *ticket = -1;
+    if (tail_kind != 1 && tail_kind != 2) { g_last_error = "ssn_mt19937_random_sample_tail_begin: tail_kind must be 1 (choice(2, n) * 2 - 1) or 2 (rand(n) * 2 - 1)"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    ssn::MtTail tail;
+    tail.kind = tail_kind; tail.total = tail_total; tail.skip = tail_skip; tail.count = tail_count; tail.out = tail_out;
+    SSN_TRY(ssn::mt19937_begin(key, pos, total, skip, count, out, 4, (hipStream_t)stream, ticket, nullptr, nullptr, 0, &tail));
+    return 0;
+}
+int ssn_build_w_mt19937_tail_begin_f32(const unsigned int* key, int pos, int B_total, int b0, int nb, const float* J, const float* D,
+                                       const float* S, float* W, float* z, int N, int tail_kind, float* zin, void* stream, int* ticket) {
+    if (!key || !ticket || !J || !D || !S || (nb && (!W || !zin)) || N < 1 || B_total < 0 || b0 < 0 || nb < 0 || b0 + nb > B_total
+        || (tail_kind != 1 && tail_kind != 2)) {
+        g_last_error = "ssn_build_w_mt19937_tail_begin: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    *ticket = -1;
+    float jds[12];
+    for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }
+    const unsigned long long mm = 4ull * N * N, m = 2ull * N;
+    ssn::MtTail tail;
+    tail.kind = tail_kind; tail.total = m * B_total; tail.skip = m * b0; tail.count = m * nb; tail.out = zin;
+    SSN_TRY(ssn::mt19937_begin(key, pos, mm * B_total, mm * b0, mm * nb, z, 4, (hipStream_t)stream, ticket, nb ? W : nullptr, jds, N, &tail));
+    return 0;
+}
 int ssn_mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out) {
     if (!out || !ssn::mt19937_plan(pos, total, skip, count, out)) { g_last_error = "ssn_mt19937_plan: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     return 0;

@@ -266,8 +266,14 @@ template <typename T> hipError_t launch_dot(const T* x, const T* y, T* out, int 
 int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits);
 hipError_t mt19937_draw(unsigned int* key, int* pos, unsigned long long total, unsigned long long skip, unsigned long long count,
                         void* out, int elem, hipStream_t st);
+// What the caller's stream holds right behind the `total` doubles and is consumed with them: `total` elements, of which
+// [skip, skip + count) are written to `out` as fp32.  kind 1: rng.choice(2, n) * 2 - 1 (one 32-bit output per element),
+// kind 2: rng.rand(n) * 2 - 1 (one double per element), 0: nothing.
+struct MtTail { int kind = 0; unsigned long long total = 0, skip = 0, count = 0; float* out = nullptr; };
+// ticket == nullptr: the numbers only -- the state after the draw is not computed (a second window of a draw begun before)
 hipError_t mt19937_begin(const unsigned int* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
-                         void* out, int elem, hipStream_t st, int* ticket, float* W = nullptr, const float* jds12 = nullptr, int N = 0);
+                         void* out, int elem, hipStream_t st, int* ticket, float* W = nullptr, const float* jds12 = nullptr, int N = 0,
+                         const MtTail* tail = nullptr);
 hipError_t mt19937_finish(int ticket, unsigned int* key, int* pos);
 bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out);
 

@@ -279,6 +279,13 @@ struct GenArgs {
     JDS<float> p = {};
     int N = 0;
     unsigned long long magic_m = 0;   // ceil(2^40 / M): e / M = (e * magic_m) >> 40 for e < 2^28 (count is checked)
+    // The tail (TAIL kernels): what the reference draws right behind zs -- zs_in of the heterogeneous-input models
+    // (ssn.py:710-720), from stream pair tail_q0 = `total` on: kind 1 = rng.choice(2, n) * 2 - 1 (one 32-bit word per element:
+    // numpy's masked rejection with mask 1 takes the low bit of every output and rejects nothing), kind 2 = rng.rand(n) * 2 - 1
+    // (one double per element).  Elements [tail_skip, tail_skip + tail_count) go to tail_out.
+    long tail_q0 = 0, tail_skip = 0, tail_count = 0;
+    int tail_kind = 0;
+    float* tail_out = nullptr;
 };
 
 constexpr int kBufStride = kN + 32;        // (words 624.. of a buffer: where the twelve idle lanes of a pass put their stores)
@@ -323,7 +330,7 @@ __device__ __forceinline__ void gen_block(uint32_t* flat, int lane) {
     gen_store<5>(flat, neww, lane, act, r1);
 }
 
-template <typename T, bool ODD, bool BUILDW>
+template <typename T, bool ODD, bool BUILDW, bool TAIL>
 __device__ __forceinline__ void emit_pass(const GenArgs<T>& a, const uint32_t* blk, const uint32_t* carry_in,
                                           int c, int lane, long qb, const float* gtab) {
     const bool act = lane < 52;
@@ -363,10 +370,25 @@ __device__ __forceinline__ void emit_pass(const GenArgs<T>& a, const uint32_t* b
         } else {
             a.out[qq] = z;
         }
+    } else if constexpr (TAIL) {
+        const long tq = qq + a.skip - a.tail_q0;          // pairs behind the end of the doubles
+        if (act && tq >= 0) {
+            if (a.tail_kind == 1) {
+                const long e0 = 2 * tq - a.tail_skip;
+                if ((unsigned long)e0 < (unsigned long)a.tail_count) a.tail_out[e0] = (w0 & 1u) ? 1.f : -1.f;
+                if ((unsigned long)(e0 + 1) < (unsigned long)a.tail_count) a.tail_out[e0 + 1] = (w1 & 1u) ? 1.f : -1.f;
+            } else {
+                const long e = tq - a.tail_skip;
+                if ((unsigned long)e < (unsigned long)a.tail_count) {
+                    const double v = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) * (1.0 / 9007199254740992.0);
+                    a.tail_out[e] = (float)(2.0 * v - 1.0);       // (exact in double, then round to nearest: the host's astype)
+                }
+            }
+        }
     }
 }
 
-template <typename T, bool ODD, bool BUILDW>
+template <typename T, bool ODD, bool BUILDW, bool TAIL>
 __global__ __launch_bounds__(BUILDW ? 576 : 256) void mt_gen_kernel(const GenArgs<T> a) {
     // waves: 0 regenerates; three emit two passes of a block each -- or, with W formed here (twice the work per number), six emit
     // one pass each.  Waves w and w + 4 of a workgroup share a SIMD: in the nine-wave form waves 4 and 8 do nothing but keep the
@@ -408,8 +430,8 @@ __global__ __launch_bounds__(BUILDW ? 576 : 256) void mt_gen_kernel(const GenArg
             const int ei = BUILDW ? (wave < 4 ? wave - 1 : wave - 2) : wave - 1;        // emitter 0 .. EW - 1 (waves 4, 8: none)
             if (!BUILDW || (wave & 3) != 0) {
                 const int c = PASSES * ei;
-                emit_pass<T, ODD, BUILDW>(a, blk, vcarry + (p ^ 1), c, lane, qb, gtab);
-                if constexpr (PASSES == 2) emit_pass<T, ODD, BUILDW>(a, blk, vcarry + (p ^ 1), c + 1, lane, qb, gtab);
+                emit_pass<T, ODD, BUILDW, TAIL>(a, blk, vcarry + (p ^ 1), c, lane, qb, gtab);
+                if constexpr (PASSES == 2) emit_pass<T, ODD, BUILDW, TAIL>(a, blk, vcarry + (p ^ 1), c + 1, lane, qb, gtab);
                 if (ODD && ei == EW - 1 && lane == 0) vcarry[p] = blk[kN - 1];
             }
         }
@@ -584,15 +606,25 @@ static inline int level_shift(int l) { return kStride0Log2 + kRadixLog2 * l; }
 // state of block s * seg_blocks and regenerates blocks s * seg_blocks + 1 .. (s + 1) * seg_blocks (segment 0 also emits the
 // rest of block 0).
 struct Plan { long p_end, b_f, b_lo, b_hi, s_lo, s_hi; int step; };
-static bool make_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, Plan& pl) {
+static bool make_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, Plan& pl,
+                      const MtTail* tail = nullptr) {
     if (pos < 0 || pos > kN || skip + count > total || total > (1ull << 40)) return false;
-    pl.p_end = (long)pos + 2 * (long)total;                      // position of the first unconsumed word, from block 0
+    // the tail in 32-bit outputs: all of it, and the wanted window (from the end of the doubles)
+    unsigned long long tw_total = 0, tw_first = 0, tw_n = 0;
+    if (tail && tail->kind) {
+        if ((tail->kind != 1 && tail->kind != 2) || tail->skip + tail->count > tail->total || tail->total > (1ull << 40)) return false;
+        const unsigned long long per = tail->kind == 1 ? 1 : 2;
+        tw_total = per * tail->total; tw_first = per * tail->skip; tw_n = per * tail->count;
+    }
+    pl.p_end = (long)pos + 2 * (long)total + (long)tw_total;     // position of the first unconsumed word, from block 0
     pl.b_f = pl.p_end <= kN ? 0 : (pl.p_end - 1) / kN;           // block of the state after the draw
     pl.b_lo = pl.b_hi = pl.s_lo = pl.s_hi = 0;
     pl.step = 1;
-    if (count) {
-        pl.b_lo = ((long)pos + 2 * (long)skip) / kN;
-        pl.b_hi = ((long)pos + 2 * (long)(skip + count) - 1) / kN;
+    if (count || tw_n) {
+        const long first = count ? 2 * (long)skip : 2 * (long)total + (long)tw_first;
+        const long last = tw_n ? 2 * (long)total + (long)(tw_first + tw_n) - 1 : 2 * (long)(skip + count) - 1;
+        pl.b_lo = ((long)pos + first) / kN;
+        pl.b_hi = ((long)pos + last) / kN;
         // segment length 128 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
         // workgroups per state, 768 at a time, ~70 us a round; a segment's workgroup generates a block in ~0.5 us
         double best = 1e30;
@@ -666,18 +698,34 @@ hipError_t mt19937_finish(int ticket, uint32_t* key, int* pos) {
 // [skip, skip + count) of them are written to out (device; elem = 4: float, 8: double) on `st`.  Returns a ticket for the state
 // after the draw (mt19937_finish).
 hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total, unsigned long long skip, unsigned long long count,
-                         void* out, int elem, hipStream_t st, int* ticket, float* W, const float* jds12, int N) {
+                         void* out, int elem, hipStream_t st, int* ticket, float* W, const float* jds12, int N, const MtTail* tail) {
     using namespace mt;
     // W != nullptr (elem 4): W of make_W_with_x from the numbers, in the generation kernel itself; `out` (the z) may then be null
-    if ((count && !out && !W) || (elem != 4 && elem != 8) || !ticket) return hipErrorInvalidValue;
+    if ((count && !out && !W) || (elem != 4 && elem != 8)) return hipErrorInvalidValue;
     if (W && (elem != 4 || !jds12 || N < 1 || N > 2048 || count >= (1ull << 28) || (skip % (4ull * N * N)) != 0)) return hipErrorInvalidValue;
+    if (tail && !tail->kind) tail = nullptr;
+    if (tail && (elem != 4 || (tail->count && !tail->out))) return hipErrorInvalidValue;
+    const bool want_tail = tail && tail->count;
+    if (want_tail && count) {
+        // two windows far apart (a rank's rows of z and its rows of the tail): two launches over what each needs, not one over
+        // everything in between
+        const unsigned long long gap = 2 * (total - skip - count) + (tail->kind == 1 ? 1 : 2) * tail->skip;
+        if (gap > 256ull * kN) {
+            MtTail none = *tail;
+            none.count = 0; none.out = nullptr;
+            const hipError_t e1 = mt19937_begin(key, pos, total, skip, count, out, elem, st, ticket, W, jds12, N, &none);
+            if (e1 != hipSuccess) return e1;
+            return mt19937_begin(key, pos, total, 0, 0, nullptr, elem, st, nullptr, nullptr, nullptr, 0, tail);
+        }
+    }
     Plan pl;
-    if (!make_plan(pos, total, skip, count, pl)) return hipErrorInvalidValue;
+    if (!make_plan(pos, total, skip, count, pl, tail)) return hipErrorInvalidValue;
     const long p_end = pl.p_end, b_f = pl.b_f, b_hi = pl.b_hi, s_lo = pl.s_lo, s_hi = pl.s_hi;
     const int step = pl.step;
     // levels needed: the top digit of the last segment must be <= kDigits
-    int top_b = count ? kSegLevel : -1;
-    if (count)
+    const bool any = count || want_tail;
+    int top_b = any ? kSegLevel : -1;
+    if (any)
         while (((s_hi * step) >> (level_shift(top_b) - level_shift(kSegLevel))) > kDigits) if (++top_b >= kLevels) return hipErrorInvalidValue;
     DeviceTables* t = nullptr;
     hipError_t e = device_tables(top_b, &t);
@@ -690,45 +738,47 @@ hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total,
 
     // (1) the state after the draw, on the side stream: block b_f - 1 by the exact polynomial, then one regeneration
     std::unique_lock<std::mutex> chain_lock(t->chain_mu);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const int slot = (int)(t->next_ticket++ % DeviceTables::kTickets);
-    DeviceTables::Ticket& tk = t->tickets[slot];
-    // a slot still marked busy after the ring has come round: its owner has not asked for the state yet (a generator that sat
-    // idle while others drew, or one that was dropped).  The state is fetched now (its launch is long over) and parked.
-    if (tk.busy) {
-        DeviceTables::Parked pk;
-        pk.pos = tk.pos;
-        if (tk.computed) {
-            if ((e = hipEventSynchronize(tk.done)) != hipSuccess) return e;
-            std::memcpy(pk.key, tk.pinned, sizeof pk.key);
-        } else {
-            std::memcpy(pk.key, tk.key, sizeof pk.key);
+    if (ticket) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int slot = (int)(t->next_ticket++ % DeviceTables::kTickets);
+        DeviceTables::Ticket& tk = t->tickets[slot];
+        // a slot still marked busy after the ring has come round: its owner has not asked for the state yet (a generator that sat
+        // idle while others drew, or one that was dropped).  The state is fetched now (its launch is long over) and parked.
+        if (tk.busy) {
+            DeviceTables::Parked pk;
+            pk.pos = tk.pos;
+            if (tk.computed) {
+                if ((e = hipEventSynchronize(tk.done)) != hipSuccess) return e;
+                std::memcpy(pk.key, tk.pinned, sizeof pk.key);
+            } else {
+                std::memcpy(pk.key, tk.key, sizeof pk.key);
+            }
+            if (t->parked.size() >= 4096) t->parked.erase(t->parked.begin());       // (dropped generators: do not grow for ever)
+            t->parked[(int)((tk.gen & 0x7fffu) << 16) | (dev << 8) | slot] = pk;
+            tk.busy = false;
         }
-        if (t->parked.size() >= 4096) t->parked.erase(t->parked.begin());       // (dropped generators: do not grow for ever)
-        t->parked[(int)((tk.gen & 0x7fffu) << 16) | (dev << 8) | slot] = pk;
-        tk.busy = false;
-    }
-    ++tk.gen;
-    tk.busy = true; tk.computed = b_f >= 1;
-    tk.pos = b_f >= 1 ? (int)(p_end - b_f * kN) : (int)p_end;
-    if (b_f < 1) std::memcpy(tk.key, key, sizeof tk.key);
-    *ticket = (int)((tk.gen & 0x7fffu) << 16) | (dev << 8) | slot;
-    if (b_f >= 1) {
-        DeviceTables::Exact ex{};
-        if ((e = exact_poly(t, b_f - 1, &ex)) != hipSuccess) return e;
-        SoloArgs sa;
-        std::memcpy(sa.root.w, key, sizeof sa.root.w);
-        sa.codes = ex.codes; sa.counts = ex.counts;
-        sa.partials = t->chain; sa.counter = (unsigned*)(t->chain + (size_t)kSoloParts * kN); sa.out = tk.pinned;
-        hipLaunchKernelGGL(mt_solo_kernel, dim3(1, kSoloParts), dim3(320), kJumpLds, t->side, sa);
-        if ((e = hipGetLastError()) != hipSuccess) { tk.busy = false; return e; }
-        if ((e = hipEventRecord(tk.done, t->side)) != hipSuccess) { tk.busy = false; return e; }
+        ++tk.gen;
+        tk.busy = true; tk.computed = b_f >= 1;
+        tk.pos = b_f >= 1 ? (int)(p_end - b_f * kN) : (int)p_end;
+        if (b_f < 1) std::memcpy(tk.key, key, sizeof tk.key);
+        *ticket = (int)((tk.gen & 0x7fffu) << 16) | (dev << 8) | slot;
+        if (b_f >= 1) {
+            DeviceTables::Exact ex{};
+            if ((e = exact_poly(t, b_f - 1, &ex)) != hipSuccess) return e;
+            SoloArgs sa;
+            std::memcpy(sa.root.w, key, sizeof sa.root.w);
+            sa.codes = ex.codes; sa.counts = ex.counts;
+            sa.partials = t->chain; sa.counter = (unsigned*)(t->chain + (size_t)kSoloParts * kN); sa.out = tk.pinned;
+            hipLaunchKernelGGL(mt_solo_kernel, dim3(1, kSoloParts), dim3(320), kJumpLds, t->side, sa);
+            if ((e = hipGetLastError()) != hipSuccess) { tk.busy = false; return e; }
+            if ((e = hipEventRecord(tk.done, t->side)) != hipSuccess) { tk.busy = false; return e; }
+        }
     }
 
     // (2) the wanted doubles: the states of every level between the root and the segments, top down, on the side stream (behind
     // the launch above) into a set of the library's buffers; then, on the caller's stream, the generation kernel
-    if (count) {
+    if (any) {
         DeviceTables::BulkSet& bs = t->bulk[t->next_bulk++ % DeviceTables::kBulkSets];
         if (!bs.ready) {
             if ((e = hipEventCreateWithFlags(&bs.ready, hipEventDisableTiming)) != hipSuccess) return e;
@@ -776,6 +826,11 @@ hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total,
             const bool odd = pos & 1;
             if (elem == 4) {
                 GenArgs<float> ga{parent, parent_parts, s_lo, s_hi, step << kStride0Log2, b_hi, pos, (long)skip, (long)count, (float*)out};
+                if (want_tail) {
+                    ga.tail_q0 = (long)total; ga.tail_skip = (long)tail->skip; ga.tail_count = (long)tail->count;
+                    ga.tail_kind = tail->kind; ga.tail_out = tail->out;
+                }
+                size_t glds = 0;
                 if (W) {
                     ga.W = W; ga.N = N;
                     ga.magic_m = ((1ull << 40) + 2ull * N - 1) / (2ull * N);
@@ -783,15 +838,25 @@ hipError_t mt19937_begin(const uint32_t* key, int pos, unsigned long long total,
                         ga.p.J[q] = jds12[q]; ga.p.D[q] = jds12[4 + q];
                         ga.p.inv2s2[q] = 1.f / (2.f * jds12[8 + q] * jds12[8 + q]);
                     }
-                    const size_t glds = sizeof(float) * 4 * (size_t)N;
-                    if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true, true>), dim3(nseg), dim3(576), glds, st, ga);
-                    else hipLaunchKernelGGL((mt_gen_kernel<float, false, true>), dim3(nseg), dim3(576), glds, st, ga);
-                } else if (odd) hipLaunchKernelGGL((mt_gen_kernel<float, true, false>), dim3(nseg), dim3(256), 0, st, ga);
-                else hipLaunchKernelGGL((mt_gen_kernel<float, false, false>), dim3(nseg), dim3(256), 0, st, ga);
+                    glds = sizeof(float) * 4 * (size_t)N;
+                }
+                // <float, ODD, BUILDW, TAIL>
+                const int form = (odd ? 4 : 0) | (W ? 2 : 0) | (want_tail ? 1 : 0);
+                const dim3 grid(nseg), blk(W ? 576 : 256);
+                switch (form) {
+                    case 0: hipLaunchKernelGGL((mt_gen_kernel<float, false, false, false>), grid, blk, glds, st, ga); break;
+                    case 1: hipLaunchKernelGGL((mt_gen_kernel<float, false, false, true>), grid, blk, glds, st, ga); break;
+                    case 2: hipLaunchKernelGGL((mt_gen_kernel<float, false, true, false>), grid, blk, glds, st, ga); break;
+                    case 3: hipLaunchKernelGGL((mt_gen_kernel<float, false, true, true>), grid, blk, glds, st, ga); break;
+                    case 4: hipLaunchKernelGGL((mt_gen_kernel<float, true, false, false>), grid, blk, glds, st, ga); break;
+                    case 5: hipLaunchKernelGGL((mt_gen_kernel<float, true, false, true>), grid, blk, glds, st, ga); break;
+                    case 6: hipLaunchKernelGGL((mt_gen_kernel<float, true, true, false>), grid, blk, glds, st, ga); break;
+                    default: hipLaunchKernelGGL((mt_gen_kernel<float, true, true, true>), grid, blk, glds, st, ga); break;
+                }
             } else {
                 GenArgs<double> ga{parent, parent_parts, s_lo, s_hi, step << kStride0Log2, b_hi, pos, (long)skip, (long)count, (double*)out};
-                if (odd) hipLaunchKernelGGL((mt_gen_kernel<double, true, false>), dim3(nseg), dim3(256), 0, st, ga);
-                else hipLaunchKernelGGL((mt_gen_kernel<double, false, false>), dim3(nseg), dim3(256), 0, st, ga);
+                if (odd) hipLaunchKernelGGL((mt_gen_kernel<double, true, false, false>), dim3(nseg), dim3(256), 0, st, ga);
+                else hipLaunchKernelGGL((mt_gen_kernel<double, false, false, false>), dim3(nseg), dim3(256), 0, st, ga);
             }
             e = hipGetLastError();
             if (e == hipSuccess) { e = hipEventRecord(bs.consumed, st); bs.used = true; }

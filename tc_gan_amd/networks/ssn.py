@@ -63,17 +63,33 @@ def make_flat_param_names(named_params):
 
 
 def _is_mt19937(rng):
-    return isinstance(rng, np.random.RandomState) and rng.get_state(legacy=True)[0] == 'MT19937' \
-        if hasattr(rng, 'get_state') else False
+    # (the bit generator's type, not get_state()[0]: that copies the 624-word key at every call)
+    return isinstance(rng, np.random.RandomState) and isinstance(getattr(rng, '_bit_generator', None), np.random.MT19937)
 
 
-def device_rand(rng, shape, tdtype, rows=None):
+TAIL_KINDS = {'bernoulli': 1, 'uniform': 2}
+
+
+def _ticket_finisher(ticket, key, kind, has_gauss, cached):
+    """What `DeviceContinuedRandomState` runs when its state is next needed: the state behind a draw begun on the device."""
+    def finish(r):
+        cpos = ctypes.c_int(0)
+        clib.check(clib.libssnode.ssn_mt19937_random_sample_finish(ticket, key.ctypes.data, ctypes.byref(cpos)),
+                   'ssn_mt19937_random_sample_finish')
+        np.random.RandomState.set_state(r, (kind, key, cpos.value, has_gauss, cached))
+    return finish
+
+
+def device_rand(rng, shape, tdtype, rows=None, tail=None):
     """``rng.rand(*shape)`` of a ``numpy.random.RandomState`` -- the reference's ``zs = rng.rand(batchsize, 2N, 2N)``
     (ssn.py:434-439) -- generated on the device, bit for bit (`ssn_mt19937_random_sample_*`), as a tensor of `tdtype`
     (float32: each double rounded to nearest, like the reference's downcast to floatX).  `rng` is left in the state numpy
     would have left it in, so the host draws that follow (minibatch `choice`, `eps`) continue the reference's stream.
     `rows = (lo, hi)`: only rows lo..hi-1 of the draw are generated (a rank's share of the global draw); the state still
-    advances by the whole draw."""
+    advances by the whole draw.
+    `tail = (dist_in, width)` (float32, a `DeviceContinuedRandomState`): the draw the heterogeneous-input models make right
+    behind it, ``zs_in = rng.choice(2, (shape[0], width)) * 2 - 1`` ('bernoulli') or ``rng.rand(shape[0], width) * 2 - 1``
+    ('uniform'; ssn.py:710-720), in the same call -- the host does not fetch the state in between; returns (z, zs_in)."""
     kind, key, pos, has_gauss, cached = rng.get_state()
     if kind != 'MT19937':
         raise ValueError('device_rand continues numpy RandomState (MT19937) streams only, got {!r}'.format(kind))
@@ -84,6 +100,17 @@ def device_rand(rng, shape, tdtype, rows=None):
     lo, hi = (0, shape[0]) if rows is None else (int(rows[0]), int(rows[1]))
     out = torch.empty((hi - lo,) + shape[1:], device='cuda', dtype=tdtype)
     f32 = tdtype == torch.float32
+    if tail is not None:
+        assert f32 and hasattr(rng, '_defer')
+        width = int(tail[1])
+        zin = torch.empty((hi - lo, width), device='cuda', dtype=torch.float32)
+        ticket = ctypes.c_int(-1)
+        clib.check(clib.libssnode.ssn_mt19937_random_sample_tail_begin_f32(
+            key.ctypes.data, int(pos), shape[0] * per_row, lo * per_row, (hi - lo) * per_row, out.data_ptr(), TAIL_KINDS[tail[0]],
+            shape[0] * width, lo * width, (hi - lo) * width, zin.data_ptr(), clib.stream_ptr(), ctypes.byref(ticket)),
+            'ssn_mt19937_random_sample_tail_begin_f32')
+        rng._defer(_ticket_finisher(ticket.value, key, kind, has_gauss, cached))
+        return out, zin
     if hasattr(rng, '_defer'):
         # the state after the draw is fetched when `rng` is next used (utils.DeviceContinuedRandomState): the caller goes on
         # queuing its launches meanwhile
@@ -92,12 +119,7 @@ def device_rand(rng, shape, tdtype, rows=None):
         clib.check(fn(key.ctypes.data, int(pos), shape[0] * per_row, lo * per_row, (hi - lo) * per_row, out.data_ptr(),
                       clib.stream_ptr(), ctypes.byref(ticket)), 'ssn_mt19937_random_sample_begin')
 
-        def finish(r, ticket=ticket.value, key=key, kind=kind, has_gauss=has_gauss, cached=cached):
-            cpos = ctypes.c_int(0)
-            clib.check(clib.libssnode.ssn_mt19937_random_sample_finish(ticket, key.ctypes.data, ctypes.byref(cpos)),
-                       'ssn_mt19937_random_sample_finish')
-            np.random.RandomState.set_state(r, (kind, key, cpos.value, has_gauss, cached))
-        rng._defer(finish)
+        rng._defer(_ticket_finisher(ticket.value, key, kind, has_gauss, cached))
         return out
     cpos = ctypes.c_int(int(pos))
     fn = clib.libssnode.ssn_mt19937_random_sample_f32 if f32 else clib.libssnode.ssn_mt19937_random_sample_f64
@@ -109,6 +131,8 @@ def device_rand(rng, shape, tdtype, rows=None):
 
 # (A/B switch: TCGAN_MT_FUSE_W=0 keeps the draw and the W build in two launches)
 _FUSE_W = __import__('os').environ.get('TCGAN_MT_FUSE_W', '1') != '0'
+# (A/B switch: TCGAN_MT_TAIL=0 draws zs_in of the heterogeneous-input models on the host, after fetching the state behind zs)
+_TAIL = __import__('os').environ.get('TCGAN_MT_TAIL', '1') != '0'
 
 
 class MTWeights(object):
@@ -119,10 +143,11 @@ class MTWeights(object):
         self.z, self.W = z, W
 
 
-def device_rand_weights(rng, num_models, N, J, D, S, rows=None, keep_z=True):
+def device_rand_weights(rng, num_models, N, J, D, S, rows=None, keep_z=True, tail=None):
     """`device_rand(rng, (num_models, 2N, 2N), float32, rows)` and `generate_weight_batch` of it in ONE launch
     (`ssn_build_w_mt19937_begin_f32`: W is formed where the numbers are, z goes to memory only when `keep_z`): same numbers,
-    same bits, `rng` left as numpy would leave it.  Returns `MTWeights`."""
+    same bits, `rng` left as numpy would leave it.  Returns `MTWeights` -- with `tail` = 'bernoulli' / 'uniform' the pair
+    (MTWeights, zs_in[rows][2N]): the heterogeneous-input draw behind zs in the same call (see `device_rand`)."""
     kind, key, pos, has_gauss, cached = rng.get_state()
     if kind != 'MT19937':
         raise ValueError('device_rand_weights continues numpy RandomState (MT19937) streams only, got {!r}'.format(kind))
@@ -134,20 +159,23 @@ def device_rand_weights(rng, num_models, N, J, D, S, rows=None, keep_z=True):
     z = torch.empty_like(W) if keep_z else None
     arrs = [(ctypes.c_float * 4)(*np.asarray(a, dtype='double').reshape(4)) for a in (J, D, S)]
     ticket = ctypes.c_int(-1)
-    clib.check(clib.libssnode.ssn_build_w_mt19937_begin_f32(
-        key.ctypes.data, int(pos), int(num_models), lo, hi - lo, arrs[0], arrs[1], arrs[2], W.data_ptr(),
-        z.data_ptr() if keep_z else None, int(N), clib.stream_ptr(), ctypes.byref(ticket)), 'ssn_build_w_mt19937_begin_f32')
-
-    def finish(r, ticket=ticket.value, key=key, kind=kind, has_gauss=has_gauss, cached=cached):
-        cpos = ctypes.c_int(0)
-        clib.check(clib.libssnode.ssn_mt19937_random_sample_finish(ticket, key.ctypes.data, ctypes.byref(cpos)),
-                   'ssn_mt19937_random_sample_finish')
-        np.random.RandomState.set_state(r, (kind, key, cpos.value, has_gauss, cached))
+    zin = None
+    if tail is not None:
+        zin = torch.empty((hi - lo, M), device='cuda', dtype=torch.float32)
+        clib.check(clib.libssnode.ssn_build_w_mt19937_tail_begin_f32(
+            key.ctypes.data, int(pos), int(num_models), lo, hi - lo, arrs[0], arrs[1], arrs[2], W.data_ptr(),
+            z.data_ptr() if keep_z else None, int(N), TAIL_KINDS[tail], zin.data_ptr(), clib.stream_ptr(), ctypes.byref(ticket)),
+            'ssn_build_w_mt19937_tail_begin_f32')
+    else:
+        clib.check(clib.libssnode.ssn_build_w_mt19937_begin_f32(
+            key.ctypes.data, int(pos), int(num_models), lo, hi - lo, arrs[0], arrs[1], arrs[2], W.data_ptr(),
+            z.data_ptr() if keep_z else None, int(N), clib.stream_ptr(), ctypes.byref(ticket)), 'ssn_build_w_mt19937_begin_f32')
+    finish = _ticket_finisher(ticket.value, key, kind, has_gauss, cached)
     if hasattr(rng, '_defer'):
         rng._defer(finish)            # (fetched when `rng` is next used: utils.DeviceContinuedRandomState)
     else:
         finish(rng)
-    return MTWeights(z, W)
+    return MTWeights(z, W) if tail is None else (MTWeights(z, W), zin)
 
 
 class PhiloxDraw(object):
@@ -392,12 +420,21 @@ class TuningCurveGenerator(object):
                 noise['model_zs_in'] = self._zgen.lazy_signs_and_amp((num_models, M), self.tdtype, vs, self.dist_in == 'bernoulli')
             return noise
         sl = slice(None) if rows is None else slice(int(rows[0]), int(rows[1]))
+        # zs_in of the heterogeneous-input models follows zs in the stream (ssn.py:764-767): drawn by the same device call when
+        # it can be (fp32, a generator whose state is fetched lazily), so that the host need not wait for the state in between
+        tail = self.dist_in if (self.heteroin and _TAIL and self.tdtype == torch.float32 and hasattr(rng, '_defer')) else None
         if self.z_host_draw or not _is_mt19937(rng):
             noise = dict(model_zs=rng.rand(num_models, M, M)[sl])
         elif keep_z is not None and _FUSE_W and self.tdtype == torch.float32 and num_models * M * M < (1 << 28):
-            noise = dict(model_zs=device_rand_weights(rng, num_models, self.num_sites, self.J, self.D, self.S, rows=rows, keep_z=keep_z))
+            got = device_rand_weights(rng, num_models, self.num_sites, self.J, self.D, self.S, rows=rows, keep_z=keep_z, tail=tail)
+            if tail is not None:
+                return dict(model_zs=got[0], model_zs_in=got[1])
+            noise = dict(model_zs=got)
         else:
-            noise = dict(model_zs=device_rand(rng, (num_models, M, M), self.tdtype, rows=rows))
+            got = device_rand(rng, (num_models, M, M), self.tdtype, rows=rows, tail=None if tail is None else (tail, M))
+            if tail is not None:
+                return dict(model_zs=got[0], model_zs_in=got[1])
+            noise = dict(model_zs=got)
         if self.heteroin:                       # drawn AFTER zs (ssn.py:764-767), ssn.py:707-720; small: stays on the host
             shape = (num_models, M)
             noise['model_zs_in'] = (rng.choice(2, shape) * 2 - 1 if self.dist_in == 'bernoulli'
@@ -463,7 +500,8 @@ class TuningCurveGenerator(object):
             if isinstance(model_zs_in, PhiloxAmp):
                 zin, amp = model_zs_in.materialize()                      # device noise outside the one-call path (fp64)
             else:
-                zin = to_device(model_zs_in, self.tdtype)                 # (pinned staging: no wait for queued kernels)
+                zin = (model_zs_in.to(self.tdtype) if torch.is_tensor(model_zs_in)      # (drawn on the device: `gen_noise`)
+                       else to_device(model_zs_in, self.tdtype))          # (pinned staging: no wait for queued kernels)
                 amp = 1 + vs[None, :] * zin                               # ssn.py:679-684
             self._zin = zin
         ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)

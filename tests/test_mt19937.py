@@ -36,6 +36,25 @@ def test_oracle_odd_position_and_fp32_downcast():
     assert (want.astype('float32') == got.astype('float32')).all()
 
 
+@pytest.mark.parametrize('start_odd', [False, True])
+def test_oracle_choice2_signs_equal_numpy_and_the_stream_goes_on(start_odd):
+    """zs_in of the heterogeneous-input models behind zs (ssn.py:714-715, 764-767): one output word per element, its low bit."""
+    rs = np.random.RandomState(3)
+    if start_odd:
+        rs.randint(0, 2 ** 31)
+    rs.random_sample(1000)
+    st = rs.get_state()
+    key, pos = st[1], st[2]
+    for n in (1, 7, 624, 1249):
+        want = rs.choice(2, (n,)) * 2 - 1
+        got, key, pos = mt.choice2_signs(key, pos, n)
+        assert (want == got).all()
+        assert (rs.get_state()[1] == key).all() and rs.get_state()[2] == pos
+        w2 = rs.random_sample(5)                   # (an odd number of words consumed: the doubles behind it pair up from there)
+        g2, key, pos = mt.random_sample(key, pos, 5)
+        assert (w2 == g2).all()
+
+
 @pytest.mark.parametrize('nblocks', [1, 4, 33, 256, 1000])
 def test_jump_polynomial_equals_stepping(nblocks):
     from tc_gan_amd import clib

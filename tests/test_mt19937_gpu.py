@@ -185,3 +185,54 @@ def test_weights_in_the_draw_s_own_launch_bit_equal_draw_then_build(N, B, rows, 
     # ... and W itself against the fp64 restatement of weight_gen.generate_weight (the reference's numpy form)
     ref = np.stack([on.generate_weight(N, jds['J'], jds['D'], jds['S'], zz.astype('float64')) for zz in z[:2]])
     np.testing.assert_allclose(got.W[:2].cpu().numpy(), ref, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('kind', ['bernoulli', 'uniform'])
+@pytest.mark.parametrize('N,B,rows,warm', [(10, 5, None, 0), (3, 2, None, 1), (100, 40, None, 7), (101, 128, None, 0), (101, 16, (4, 12), 311),
+                                           (100, 64, (32, 64), 0), (100, 64, (0, 32), 623), (102, 9, (0, 9), 624), (100, 1024, (0, 128), 5)])
+def test_input_noise_behind_zs_in_the_same_call(kind, N, B, rows, warm):
+    """`ssn_build_w_mt19937_tail_begin_f32` / `ssn_mt19937_random_sample_tail_begin_f32`: zs and, right behind it in the
+    stream, zs_in of the heterogeneous-input models (ssn.py:710-720, 764-767) -- `rng.choice(2, (B, 2N)) * 2 - 1` or
+    `rng.rand(B, 2N) * 2 - 1` -- in one call, against numpy making the two draws: same z, same W, same zs_in (as fp32), same
+    RandomState afterwards, also for a rank's rows (windows far apart in the stream: a launch each)."""
+    from oracle import ssn_numpy as on
+    from tc_gan_amd.networks.ssn import device_rand, device_rand_weights
+    from tc_gan_amd.utils import as_randomstate
+    from tc_gan_amd.weight_gen import generate_weight_batch
+    jds = on.new_JDS()
+    M = 2 * N
+    host = np.random.RandomState(11)
+    devs = [as_randomstate(11) for _ in range(3)]
+    for rs in [host] + devs:
+        if warm:
+            rs.randint(0, 2 ** 31, size=warm)
+    lo, hi = rows or (0, B)
+    z = host.rand(B, M, M).astype('float32')[lo:hi]
+    zin = (host.choice(2, (B, M)) * 2 - 1 if kind == 'bernoulli' else host.rand(B, M) * 2 - 1).astype('float32')[lo:hi]
+    want = generate_weight_batch(N, jds['J'], jds['D'], jds['S'], torch.as_tensor(z).cuda(), dtype='float32')
+    got, gin = device_rand_weights(devs[0], B, N, jds['J'], jds['D'], jds['S'], rows=rows, keep_z=True, tail=kind)
+    assert torch.equal(got.W, want) and np.array_equal(got.z.cpu().numpy(), z) and np.array_equal(gin.cpu().numpy(), zin)
+    none, nin = device_rand_weights(devs[1], B, N, jds['J'], jds['D'], jds['S'], rows=rows, keep_z=False, tail=kind)
+    assert none.z is None and torch.equal(none.W, want) and np.array_equal(nin.cpu().numpy(), zin)
+    gz, gzin = device_rand(devs[2], (B, M, M), torch.float32, rows=rows, tail=(kind, M))
+    assert np.array_equal(gz.cpu().numpy(), z) and np.array_equal(gzin.cpu().numpy(), zin)
+    for rs in devs:
+        assert np.array_equal(rs.get_state()[1], host.get_state()[1]) and rs.get_state()[2] == host.get_state()[2]
+    assert np.array_equal(host.choice(1000, 50), devs[0].choice(1000, 50))
+
+
+@pytest.mark.parametrize('dist_in', ['bernoulli', 'uniform'])
+def test_gan_loop_heterogeneous_input_noise_on_the_device_equals_host_draw(dist_in, monkeypatch):
+    """The deg-heteroin loop with zs_in drawn behind zs on the device (default), with zs_in drawn on the host after fetching
+    the state (TCGAN_MT_TAIL=0) and with everything drawn by numpy: the same records, parameters and RandomState."""
+    from tc_gan_amd.networks import ssn
+    a = _gan_run(False, 'deg-heteroin', dist_in=dist_in)
+    monkeypatch.setattr(ssn, '_TAIL', False)
+    b = _gan_run(False, 'deg-heteroin', dist_in=dist_in)
+    c = _gan_run(True, 'deg-heteroin', dist_in=dist_in)
+    for other in (b, c):
+        assert np.array_equal(a[0], other[0])
+        assert np.array_equal(a[1], other[1]) and a[2] == other[2]
+        for x, y in zip(a[3], other[3]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[4], other[4])
