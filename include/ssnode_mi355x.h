@@ -164,6 +164,10 @@ int ssn_build_w_f32(const float *z, const float *J, const float *D, const float 
                     float *W, int B, int N, void *stream);
 int ssn_build_w_f64(const double *z, const double *J, const double *D, const double *S,
                     double *W, int B, int N, void *stream);
+/* ssn_build_w_f32 with J, D, S read on the DEVICE: jds_dev = device float[12] (J, D, S, each 2x2 row-major) -- e.g. the
+ * parameter vector an ssn_gen_apply_f32 queued on the same stream is about to update, so that the next forward can be queued
+ * before the host has read the new values.  Same arithmetic, same bits as ssn_build_w_f32 of the same values. */
+int ssn_build_w_devparams_f32(const float *z, const float *jds_dev, float *W, int B, int N, void *stream);
 
 /*
  * Stimulus: ext[b][s][pN + i] = c[b][s] * sig((x_i + bw/2)/l) * sig((bw/2 - x_i)/l),

@@ -10,9 +10,25 @@ namespace ssn {
 // W[b][pN+i][qN+j] = exp(-(x_i-x_j)^2/(2 S_pq^2)) * sign_q * (J_pq + D_pq z[b][pN+i][qN+j])
 // (gradient_expressions/make_w_batch.py:8-34; weight_gen.py:13-26).  8 B/element of HBM
 // traffic; one thread per 4 consecutive columns when M % 4 == 0 (16-B accesses).
+// pdev != nullptr: J, D, S as DEVICE T[12] (what an optimizer launch queued just before has left there -- the host has not
+// seen the values yet); the constants derived from them by the host's own expressions, so that the same values give the same W
 template <typename T, int VEC>
 __global__ void __launch_bounds__(256) build_w_kernel(const T* __restrict__ z, T* __restrict__ W, JDS<T> p,
-                                                      int N, long total_vec) {
+                                                      int N, long total_vec, const T* __restrict__ pdev) {
+    if (pdev) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p.J[q] = pdev[q];
+            p.D[q] = pdev[4 + q];
+            const T s = pdev[8 + q];
+            T two_s2;
+            {
+#pragma clang fp contract(off)
+                two_s2 = (T)2 * s * s;
+            }
+            p.inv2s2[q] = (T)1 / two_s2;
+        }
+    }
     const int M = 2 * N;
     const T inv_nm1 = (N > 1) ? (T)1 / (T)(N - 1) : (T)0;
     for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < total_vec; v += (long)gridDim.x * blockDim.x) {
@@ -40,9 +56,9 @@ __global__ void __launch_bounds__(256) build_w_kernel(const T* __restrict__ z, T
 }
 
 template <typename T>
-hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st) {
-    JDS<T> p;
-    for (int q = 0; q < 4; ++q) {
+hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st, const T* jds12_dev) {
+    JDS<T> p = {};
+    for (int q = 0; q < 4 && !jds12_dev; ++q) {
         p.J[q] = jds12[q];
         p.D[q] = jds12[4 + q];
         p.inv2s2[q] = (T)1 / ((T)2 * jds12[8 + q] * jds12[8 + q]);
@@ -53,12 +69,12 @@ hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStr
     const bool vec4 = (M % 4 == 0) && (((uintptr_t)z | (uintptr_t)W) % (4 * sizeof(T)) == 0);
     const long nvec = vec4 ? total / 4 : total;
     const int blocks = (int)((nvec + 255) / 256 < 256 * 8 ? (nvec + 255) / 256 : 256 * 8);
-    if (vec4) hipLaunchKernelGGL((build_w_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, z, W, p, N, nvec);
-    else      hipLaunchKernelGGL((build_w_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, z, W, p, N, nvec);
+    if (vec4) hipLaunchKernelGGL((build_w_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, z, W, p, N, nvec, jds12_dev);
+    else      hipLaunchKernelGGL((build_w_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, z, W, p, N, nvec, jds12_dev);
     return hipGetLastError();
 }
-template hipError_t launch_build_w<float>(const float*, const float*, float*, int, int, hipStream_t);
-template hipError_t launch_build_w<double>(const double*, const double*, double*, int, int, hipStream_t);
+template hipError_t launch_build_w<float>(const float*, const float*, float*, int, int, hipStream_t, const float*);
+template hipError_t launch_build_w<double>(const double*, const double*, double*, int, int, hipStream_t, const double*);
 
 // ext[b][s][pN+i] = c * sig((x_i + bw/2)/l) * sig((bw/2 - x_i)/l)   (stimuli.py:3-10)
 template <typename T>

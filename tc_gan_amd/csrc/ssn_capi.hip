@@ -1188,6 +1188,11 @@ int ssn_build_w_f32(const float* z, const float* J, const float* D, const float*
     SSN_TRY(ssn::launch_build_w<float>(z, jds, W, B, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_build_w_devparams_f32(const float* z, const float* jds_dev, float* W, int B, int N, void* stream) {
+    if (!jds_dev || (B > 0 && (!z || !W)) || N < 1 || B < 0) { g_last_error = "ssn_build_w_devparams_f32: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    SSN_TRY(ssn::launch_build_w<float>(z, nullptr, W, B, N, (hipStream_t)stream, jds_dev));
+    return 0;
+}
 int ssn_build_w_f64(const double* z, const double* J, const double* D, const double* S, double* W, int B, int N, void* stream) {
     double jds[12];
     for (int q = 0; q < 4; ++q) { jds[q] = J[q]; jds[4 + q] = D[q]; jds[8 + q] = S[q]; }

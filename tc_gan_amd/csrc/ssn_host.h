@@ -243,7 +243,8 @@ hipError_t launch_ff_backward_sparse(const FFArgs& a, const int* idx, const floa
 hipError_t launch_moment_sums(const float* x, int B, int D, double* sums, hipStream_t st);
 hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg, const double* data_moments,
                                    const double* weights, int B, int D, float* gx, double* out, hipStream_t st);
-template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st);
+// jds12_dev: J, D, S as device T[12] instead of the host's jds12 (which may then be null)
+template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st, const T* jds12_dev = nullptr);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st);
 template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st);
 template <typename T> hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long offset, T* out, unsigned long long n, hipStream_t st);

@@ -454,6 +454,11 @@ class TuningCurveGenerator(object):
         return dev
 
     def _input_variability(self):
+        pd = self.__dict__.get('_params_dev')
+        if pd is not None:
+            # (V where the optimizer launch leaves it: the host has not read the new value yet -- `forward(params_dev=...)`)
+            v = pd['V'].to(self.tdtype).reshape(-1)
+            return (v.expand(2) if v.numel() == 1 else v).repeat_interleave(self.num_sites)
         # (per-neuron vector from the population values; rebuilt only when V changed -- twice per forward otherwise)
         v = np.asarray(self.V, dtype='float64')
         hit = self.__dict__.get('_vs_of')
@@ -518,6 +523,12 @@ class TuningCurveGenerator(object):
             z = model_zs.to('cuda', self.tdtype).contiguous()
         else:
             z = torch.as_tensor(np.ascontiguousarray(model_zs)).to('cuda', self.tdtype)
+        pd = self.__dict__.get('_params_dev')
+        if pd is not None:
+            W = torch.empty_like(z)
+            clib.check(clib.libssnode.ssn_build_w_devparams_f32(z.data_ptr(), pd['JDS'].data_ptr(), W.data_ptr(), int(z.shape[0]),
+                                                                int(self.num_sites), clib.stream_ptr()), 'ssn_build_w_devparams_f32')
+            return ext, z, W
         W = generate_weight_batch(self.num_sites, self.J, self.D, self.S, z, dtype=self.dtype)
         return ext, z, W
 
@@ -544,16 +555,29 @@ class TuningCurveGenerator(object):
         tc = time_avg[:, :, pr].reshape(time_avg.shape[0], -1)                         # ssn.py:846-848
         return tc, None, pr
 
-    def forward(self, rng=None, save=False, **kwargs):
+    def accepts_params_dev(self, model_zs):
+        """Whether `forward(params_dev=...)` can form this draw's W from device-resident parameters: fp32, z given as numbers."""
+        return self.tdtype == torch.float32 and (torch.is_tensor(model_zs) or isinstance(model_zs, np.ndarray))
+
+    def forward(self, rng=None, save=False, params_dev=None, **kwargs):
         """ssn.py:910-914.  Keyword inputs: stimulator_bandwidths, stimulator_contrasts (num_models, num_tcdom),
         model_zs (optional when `rng` is given), model_rate_penalty_threshold, and for the conditional prober
-        prober_norm_probes, prober_model_ids, prober_cell_types.  Outputs are torch CUDA tensors."""
+        prober_norm_probes, prober_model_ids, prober_cell_types.  Outputs are torch CUDA tensors.
+        `params_dev` = dict(JDS=device float32[12][, V=device float32[1 or 2]]): W (and the input variability) from these
+        device values instead of the attributes J, D, S, V -- for a caller whose optimizer launch has just been queued and
+        who has not read the new values back yet (`accepts_params_dev`; same values, same W bits)."""
         if rng is not None or self._zgen is not None:
             if 'model_zs' not in kwargs:
                 kwargs.update(self.gen_noise(rng, **kwargs))
         theta = kwargs.pop('model_rate_penalty_threshold', 200.0)
-        ext, z, W = self._device_inputs(kwargs.pop('stimulator_bandwidths'), kwargs.pop('stimulator_contrasts'),
-                                        kwargs.pop('model_zs'), kwargs.pop('model_zs_in', None), save=save)
+        if params_dev is not None:
+            assert self.accepts_params_dev(kwargs['model_zs'])
+        self._params_dev = params_dev
+        try:
+            ext, z, W = self._device_inputs(kwargs.pop('stimulator_bandwidths'), kwargs.pop('stimulator_contrasts'),
+                                            kwargs.pop('model_zs'), kwargs.pop('model_zs_in', None), save=save)
+        finally:
+            self._params_dev = None
         probe_kw = {k: kwargs.pop(k) for k in list(kwargs) if k.startswith('prober_')}
         assert not kwargs, 'unknown inputs: {}'.format(sorted(kwargs))
         gp = self.gen_params(theta)

@@ -383,3 +383,49 @@ def test_poisoned_generator_gradient_is_not_hidden_by_the_parameter_bounds(tail,
     assert np.isfinite(values).all() and np.isfinite(info.gen_loss)
     np.testing.assert_allclose(values, want, rtol=1e-5, atol=1e-7)
     assert all(gan.gen_updaters[name].step == 1 for name in gan._pnames)
+
+
+def _small_run(records, ssn_type='default', poke=None, **over):
+    from tc_gan_amd.networks.cwgan import make_gan
+    JDS = on.new_JDS()
+    cfg = dict(num_sites=10, seqlen=40, skip_steps=30, num_models=6, probes_per_model=2, norm_probes=[0, 0.5],
+               include_inhibitory_neurons=True, bandwidths=[0.0625, 0.125, 0.25, 0.75], contrasts=[5., 20.],
+               J0=JDS['J'], D0=JDS['D'], S0=JDS['S'], critic_iters_init=3, critic_iters=2, lipschitz_cost=10.0, ssn_type=ssn_type,
+               gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01, rate_penalty_threshold=5.0),
+               disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[16, 16], normalization='none',
+                         nonlinearity='rectify', precision='fp32'))
+    cfg.update(over)
+    gan, _ = make_gan(cfg)
+    ncols = len(gan.bandwidths) * len(gan.contrasts) * len(gan.norm_probes) * 2
+    gan.set_dataset(np.random.RandomState(3).rand(9, ncols) * 10)
+    it = gan.learning()
+    out, taken = [], 0
+    for k in range(records):
+        info = next(it)
+        out.append(info.disc_loss if info.is_discriminator else info.gen_loss)
+        if not info.is_discriminator:
+            taken += gan._next_ctx is not None
+            if poke is not None and info.gen_step == poke:
+                gan.gen.J = np.asarray(gan.gen.J) * 1.01          # (somebody changes the generator between two iterations)
+    st = gan.rng.get_state()
+    return np.array(out), st[1].copy(), int(st[2]), gan.get_gen_param(), gan.disc.get_flat().copy(), taken
+
+
+@pytest.mark.parametrize('over', [dict(), dict(ssn_type='deg-heteroin'), dict(ssn_type='heteroin', V=[0.3, 0.1]), dict(z_host_draw=True)])
+def test_first_critic_forward_queued_behind_the_generator_update_gives_the_same_run(over, monkeypatch):
+    """`_prequeue_next_disc`: the next iteration's first critic forward is queued behind the optimizer launch, W (and the input
+    variability) formed from the device-resident parameters (`ssn_build_w_devparams_f32`), before the host has read the new
+    values.  Same records, parameters and RandomState as the loop that reads first (TCGAN_PREQUEUE=0), bit for bit -- also
+    when somebody changes a parameter between two iterations (the prepared step is dropped and made again)."""
+    from tc_gan_amd.networks import cwgan
+    for poke in (None, 2):
+        monkeypatch.setattr(cwgan, '_PREQUEUE', True)
+        a = _small_run(20, poke=poke, **over)
+        monkeypatch.setattr(cwgan, '_PREQUEUE', False)
+        b = _small_run(20, poke=poke, **over)
+        assert a[5] >= 4 and b[5] == 0              # (the prepared step was there after every generator step / never)
+        assert np.array_equal(a[0], b[0]) and np.isfinite(a[0]).all()
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2]
+        for x, y in zip(a[3], b[3]):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[4], b[4])
