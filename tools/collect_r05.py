@@ -22,7 +22,8 @@ SRC = os.path.join(ROOT, 'gpurun_out')
 COPIES = [   # (source under gpurun_out/, name under profiles/r05/)
     ('prof_r05/c2_kernel_stats.csv', 'c2_kernel_stats.csv'), ('prof_r05/c3_kernel_stats.csv', 'c3_gan_loop_kernel_stats.csv'),
     ('prof_r05/c3_iteration.csv', 'c3_gan_loop_iteration.csv'), ('prof_r05/c3_gaps.txt', 'c3_gan_loop_gaps.txt'),
-    ('prof_r05/c3paper_kernel_stats.csv', 'c3paper_kernel_stats.csv'), ('prof_r05/c5_kernel_stats.csv', 'c5_kernel_stats.csv'),
+    ('prof_r05/c3paper_kernel_stats.csv', 'c3paper_kernel_stats.csv'), ('prof_r05/c3paper_iteration.csv', 'c3paper_iteration.csv'),
+    ('prof_r05/c3paper_gaps.txt', 'c3paper_gaps.txt'), ('prof_r05/c5_kernel_stats.csv', 'c5_kernel_stats.csv'),
     ('prof_r05/c2nb8_kernel_stats.csv', 'c2nb8_kernel_stats.csv'), ('prof_r05/mt_kernel_stats.csv', 'mt19937_kernel_stats.csv'),
     ('prof_r05/mt_time.log', 'mt19937_draw_times.txt'),
     ('pmc_r05_mt/summary_pmc_summary.csv', 'mt19937_pmc_summary.csv'), ('pmc_r05_fwd/summary_pmc_summary.csv', 'duo_forward_pmc_summary.csv'),

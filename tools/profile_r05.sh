@@ -22,6 +22,8 @@ traces)
   for t in c2 c3 c3paper c5 c2nb8 mt; do python3 tools/summarize_profile.py $out/$t $out/$t; done
   # (iteration 2: the last of the first loop -- the reference-stream loop; the fp32 / one-launch-backward / Philox comparison loops follow)
   python3 tools/trace_gaps.py $out/c3/trace "gen_forward_duo_kernel<208, true" $out/c3_iteration.csv 2 > $out/c3_gaps.txt 2>&1
+  # (paper shape: an iteration of the first loop, the reference-stream one; the Philox comparison loop follows it)
+  python3 tools/trace_gaps.py $out/c3paper/trace "gen_forward_split_kernel<208, true" $out/c3paper_iteration.csv 15 > $out/c3paper_gaps.txt 2>&1
   ;;
 pmc1)
   bash tools/pmc_run.sh r05_mt tools/time_mt.py > $out/pmc_mt.log 2>&1 || exit 1
