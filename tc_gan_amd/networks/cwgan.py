@@ -390,7 +390,9 @@ class ConditionalBPTTWassersteinGAN(object):
         if 'V' in names:
             v = names.index('V')
             pd['V'] = st['flat'][offs[v]:offs[v + 1]]
-        return self._prepare_disc(params_dev=pd)
+        ctx = self._prepare_disc(params_dev=pd)
+        ctx.prequeued_time = self.gen_forward_watch.times.pop()       # (booked on the iteration that uses the step)
+        return ctx
 
     def _take_prequeued(self):
         """The critic step `_prequeue_next_disc` prepared, unless the generator's attributes were changed from outside since
@@ -403,6 +405,7 @@ class ConditionalBPTTWassersteinGAN(object):
             if cached is None or not np.array_equal(cached, np.asarray(getattr(self.gen, name))):
                 return None
         self._predrawn = self._rng_before_predraw = None
+        self.gen_forward_watch.times.append(ctx.prequeued_time)
         return ctx
 
     def _launch_disc(self, ctx):
