@@ -17,12 +17,16 @@
 //   mt_expand_kernel one workgroup per parent state: the 20608 words x[] its children's taps can reach, to memory.
 //   mt_jump_kernel   one workgroup per (state, quarter of the polynomial's tap range): its window of the parent's x[] in LDS,
 //                    twice (the second copy shifted by one word, so that every tap is ONE aligned 8-byte read per lane: words
-//                    tap + 2 t, tap + 2 t + 1 for lane t); taps arrive as LDS byte offsets by scalar loads, 16 per load, one group
-//                    ahead; XOR into two registers per lane.  Consumers XOR the four shares when they load the state.
+//                    tap + 2 t, tap + 2 t + 1 for lane t); taps arrive as LDS byte offsets, 128 per vector load a group ahead,
+//                    and reach the scalar side by v_readlane; XOR into two registers per lane.  Consumers XOR the four shares
+//                    when they load the state.
 //   mt_gen_kernel    one workgroup per segment: wave 0 regenerates block after block (104 words per pass, 52 lanes x 2 words:
-//                    a pass depends on no pass nearer than two back), waves 1-3 temper the block before, form randomkit's
+//                    a pass depends on no pass nearer than two back), the other waves temper the block before, form randomkit's
 //                    rk_double (a >> 5, b >> 6) -> double, round to fp32 where asked (round to nearest even = numpy's astype)
-//                    and store the [skip, skip + count) window only (the rows of one rank of a data-parallel job).
+//                    and store the [skip, skip + count) window only (the rows of one rank of a data-parallel job).  BUILDW
+//                    form: W = make_W_with_x of the number in the same pass (nine waves, six of them emitting); TAIL form: a
+//                    second window behind the doubles -- zs_in of the heterogeneous-input models, `choice(2, n) * 2 - 1` (one
+//                    32-bit output per element, its low bit) or `rand(n) * 2 - 1`.
 //   mt_solo_kernel   the state after the whole draw (every rank needs it, whatever rows it generates): ONE launch on a side
 //                    stream of the library's own, by the exact polynomial of the draw's length (kept per length); the host
 //                    waits for this launch only, never for the caller's stream.
@@ -551,9 +555,10 @@ static hipError_t exact_poly(DeviceTables* t, long nblocks, DeviceTables::Exact*
     DeviceTables::Exact x{};
     hipError_t e;
     if ((e = hipMalloc((void**)&x.codes, codes.size() * sizeof(uint16_t))) != hipSuccess) return e;
-    if ((e = hipMalloc((void**)&x.counts, sizeof counts)) != hipSuccess) return e;
-    if ((e = hipMemcpy(x.codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
-    if ((e = hipMemcpy(x.counts, counts, sizeof counts, hipMemcpyHostToDevice)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&x.counts, sizeof counts)) == hipSuccess
+        && (e = hipMemcpy(x.codes, codes.data(), codes.size() * sizeof(uint16_t), hipMemcpyHostToDevice)) == hipSuccess)
+        e = hipMemcpy(x.counts, counts, sizeof counts, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(x.codes); if (x.counts) (void)hipFree(x.counts); return e; }
     t->exact[nblocks] = x;
     *out = x;
     return hipSuccess;

@@ -15,7 +15,7 @@ import torch
 from .. import clib
 from ..clib import libssnode
 from ..critic import Updater
-from ..utils import Namespace, StopWatch
+from ..utils import Namespace, StopWatch, as_randomstate
 from .cwgan import _v_bounds, GradientAllReducer
 from .ssn import TuningCurveGenerator
 from .wgan import DEFAULT_PARAMS as _WGAN_DEFAULTS, grid_stimulator_inputs, probes_from_stim_space
@@ -65,7 +65,7 @@ class BPTTMomentMatcher(object):
         self.lam = lam
         self.moment_weights_regularization = moment_weights_regularization
         self.moment_weight_type = moment_weight_type
-        self.rng = np.random.RandomState(seed)
+        self.rng = as_randomstate(seed)          # (the reference's stream; device draws hand their state back lazily)
         self.bandwidths = bandwidths
         self.contrasts = contrasts
         self.reducer = GradientAllReducer()
