@@ -43,9 +43,21 @@
 namespace ssn {
 namespace mt {
 
+#ifndef SSN_MT_STRIDE0_LOG2
+#define SSN_MT_STRIDE0_LOG2 7
+#endif
+#ifndef SSN_MT_RADIX_LOG2
+#define SSN_MT_RADIX_LOG2 8
+#endif
+#ifndef SSN_MT_MAX_STEP
+#define SSN_MT_MAX_STEP 8
+#endif
+#ifndef SSN_MT_FRACTIONAL_ROUNDS
+#define SSN_MT_FRACTIONAL_ROUNDS 0
+#endif
 constexpr int kLevels = 3;                 // strides 128 * 256^l blocks
-constexpr int kStride0Log2 = 7;
-constexpr int kRadixLog2 = 8;              // 255 polynomials per level: up to 255 * 128 * step blocks (10 M doubles x step) in ONE round of jumps
+constexpr int kStride0Log2 = SSN_MT_STRIDE0_LOG2;
+constexpr int kRadixLog2 = SSN_MT_RADIX_LOG2;   // 255 polynomials per level: up to 255 * 128 * step blocks (10 M doubles x step) in ONE round of jumps
 constexpr int kDigits = (1 << kRadixLog2) - 1;
 constexpr int kSegLevel = 0;               // segments start at states of level 0: every `step`-th one, 128 * step blocks long
 constexpr int kSoloParts = 16;             // workgroups of the kernel that computes the state after the draw
@@ -633,10 +645,12 @@ static bool make_plan(int pos, unsigned long long total, unsigned long long skip
         // segment length 128 * step blocks, by a cost model of the two launches that matter (measured, MI355X): the jump runs 4
         // workgroups per state, 768 at a time, ~70 us a round; a segment's workgroup generates a block in ~0.5 us
         double best = 1e30;
-        for (int c = 1; c <= 8; c *= 2) {
+        for (int c = 1; c <= SSN_MT_MAX_STEP; c *= 2) {
             const long len = (long)c << kStride0Log2;
             const long nseg = (pl.b_hi - pl.b_lo + len) / len;
-            const double cost = 70.0 * (double)((4 * nseg + 767) / 768) + 0.5 * (double)len;
+            const double rounds = SSN_MT_FRACTIONAL_ROUNDS ? (4.0 * (double)nseg / 768.0 < 1.0 ? 1.0 : 4.0 * (double)nseg / 768.0)
+                                                           : (double)((4 * nseg + 767) / 768);
+            const double cost = 70.0 * rounds + 0.5 * (double)len;
             if (cost < best) { best = cost; pl.step = c; }
         }
         const long seg_blocks = (long)pl.step << kStride0Log2;
