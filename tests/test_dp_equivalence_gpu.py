@@ -27,9 +27,9 @@ def _config():
                   nonlinearity='rectify', precision='fp32'))
 
 
-def _train(n_gen_steps=2, z_device_seed=None):
+def _train(n_gen_steps=2, z_device_seed=None, **over):
     from tc_gan_amd.networks.cwgan import make_gan
-    gan, _ = make_gan(dict(_config(), z_device_seed=z_device_seed))
+    gan, _ = make_gan(dict(_config(), z_device_seed=z_device_seed, **over))
     data = np.random.RandomState(4).rand(9, 4 * 2 * 2 * 2) * 10
     gan.set_dataset(data)
     it = gan.learning()
@@ -121,6 +121,7 @@ def _worker(rank, world, port, out, what='gan'):
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     res = {'gan': _train, 'gan_devnoise': lambda: _train(z_device_seed=31), 'moments': _train_moments,
+           'gan_heteroin': lambda: _train(n_gen_steps=3, ssn_type='deg-heteroin', V=0.3),
            'find': _find_fixed_points, 'wgan': _train_unconditional,
            'wgan_fused': lambda: _train_unconditional(gen_kernel='duo-fused')}[what]()
     if what == 'gan':
@@ -185,6 +186,31 @@ def test_two_ranks_with_device_noise_follow_the_single_process_run():
         np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
         np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
     np.testing.assert_array_equal(res[0][2], res[1][2])
+
+
+def test_two_ranks_heterogeneous_input_on_the_reference_stream_follow_the_single_process_run():
+    """deg-heteroin on the default noise (the reference's RandomState continued on the device): each rank generates its rows
+    of zs AND its rows of zs_in behind it (two windows far apart in the stream: a launch each, `ssn_build_w_mt19937_tail_begin_f32`
+    / `ssn_mt19937_random_sample_tail_begin_f32`), the first critic forward of an iteration is queued behind the optimizer
+    launch with V read on the device -- and the job follows the single process."""
+    sys.path.insert(0, ROOT)
+    jds1, critic1, losses1, _ = _train(n_gen_steps=3, ssn_type='deg-heteroin', V=0.3)
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = 25700 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, 'gan_heteroin')) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        np.testing.assert_allclose(res[r][3], losses1, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(res[r][1], jds1, rtol=2e-4, atol=1e-6)
+        np.testing.assert_allclose(res[r][2], critic1, rtol=5e-3, atol=5e-5)
+    np.testing.assert_array_equal(res[0][2], res[1][2])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
 @pytest.mark.parametrize('what', ['wgan', 'wgan_fused'])
