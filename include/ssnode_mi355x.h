@@ -677,6 +677,9 @@ int ssn_build_w_mt19937_tail_begin_f32(const unsigned int *key, int pos, int B_t
  * segment, first and last segment this call generates, first and last block that holds a wanted word} for the given pos /
  * total / skip / count -- what the CPU tests check against numpy's own positions, rank by rank. */
 int ssn_mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long *out);
+/* ... of a draw with a tail (ssn_mt19937_random_sample_tail_begin_f32): the position and the blocks cover the tail's words too */
+int ssn_mt19937_plan_tail(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, int tail_kind,
+                          unsigned long long tail_total, unsigned long long tail_skip, unsigned long long tail_count, long *out);
 
 #ifdef __cplusplus
 }

@@ -350,7 +350,7 @@ DECLARED_SYMBOLS = (
     'ssn_mt19937_random_sample_f32', 'ssn_mt19937_random_sample_f64', 'ssn_mt19937_jump_poly',
     'ssn_mt19937_random_sample_begin_f32', 'ssn_mt19937_random_sample_begin_f64', 'ssn_mt19937_random_sample_finish',
     'ssn_mt19937_plan', 'ssn_build_w_mt19937_begin_f32', 'ssn_build_w_devparams_f32', 'ssn_mt19937_random_sample_tail_begin_f32',
-    'ssn_build_w_mt19937_tail_begin_f32',
+    'ssn_build_w_mt19937_tail_begin_f32', 'ssn_mt19937_plan_tail',
     'ssn_critic_num_params_act', 'ssn_critic_forward_act', 'ssn_critic_loss_grad_act', 'ssn_critic_input_grad_act',
     'ssn_critic_accuracy_act',
 )
@@ -391,6 +391,9 @@ libssnode.ssn_build_w_mt19937_tail_begin_f32.argtypes = [c_void_p, c_int, c_int,
 libssnode.ssn_build_w_mt19937_tail_begin_f32.restype = c_int
 libssnode.ssn_build_w_devparams_f32.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]
 libssnode.ssn_build_w_devparams_f32.restype = c_int
+libssnode.ssn_mt19937_plan_tail.argtypes = [c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, ctypes.c_ulonglong,
+                                            ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p]
+libssnode.ssn_mt19937_plan_tail.restype = c_int
 libssnode.ssn_mt19937_plan.argtypes = [c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p]
 libssnode.ssn_mt19937_plan.restype = c_int
 libssnode.ssn_mt19937_random_sample_finish.argtypes = [c_int, c_void_p, POINTER(c_int)]

@@ -1292,6 +1292,13 @@ int ssn_mt19937_plan(int pos, unsigned long long total, unsigned long long skip,
     if (!out || !ssn::mt19937_plan(pos, total, skip, count, out)) { g_last_error = "ssn_mt19937_plan: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     return 0;
 }
+int ssn_mt19937_plan_tail(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, int tail_kind,
+                          unsigned long long tail_total, unsigned long long tail_skip, unsigned long long tail_count, long* out) {
+    ssn::MtTail tail;
+    tail.kind = tail_kind; tail.total = tail_total; tail.skip = tail_skip; tail.count = tail_count;
+    if (!out || !ssn::mt19937_plan(pos, total, skip, count, out, &tail)) { g_last_error = "ssn_mt19937_plan_tail: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
+    return 0;
+}
 int ssn_mt19937_random_sample_finish(int ticket, unsigned int* key, int* pos) {
     if (!key || !pos) { g_last_error = "ssn_mt19937_random_sample_finish: null state"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     SSN_TRY(ssn::mt19937_finish(ticket, key, pos));

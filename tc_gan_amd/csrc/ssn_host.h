@@ -276,6 +276,7 @@ hipError_t mt19937_begin(const unsigned int* key, int pos, unsigned long long to
                          void* out, int elem, hipStream_t st, int* ticket, float* W = nullptr, const float* jds12 = nullptr, int N = 0,
                          const MtTail* tail = nullptr);
 hipError_t mt19937_finish(int ticket, unsigned int* key, int* pos);
-bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out);
+bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out, const MtTail* tail = nullptr);
+
 
 }  // namespace ssn

@@ -675,9 +675,9 @@ int mt19937_jump_poly(unsigned long long nblocks, unsigned long long* bits) {
 }
 
 // Where a draw lands in the block / segment grid (host arithmetic only: tests check it against numpy's positions)
-bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out) {
+bool mt19937_plan(int pos, unsigned long long total, unsigned long long skip, unsigned long long count, long* out, const MtTail* tail) {
     mt::Plan pl;
-    if (!mt::make_plan(pos, total, skip, count, pl)) return false;
+    if (!mt::make_plan(pos, total, skip, count, pl, tail)) return false;
     out[0] = pl.p_end - pl.b_f * mt::kN;   // pos after the draw
     out[1] = pl.b_f;                       // regenerations between the caller's key and the key after the draw
     out[2] = (long)pl.step << mt::kStride0Log2;    // blocks per segment

@@ -137,3 +137,40 @@ def test_draw_plan_positions_and_rank_segments(world, pos):
         first = 0 if s_lo == 0 else s_lo * seg_blocks + 1
         assert first <= b_lo and b_hi <= (s_hi + 1) * seg_blocks and (s_lo == 0 or b_lo > (s_lo - 1) * seg_blocks + seg_blocks)
     assert len(ends) == 1                                  # every rank hands back the same generator state
+
+
+@pytest.mark.parametrize('kind', [1, 2])
+@pytest.mark.parametrize('world', [1, 2, 8])
+@pytest.mark.parametrize('pos', [0, 311, 624])
+def test_draw_plan_with_the_input_noise_behind_zs(kind, world, pos):
+    """`ssn_mt19937_plan_tail`: zs and, behind it, zs_in of the heterogeneous-input models (kind 1: `choice(2, (B, M))`, one word
+    per element; kind 2: `rand(B, M)`, two) -- the position and the regenerations after BOTH draws equal numpy's; a rank whose
+    rows of the two draws lie in one stretch of the stream plans one launch that covers both, every rank the same end state."""
+    from tc_gan_amd import clib
+    B, M = 64, 101
+    total = B * M * M
+    rs = np.random.RandomState(9)
+    rs.randint(0, 2 ** 31, size=700)
+    st = rs.get_state()
+    rs.set_state((st[0], st[1], pos, st[3], st[4]))
+    rs.random_sample(total)
+    if kind == 1:
+        rs.choice(2, (B, M))
+    else:
+        rs.rand(B, M)
+    want_pos = rs.get_state()[2]
+    words = 2 * total + (1 if kind == 1 else 2) * B * M
+    ends = set()
+    for rank in range(world):
+        per = B // world
+        out = np.zeros(7, dtype=np.int64)
+        assert clib.libssnode.ssn_mt19937_plan_tail(pos, total, rank * per * M * M, per * M * M, kind, B * M, rank * per * M, per * M,
+                                                    out.ctypes.data) == 0
+        new_pos, b_f, seg_blocks, s_lo, s_hi, b_lo, b_hi = (int(v) for v in out)
+        ends.add((new_pos, b_f))
+        assert new_pos == want_pos and b_f == (0 if pos + words <= 624 else (pos + words - 1) // 624)
+        last = 2 * total + (1 if kind == 1 else 2) * (rank + 1) * per * M - 1       # last word of the rank's rows of the tail
+        assert b_lo == (pos + 2 * rank * per * M * M) // 624 and b_hi == (pos + last) // 624
+        first = 0 if s_lo == 0 else s_lo * seg_blocks + 1
+        assert first <= b_lo and b_hi <= (s_hi + 1) * seg_blocks
+    assert len(ends) == 1
