@@ -38,6 +38,8 @@ from ._common import DEFAULT_PARAMS as _WGAN_DEFAULTS
 
 # (A/B switch: TCGAN_PREQUEUE=0 queues the first critic forward of an iteration only after the generator step's record was read)
 _PREQUEUE = os.environ.get('TCGAN_PREQUEUE', '1') != '0'
+# (TCGAN_SUBSET_RETRY=0: a refused generator step is recomputed on the fp32 kernels for ALL draws, not only the refused ones)
+_SUBSET_RETRY = os.environ.get('TCGAN_SUBSET_RETRY', '1') != '0'
 
 logger = getLogger(__name__)
 
@@ -697,13 +699,29 @@ class ConditionalBPTTWassersteinGAN(object):
             # The update was withheld: the summed gradient is not finite.  With the fp16-split adjoint that is what a draw whose
             # adjoint grows by more than 2^8 within one Euler step gives (unstable dynamics: NaN by construction, never a
             # clamped value); the reference's fp32 arithmetic carries such a draw's large finite gradient.  So does the fp32
-            # sweep: the step is made again on it -- forward, adjoint, dL/dW -- and THAT gradient is applied, whatever it is.
+            # sweep: the refused draws are made again on it -- forward, adjoint, dL/dW; all draws when more than half were
+            # refused -- and THAT gradient is applied, whatever it is.
             bad = self.gen.poisoned_draws()
             logger.warning('generator step %s: %d draws have an adjoint that grew by more than 2^8 within one Euler step, beyond '
-                           'the lagged scale of the fp16-split sweep; the step is recomputed on the fp32 kernels (gen_kernel '
+                           'the lagged scale of the fp16-split sweep; they are recomputed on the fp32 kernels (gen_kernel '
                            'mfma-fp32 runs every step there)', getattr(self, '_gen_step_now', '?'), bad)
             self._next_ctx = None          # (prepared with the parameters the withheld update left: prepared again later)
-            pieces = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, raw=True, exact=True)
+            idx = self.gen.poisoned_draw_indices()
+            nb = int(pieces['parts'].shape[0])
+            if _SUBSET_RETRY and (0 < idx.numel() <= nb // 2 or (self.reducer.on and idx.numel() == 0)):
+                # only the refused draws go through the fp32 kernels (a job-wide NaN may come from another rank's draws: then
+                # this rank has nothing to redo); every other draw keeps the gradient pieces it has
+                parts, g_ext = pieces['parts'], pieces.get('g_ext')
+                if idx.numel():
+                    sub = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, raw=True, exact=True, subset=idx)
+                    parts = parts.clone()
+                    parts[idx] = sub['parts']
+                    if g_ext is not None:
+                        g_ext = g_ext.clone()
+                        g_ext[idx] = sub['g_ext']
+                pieces = dict(pieces, parts=parts, g_ext=g_ext)
+            else:
+                pieces = self.gen.backward(gx, self.dynamics_cost, self.rate_cost, raw=True, exact=True)
             gl = genops.gen_grads(pieces['parts'], dmean, pens, self.dynamics_cost, self.rate_cost,
                                   nv=pieces['nv'], g_ext=pieces.get('g_ext'), ext_base=pieces.get('ext_base'), zin=pieces.get('zin'))
             self.reducer.mean_(gl)

@@ -602,41 +602,53 @@ class TuningCurveGenerator(object):
                                theta=theta)
         return out
 
-    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False, raw=False, exact=False):
+    def backward(self, g_tuning_curve, dynamics_cost, rate_cost, as_tensor=False, raw=False, exact=False, subset=None):
         """BPTT: gradient of  sum(g_tuning_curve * tuning_curve) + dynamics_cost * dynamics_penalty
         + rate_cost * rate_penalty  w.r.t. the generator parameters (dict: J, D, S[, V]), for the last
         ``forward(save=True)`` call.  float64 numpy arrays by default; with ``as_tensor=True`` float64 CUDA tensors
         and no host synchronisation anywhere in the call (the GAN loop keeps queuing work behind it).
         ``raw=True``: the pieces `genops.gen_grads` turns into the flat gradient vector in one launch -- dict(parts (B, 4, 3)
-        float64, nv[, g_ext, ext_base, zin]) -- instead of the sums."""
+        float64, nv[, g_ext, ext_base, zin]) -- instead of the sums.
+        ``exact=True`` (after a ``raw=True`` call): the step again on the fp32 kernels, forward included; with ``subset`` (int64
+        CUDA indices of draws) only for those draws -- the pieces come back with len(subset) rows, for the caller to put in
+        place of the rows it could not use."""
         sv = self._saved
+        full = None
         if exact:
             # the step again on the fp32 kernels, forward included (the split sweep has overwritten f' with its deltas): the
             # gradient the reference's fp32 arithmetic gives where the fp16-split adjoint refuses (a draw whose adjoint grows
             # by more than 2^8 within one step -- unstable dynamics -- is NaN there by construction)
             sv = self._retry
+            full = (sv['shape'], sv['n_dyn'], sv['n_rate'])
+            if subset is not None:
+                sv = dict(sv, **{k: sv[k][subset].contiguous() for k in ('W', 'z', 'zin', 'ext_base', 'ext') if sv[k] is not None})
             gp = genops.make_gen_params(io_type=self.io_type, k=self.k, n=self.n, tau_E=self.tau_E, tau_I=self.tau_I, dt=self.dt,
                                         seqlen=self.seqlen, skip_steps=self.skip_steps, rate_penalty_threshold=sv['theta'],
                                         kernel=clib.GEN_KERNELS['mfma-fp32'])
-            probe = (sv['ids'], sv['probes']) if self.conditional else None
-            sv = dict(sv, gp=gp, fwd=genops.gen_forward(sv['W'], sv['ext'], gp, save=True, **({'probe': probe} if probe else {})))
+            # (trajectory and f' are all the sweep needs of it: no probe gather)
+            sv = dict(sv, gp=gp, fwd=genops.gen_forward(sv['W'], sv['ext'], gp, save=True))
         fwd = sv['fwd']
         g = g_tuning_curve.to(fwd['time_avg'].dtype)
+        shape_full = full[0] if full is not None else tuple(fwd['time_avg'].shape)
         if self.conditional:
             # scatter-add of the probe gather (several samples may probe the same model/neuron):
             # tuning_curve[n, :] = time_avg[ids[n], :, probes[n]]; one launch, samples added in order, no host wait
             # (torch.index_add_ spends a millisecond on the host per call, index_put_(accumulate=True) synchronises)
-            B, NB, M = fwd['time_avg'].shape
+            B, NB, M = shape_full
             g = g.contiguous()
-            g_ta = torch.empty_like(fwd['time_avg'])
+            g_ta = torch.empty(shape_full, device=g.device, dtype=g.dtype)
             fn = clib.libssnode.ssn_probe_scatter_f32 if g.dtype == torch.float32 else clib.libssnode.ssn_probe_scatter_f64
             clib.check(fn(g.data_ptr(), sv['ids'].data_ptr(), sv['probes'].data_ptr(), g_ta.data_ptr(), int(g.shape[0]),
                           int(B), int(NB), int(M), clib.stream_ptr()),
                        'ssn_probe_scatter')
         else:
-            g_ta = torch.zeros_like(fwd['time_avg'])
+            g_ta = torch.zeros(shape_full, device=g.device, dtype=g.dtype)
             g_ta[:, :, sv['probes']] = g.reshape(g_ta.shape[0], g_ta.shape[1], -1)
-        c_dyn, c_rate = dynamics_cost / max(fwd['n_dyn'], 1), rate_cost / fwd['n_rate']
+        if subset is not None:
+            g_ta = g_ta[subset].contiguous()
+        # (the means of the loss run over the WHOLE batch, whatever part of it this call sweeps)
+        n_dyn, n_rate = (full[1], full[2]) if full is not None else (fwd['n_dyn'], fwd['n_rate'])
+        c_dyn, c_rate = dynamics_cost / max(n_dyn, 1), rate_cost / n_rate
         if self.fused_backward and not exact:
             B, NB, _, M = fwd['traj'].shape
             xmax = genops.rate_bound(sv['gp'])
@@ -660,7 +672,8 @@ class TuningCurveGenerator(object):
             if self.heteroin:
                 pieces.update(nv=2 if self.ssn_type == 'heteroin' else 1, g_ext=g_ext, ext_base=sv['ext_base'], zin=sv['zin'])
             # (what a second pass on the fp32 kernels needs, should this one turn out poisoned: references, no copies)
-            self._retry = None if exact else {k: sv[k] for k in ('W', 'z', 'ids', 'probes', 'zin', 'ext_base', 'ext', 'theta')}
+            self._retry = None if exact else dict({k: sv[k] for k in ('W', 'z', 'ids', 'probes', 'zin', 'ext_base', 'ext', 'theta')},
+                                                   shape=tuple(fwd['time_avg'].shape), n_dyn=fwd['n_dyn'], n_rate=fwd['n_rate'])
             self._saved = None
             return pieces
         gJ, gD, gS = genops.jds_grad(gW, sv['z'], self.J, self.D, self.S, as_tensor=as_tensor)
@@ -677,6 +690,13 @@ class TuningCurveGenerator(object):
                 grads['V'] = gv if self.ssn_type == 'heteroin' else np.asarray(gv.sum())
         self._saved = None
         return grads
+
+    def poisoned_draw_indices(self):
+        """int64 CUDA indices of the draws `poisoned_draws` counts (empty when the sweep tracks no max |delta|)."""
+        dmax = getattr(self, 'last_dmax', None)
+        if dmax is None:
+            return torch.empty(0, device='cuda', dtype=torch.int64)
+        return torch.isnan(dmax).nonzero().reshape(-1)
 
     def poisoned_draws(self):
         """Number of draws of the last `backward` whose adjoint outgrew the lagged power-of-two scale of the fp16-split

@@ -338,23 +338,28 @@ def test_conditional_tuning_curves_vs_fixed_point_dataset(truth_size, probes_per
         np.testing.assert_allclose(ta[m], fp[padded[m], ci], rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize('tail', ['fused', 'per-parameter'])
-def test_poisoned_generator_gradient_is_not_hidden_by_the_parameter_bounds(tail, caplog):
+@pytest.mark.parametrize('tail,retry,ssn_type', [('fused', 'subset', 'default'), ('fused', 'all', 'default'),
+                                                 ('fused', 'subset', 'heteroin'), ('per-parameter', 'subset', 'default')])
+def test_poisoned_generator_gradient_is_not_hidden_by_the_parameter_bounds(tail, retry, ssn_type, caplog, monkeypatch):
     """a draw whose fp16 adjoint outgrows its scale makes the summed gradient NaN; the optimizer's clip used to turn
     the NaN update into the lower bound (fmaxf(NaN, lo) = lo), so the parameters stayed finite, the loss stayed finite and
     nothing reported.  Now: the clip keeps NaN as Theano's does (wgan.py:244-251: a switch on comparisons) -- the
     parameter-by-parameter tail returns non-finite parameters, the drivers' NaN guards see them, the loop says how many draws
     were poisoned -- and the default tail withholds the update (device-side gate: parameters and Adam state untouched), makes
     the step again on the fp32 kernels (forward, adjoint, dL/dW: what `gen_kernel mfma-fp32` runs every step, and what the
-    reference's fp32 arithmetic does with such a draw) and applies THAT gradient."""
+    reference's fp32 arithmetic does with such a draw) and applies THAT gradient -- for the refused draws only ('subset': the
+    other draws keep the gradient pieces they have) or for all of them (TCGAN_SUBSET_RETRY=0, or more than half refused)."""
     import logging
+    from tc_gan_amd.networks import cwgan
+    monkeypatch.setattr(cwgan, '_SUBSET_RETRY', retry == 'subset')
     from argparse import Namespace
     from tc_gan_amd.networks.cwgan import make_gan
     from tc_gan_amd.utils import StopWatch
 
     def step(kernel, poison):
         cfg = dict(TEST_PARAMS, num_sites=60, num_models=4, probes_per_model=1, seqlen=60, skip_steps=40,
-                   bandwidths=[0.0625, 0.125, 0.25, 0.5, 0.75, 1.0, 0.3, 0.4], contrasts=[20.], gen_kernel=kernel, critic_iters=0)
+                   bandwidths=[0.0625, 0.125, 0.25, 0.5, 0.75, 1.0, 0.3, 0.4], contrasts=[20.], gen_kernel=kernel, critic_iters=0,
+                   ssn_type=ssn_type, **(dict(V=[0.3, 0.1]) if ssn_type != 'default' else {}))
         cfg['gen'] = dict(cfg['gen'], update_name='adam-wgan')
         gan, _ = make_gan(cfg)
         if tail == 'per-parameter':
@@ -367,7 +372,7 @@ def test_poisoned_generator_gradient_is_not_hidden_by_the_parameter_bounds(tail,
         if poison:
             gan.gen._saved['fwd']['df'][1, :, 50, :] *= 1e5        # one draw's f' at one step: its adjoint grows by 1e5 within a step
         info = gan.train_generator(Namespace(gen_step=0), batch, prepared)
-        return gan, info, np.concatenate([np.ravel(getattr(gan.gen, name)) for name in 'JDS'])
+        return gan, info, np.concatenate([np.ravel(getattr(gan.gen, name)) for name in gan._pnames])
 
     with caplog.at_level(logging.WARNING):
         gan, info, values = step('duo', poison=True)
