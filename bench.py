@@ -161,7 +161,7 @@ def _traffic(key):
 
 
 def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iters_init=5, critic_iters=5, models=None,
-                gen_kernel='auto', z_mode='philox'):
+                gen_kernel='auto', z_mode='philox', gen_learning_rate=None):
     """The GAN of BASELINE config 3/4 (or, `paper=True`, of scripts/fig4/gan/run.json) with its truth data set:
     returns (gan, (N, models_per_rank, NB, T, skip), bandwidths).  Shared by the bench and by the full-size parity test."""
     from tc_gan_amd.networks.cwgan import make_gan
@@ -173,7 +173,13 @@ def make_c3_gan(world=1, rank=0, paper=False, disc_precision='bf16', critic_iter
                include_inhibitory_neurons=False, bandwidths=bandwidths, contrasts=[20.0],
                seqlen=T, skip_steps=skip, J0=J, D0=D, S0=S, critic_iters_init=critic_iters_init, critic_iters=critic_iters,
                lipschitz_cost=10.0, gen_kernel=gen_kernel,
-               gen=dict(learning_rate=0.01, update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
+               # generator step size: the reference's default (networks/wgan.py:119).  Rounds 1-4 timed this loop at 0.01: with
+               # S0 = 0.025 .. 0.17 three Adam steps of +-0.01 take S_EI / S_II to the lower bound, and at 2048 models and more
+               # (the data-parallel sizes) this seed's dynamics explode at the second generator step -- rate penalty 700,
+               # every draw refused by the fp16-split adjoint and redone in fp32.  Same kernels, same shapes,
+               # same time per iteration at 1024 models; a run that trains instead of one that has diverged.
+               gen=dict(learning_rate=float(os.environ.get('BENCH_GEN_LR', '0.001')) if gen_learning_rate is None else gen_learning_rate,
+                        update_name='adam-wgan', dynamics_cost=1.0, rate_cost=0.01,
                         rate_penalty_threshold=200.0, J_min=1e-3, J_max=10, D_min=1e-3, D_max=10, S_min=1e-3, S_max=10),
                disc=dict(learning_rate=0.01, update_name='adam-wgan', layers=[512, 512, 512], normalization='none',
                          nonlinearity='rectify', precision=disc_precision))
@@ -358,7 +364,8 @@ def run_c3(args, rank, world, local_rank, paper=False, z_mode='refstream', compa
                                 'seqlen 240 / skip 200, tau_E=2, deg-heteroin, 4x128 critic with LayerNorm on layers 2-4, '
                                 'rmsprop, ' + Z_MODES[z_mode]) if paper else
                                'C3: bptt_cwgan loop, 2N=200, 1024 models x 8 bandwidths per GPU, seqlen 1200 / skip 1000, '
-                               '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan, '
+                               '5 critic updates + 1 generator BPTT update per iteration, 3x512 critic, adam-wgan '
+                               '(generator step size %g, critic 0.01), ' % gan.gen_updaters[gan._pnames[0]].learning_rate
                                + Z_MODES[z_mode], 'parallelism': 'models sharded over %d GPU(s), one all-reduce per update' % world},
         'roofline': _forward_roofline(variant, achieved, traffic, kernel_ms, M, 7 * units * iters_per_s * world),
         'last_gen_loss': info.gen_loss, 'gen_kernel': out_extra_kernel, 'forward_variant': variant,

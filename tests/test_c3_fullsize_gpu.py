@@ -67,5 +67,5 @@ def test_bf16_critic_tracks_fp32_critic_for_one_update_at_full_size():
     j32 = np.concatenate([np.ravel(p) for p in g32.get_gen_param()])
     j16 = np.concatenate([np.ravel(p) for p in g16.get_gen_param()])
     assert np.all(np.isfinite(j16))
-    # 12 parameters, each moved by +-0.01 (first adam-wgan step): allow one sign disagreement
+    # 12 parameters, each moved by +-lr = +-0.001 (first adam-wgan step; a sign disagreement shows as 0.002): allow one
     assert (np.abs(j32 - j16) > 1e-3).sum() <= 1, (j32, j16)
