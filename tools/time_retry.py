@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-iteration wall time of the C3 loop at 2048 models in one process (the size at which this seed's dynamics explode at the
-third generator step): what a refused step costs.  usage: tools/time_retry.py [iterations]   (TCGAN_SUBSET_RETRY=0/1)"""
+third generator step): what a refused step costs.  usage: tools/time_retry.py [iterations] [models]   (TCGAN_SUBSET_RETRY=0/1, BENCH_GEN_LR=0.01 for the step size of rounds 1-4)"""
 import os
 import sys
 import time
@@ -13,7 +13,8 @@ import bench  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    gan, _, _ = bench.make_c3_gan(models=2048, z_mode='refstream')
+    models = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+    gan, _, _ = bench.make_c3_gan(models=models, z_mode='refstream')
     it = gan.learning()
     for k in range(n):
         torch.cuda.synchronize()
