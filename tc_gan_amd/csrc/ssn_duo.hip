@@ -57,12 +57,21 @@ __device__ __forceinline__ void duo_forward_wave(const GenFwdArgs<float>& a, int
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
     // ---- W: pass 1 = max |W| of the draw, pass 2 = the two fp16 parts of W 2^a
     using Ops = DuoOperands<MK, WV, S::nl(SAVE)>;
+#if SSN_DUO_ONEPASS
+    typename Ops::Raw raw;
+    atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::fetch(rsrc, M, li, lg, raw)));
+#else
     atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)));
+#endif
     __syncthreads();                                                          // (A)
     const int wexp = duo_w_exp(*wmax);
     const float sa = duo_pow2(wexp), usc = duo_pow2(-wexp - rshift), rs = duo_pow2(rshift);
     Ops ops;
+#if SSN_DUO_ONEPASS
+    ops.split(raw, sa, wlds, lane);
+#else
     ops.load(rsrc, M, li, lg, sa, wlds, lane);
+#endif
     // ---- the values this lane finishes: row tile RT0 + tf, rows 4 lg + 2 hi + e, stimulus s0 + st
     const IoSelect io(a.io);
     const int s = s0 + st;
@@ -394,32 +403,47 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
     using Ops = DuoOperands<MK, WV, S::nl_solve()>;
+#if SSN_DUO_ONEPASS_SOLVE
+    typename Ops::Raw raw;
+    __hip_atomic_fetch_max(wmax, __builtin_bit_cast(unsigned, Ops::fetch(rsrc, M, li, lg, raw)), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     __hip_atomic_fetch_max(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     // ---- the values this lane finishes
     const IoSelect io(a.io);
     const int s = s0 + st;
     const bool live = valid && s < a.NB;
+    // (One-pass prologue: the W units are 176-184 live registers across barrier (A), so the lane's state, input and
+    // constants are read BEHIND the split -- alive across it they were spilled and reloaded from scratch in every step;
+    // max |r0| comes from a first read of the same 6-8 values.)
     float rc[NE], ex[NE], eps[NE];
     float r0max = 0.f;
-    {
+    auto read_values = [&](bool keep) {
         const size_t vec = ((size_t)b * a.NB + (s < a.NB ? s : 0)) * M;
 #pragma unroll
         for (int i = 0; i < NE; ++i) {
             const int row = 16 * (RT0 + i / 2) + 4 * lg + 2 * hi + (i & 1);
             const bool ok = s < a.NB && row < M;
-            rc[i] = ok ? a.r[vec + row] : 0.f;
-            ex[i] = ok ? a.ext[(a.ext_per_draw ? vec : (size_t)s * M) + row] : 0.f;
-            eps[i] = row < N ? a.st.eps_E : a.st.eps_I;
-            r0max = fmaxf(r0max, __builtin_fabsf(rc[i]));
+            const float r0 = ok ? a.r[vec + row] : 0.f;
+            if (keep) {
+                rc[i] = r0;
+                ex[i] = ok ? a.ext[(a.ext_per_draw ? vec : (size_t)s * M) + row] : 0.f;
+                eps[i] = row < N ? a.st.eps_E : a.st.eps_I;
+            } else {
+                r0max = fmaxf(r0max, __builtin_fabsf(r0));
+            }
         }
-    }
+    };
+    read_values(false);
+    if (!SSN_DUO_ONEPASS_SOLVE) read_values(true);
     __hip_atomic_fetch_max(wmax + 1, __builtin_bit_cast(unsigned, r0max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     auto store_prev = [&]() {
         rp_slot[0] = (mf4){rc[0], rc[1], NE > 2 ? rc[2 % NE] : 0.f, NE > 2 ? rc[3 % NE] : 0.f};
         if constexpr (NE > 4) rp_slot[64] = (mf4){rc[4 % NE], rc[5 % NE], NE > 6 ? rc[6 % NE] : 0.f, NE > 6 ? rc[7 % NE] : 0.f};
     };
-    store_prev();                                        // (zero steps: previous = initial state)
+    if (!SSN_DUO_ONEPASS_SOLVE) store_prev();                  // (zero steps: previous = initial state; a slot only its own lane reads)
     __syncthreads();                                                          // (A) max |W|, max |r0| of both draws
     // state scale: bound 2^rshift < 2^14 for bound = max(rate_hard_bound, max |r0|): every later state is a convex
     // combination of values inside that bound
@@ -429,7 +453,13 @@ __device__ __forceinline__ void duo_solve_wave(const SolveArgs<float>& a, int d,
     const int wexp = duo_w_exp(wmax[0]);
     const float sa = duo_pow2(wexp), usc = duo_pow2(-wexp - rshift), rs = duo_pow2(rshift);
     Ops ops;
+#if SSN_DUO_ONEPASS_SOLVE
+    ops.split(raw, sa, wwlds, lane);
+    read_values(true);
+    store_prev();
+#else
     ops.load(rsrc, M, li, lg, sa, wwlds, lane);
+#endif
     using LdsH8 = const __attribute__((address_space(3))) hv8*;
     using LdsF4 = __attribute__((address_space(3))) mf4*;
     using LdsU = __attribute__((address_space(3))) unsigned*;
@@ -699,7 +729,12 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.W + (size_t)b * M * M), 0, M * M * 4, 0x00020000);
     using Ops = DuoOperands<MK, WV, S::nl_bwd_win(WV, WS::NTF), true>;             // window steps
     using OpsN = DuoOperands<MK, WV, S::nl_bwd(WS::NTF, GEXT), true>;            // the steps after the window
+#if SSN_DUO_ONEPASS
+    typename Ops::Raw raw;
+    atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::fetch(rsrc, M, li, lg, raw)));
+#else
     atomicMax(wmax, __builtin_bit_cast(unsigned, Ops::max_abs(rsrc, M, li, lg)));
+#endif
     using LdsH8 = const __attribute__((address_space(3))) hv8*;
     using LdsF4 = __attribute__((address_space(3))) mf4*;
     using LdsU = __attribute__((address_space(3))) unsigned*;
@@ -756,7 +791,11 @@ __device__ __forceinline__ void duo_backward_wave(const GenBwdArgs<float>& a, in
     __syncthreads();                                                          // (A) max |W|
     const int wexp = duo_w_exp(*wmax);
     Ops ops;
+#if SSN_DUO_ONEPASS
+    ops.split(raw, duo_pow2(wexp), wwlds, lane);
+#else
     ops.load(rsrc, M, li, lg, duo_pow2(wexp), wwlds, lane);
+#endif
     // (the per-value state is set up AFTER the W prologue, the one place where every register is taken: set up before it,
     // two of the window's constants were spilled there and reloaded from scratch -- with s_waitcnt vmcnt(0) -- in every step)
     float m0 = 0.f;

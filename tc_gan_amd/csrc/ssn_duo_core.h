@@ -62,6 +62,14 @@
 #ifndef SSN_DUO_STORE_LAYOUT
 #define SSN_DUO_STORE_LAYOUT 0    // 1: timing experiment, WRONG results -- every wave store 512 contiguous bytes
 #endif
+#ifndef SSN_DUO_ONEPASS
+#define SSN_DUO_ONEPASS 1         // W prologue: 1 = the units fetched for max |W| stay in registers and are split from there (W read once);
+                                  // 0 = round 4's two passes (max |W|, barrier, fetch again and split)
+#endif
+#ifndef SSN_DUO_ONEPASS_SOLVE
+#define SSN_DUO_ONEPASS_SOLVE 0   // ... in solve_duo_kernel (2N > 152: the one kernel whose time loop has no register to spare -- with the
+                                  // fp32 units alive across barrier (A) the allocator reloads 11 values from scratch in every step)
+#endif
 #ifndef SSN_DUO_STORE_AUX
 #define SSN_DUO_STORE_AUX 0       // cache policy of the trajectory / f' / delta stores (raw buffer store aux: 1 sc0, 2 nt, 16 sc1)
 #endif
@@ -226,6 +234,39 @@ struct DuoOperands {
             for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(w[e]));
         }
         return mx;
+    }
+    // ONE pass over W (SSN_DUO_ONEPASS, default): the wave's units stay in registers as fp32 from the fetch that finds max |W|
+    // (NU x 8 = 176-184 registers, the size of the two fp16 parts they become: each unit's 8 registers turn into its
+    // 4 + 4), so the draw's W crosses HBM once per launch instead of twice.  Same loads, same arithmetic, same bits.
+    struct Raw { float w[NU][8]; };
+    static __device__ __forceinline__ float fetch(const __amdgpu_buffer_rsrc_t& rsrc, int M, int li, int lg, Raw& raw) {
+        float mx = 0.f;
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui) {
+            if (TR) duo_fetch_t(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, raw.w[ui]);
+            else duo_fetch(rsrc, M, 16 * ((U0 + ui) / S::NKT) + li, 32 * ((U0 + ui) % S::NKT) + 8 * lg, raw.w[ui]);
+        }
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx = fmaxf(mx, __builtin_fabsf(raw.w[ui][e]));
+        return mx;
+    }
+    __device__ __forceinline__ void split(const Raw& raw, float sa, char* wlds, int lane) {
+        wl = (unsigned)(size_t)(LdsH8)wlds + (unsigned)(lane * 16);
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui) {
+            hv8 m;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float sc = raw.w[ui][e] * sa;
+                const _Float16 h = (_Float16)sc;
+                Ah[ui][e] = h;
+                m[e] = (_Float16)(sc - (float)h);
+            }
+            if (ui < NR) Am[ui < NR ? ui : 0] = m;
+            else *(LdsH8)(size_t)(wl + (unsigned)((ui - NR) * 1024)) = m;
+        }
     }
     // pass 2: W 2^a = W_h + W_m by round to nearest
     __device__ __forceinline__ void load(const __amdgpu_buffer_rsrc_t& rsrc, int M, int li, int lg, float sa, char* wlds, int lane) {
