@@ -27,6 +27,7 @@
 #include <type_traits>
 #include <cstdlib>
 #include "ssn_host.h"
+#include "ssn_critic_dev.h"
 
 namespace ssn {
 
@@ -56,7 +57,7 @@ struct GemmArgs {
 };
 
 // ---- epilogue of one 32 x 32 wave tile: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -----------
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc, int mw, int nw, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc, int mw, int nw, int lane, int bz, int nz) {
     const int n = nw + (lane & 31);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& a
             float* c = g.C + m * g.ldc + n;
             if (g.epilogue == EPI_BIAS_RELU) { v += g.bias[n]; v = v > 0.f ? v : g.leak * v; }
             else if (g.epilogue == EPI_MASK) { v = (g.mask[m * g.ldm + n] > 0.f) ? v : g.leak * v; }
-            else if (gridDim.z > 1) { g.partial[((long)blockIdx.z * g.M + m) * g.N + n] = v; continue; }   // split-K partial
+            else if (g.partial) { g.partial[((long)bz * g.M + m) * g.N + n] = v; continue; }   // slab of K slice bz
             else { v = g.alpha * v + (g.beta != 0.f ? g.beta * (*c) : 0.f); }
             *c = v;
         }
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane);
+    gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane, blockIdx.z, gridDim.z);
 }
 
 // ---- deterministic split-K ---------------------------------------------------------------------------------------
@@ -169,13 +170,34 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(SplitKReduceArgs a) 
     const int grp = blockIdx.y, len = a.group_len[grp];
     const long mn = a.e[a.group_of[grp][0]].mn;
     float* C = a.e[a.group_of[grp][0]].C;
+    // (four elements per thread where the tensor allows it: 16-byte reads of the slabs; the arithmetic per element is the same)
+    bool vec = (mn & 3) == 0 && (reinterpret_cast<size_t>(C) & 15) == 0;
+    for (int k = 0; k < len; ++k) vec = vec && (reinterpret_cast<size_t>(a.e[a.group_of[grp][k]].partial) & 15) == 0;
+    if (vec) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (long i = 4 * (blockIdx.x * 256L + threadIdx.x); i < mn; i += 4 * gridDim.x * 256L) {
+            f4 c = *reinterpret_cast<const f4*>(C + i);
+            for (int k = 0; k < len; ++k) {
+                const SplitKEntry& en = a.e[a.group_of[grp][k]];
+                f4 s = *reinterpret_cast<const f4*>(en.partial + i);
+                for (int z = 1; z < en.splits; ++z) {
+                    const f4 t = *reinterpret_cast<const f4*>(en.partial + z * mn + i);
+                    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+                }
+                c.x = __builtin_fmaf(en.alpha, s.x, c.x); c.y = __builtin_fmaf(en.alpha, s.y, c.y);
+                c.z = __builtin_fmaf(en.alpha, s.z, c.z); c.w = __builtin_fmaf(en.alpha, s.w, c.w);
+            }
+            *reinterpret_cast<f4*>(C + i) = c;
+        }
+        return;
+    }
     for (long i = blockIdx.x * 256L + threadIdx.x; i < mn; i += gridDim.x * 256L) {
         float c = C[i];
         for (int k = 0; k < len; ++k) {
             const SplitKEntry& en = a.e[a.group_of[grp][k]];
             float s = en.partial[i];
             for (int z = 1; z < en.splits; ++z) s += en.partial[z * mn + i];
-            c += en.alpha * s;
+            c = __builtin_fmaf(en.alpha, s, c);
         }
         C[i] = c;
     }
@@ -195,18 +217,18 @@ typedef float gf4 __attribute__((ext_vector_type(4)));
 #endif
 // operand modes: 0 = k contiguous (16-byte vectors along k), 1 = m / n contiguous (vectors along m / n), 2 = any strides
 // (scalar loads, k fastest: the 11-wide input side of the first layer, whose extents are not multiples of four)
+constexpr int GP_BM = 64, GP_BN = 64, GP_BK = 64, GP_LDK = GP_BK + 8;
+// one 64 x 64 tile: workgroup (bx, by) of a gx x gy grid, K slice bz of nz
 template <int AMODE, int BMODE>
-__global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
-    constexpr int BM = 64, BN = 64, BK = 64, LDK = BK + 8, NST = 3;
-    __shared__ __align__(16) unsigned short As[2][BM][LDK];
-    __shared__ __align__(16) unsigned short Bs[2][BN][LDK];
+__device__ __forceinline__ void gemm_pipe_tile(const GemmArgs& g, int bx, int by, int bz, int gx, int gy, int nz,
+                                               unsigned short (&As)[2][GP_BM][GP_LDK], unsigned short (&Bs)[2][GP_BN][GP_LDK]) {
+    constexpr int BM = GP_BM, BN = GP_BN, BK = GP_BK, LDK = GP_LDK, NST = 3;
     // Workgroups go to the 8 XCDs round robin by their linear id, and each XCD has an L2 of its own.  With x (the column tile)
     // running fastest and 8 column tiles, XCD k would compute column k of EVERY row tile: all of A through every L2.  The tiles
     // are dealt so that an XCD gets a contiguous run of them (whole row tiles: 1 / 8 of A, all of B, once).  Same tiles, same
     // arithmetic: the results do not change by a bit.
-    int bx = blockIdx.x, by = blockIdx.y;
     {
-        const int gx = gridDim.x, tiles = gx * (int)gridDim.y;
+        const int tiles = gx * gy;
         if ((tiles & 7) == 0 && !SSN_GEMM_NO_XCD_DEAL) {
             const int lin = by * gx + bx, t = (lin & 7) * (tiles >> 3) + (lin >> 3);
             by = t / gx; bx = t - by * gx;
@@ -215,7 +237,7 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
     const int m0 = by * BM, n0 = bx * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int kbeg = blockIdx.z * g.kchunk;
+    const int kbeg = bz * g.kchunk;
     const int kend = (kbeg + g.kchunk < g.K) ? kbeg + g.kchunk : g.K;
     const int nt = (kend - kbeg + BK - 1) / BK;
     const int q = tid & 15, p = tid >> 4;             // vector index along the contiguous extent, line within a group of 16
@@ -297,7 +319,33 @@ __global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
         if (t + 1 < nt) step(S1, t + 1);
         if (t + 2 < nt) step(S2, t + 2);
     }
-    gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane);
+    gemm_epilogue(g, acc, m0 + wr * 32, n0 + wc * 32, lane, bz, nz);
+}
+template <int AMODE, int BMODE>
+__global__ void __launch_bounds__(256) gemm_bf16_pipe_kernel(GemmArgs g) {
+    __shared__ __align__(16) unsigned short As[2][GP_BM][GP_LDK];
+    __shared__ __align__(16) unsigned short Bs[2][GP_BN][GP_LDK];
+    gemm_pipe_tile<AMODE, BMODE>(g, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, As, Bs);
+}
+// SEVERAL GEMMs in one launch (the weight-gradient GEMMs of a critic update on the row-block path: nothing orders them among
+// themselves, every one writes slabs or a C of its own): workgroup id -> (problem, tile, K slice), the tile code is the one above
+constexpr int kMaxBatch = 8;
+struct GemmBatchArgs { GemmArgs g[kMaxBatch]; int first[kMaxBatch + 1]; int gx[kMaxBatch], gy[kMaxBatch], nz[kMaxBatch], am[kMaxBatch], bm[kMaxBatch]; int n; };
+__global__ void __launch_bounds__(256) gemm_bf16_pipe_batch_kernel(GemmBatchArgs b) {
+    __shared__ __align__(16) unsigned short As[2][GP_BM][GP_LDK];
+    __shared__ __align__(16) unsigned short Bs[2][GP_BN][GP_LDK];
+    int p = 0;
+    while (p + 1 < b.n && (int)blockIdx.x >= b.first[p + 1]) ++p;
+    const int lin = blockIdx.x - b.first[p], gx = b.gx[p], gy = b.gy[p], nz = b.nz[p];
+    const int bz = lin / (gx * gy), rem = lin - bz * gx * gy, by = rem / gx, bx = rem - by * gx;
+    const GemmArgs& g = b.g[p];
+    const int mode = b.am[p] * 3 + b.bm[p];
+    switch (mode) {                         // (the operand modes the weight gradients meet; anything else: the general form)
+        case 4: gemm_pipe_tile<1, 1>(g, bx, by, bz, gx, gy, nz, As, Bs); break;
+        case 7: gemm_pipe_tile<2, 1>(g, bx, by, bz, gx, gy, nz, As, Bs); break;
+        case 5: gemm_pipe_tile<1, 2>(g, bx, by, bz, gx, gy, nz, As, Bs); break;
+        default: gemm_pipe_tile<2, 2>(g, bx, by, bz, gx, gy, nz, As, Bs); break;
+    }
 }
 // how gemm_bf16_pipe_kernel fetches an operand X(line, k) = base[line * sl + k * sk] with `lines` lines and K columns:
 // 16-byte vectors need an aligned base, a unit stride along the vector and the other stride and the extent in fours
@@ -358,9 +406,22 @@ hipError_t critic_splitk_flush(hipStream_t st) {
     return e;
 }
 
+// GEMMs collected for one launch (gemm_bf16_pipe_batch_kernel): between gemm_batch_begin and gemm_batch_flush every GEMM the
+// pipelined kernel would take is queued here instead of launched -- same tiles, same K slices, same slabs
+struct GemmBatch { bool on; int blocks; GemmBatchArgs b; };
+static thread_local GemmBatch tl_batch{false, 0, {}};
+static void gemm_batch_begin() { tl_batch.on = true; tl_batch.blocks = 0; tl_batch.b.n = 0; tl_batch.b.first[0] = 0; }
+static hipError_t gemm_batch_flush(hipStream_t st) {
+    tl_batch.on = false;
+    if (tl_batch.b.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gemm_bf16_pipe_batch_kernel, dim3(tl_batch.blocks), dim3(256), 0, st, tl_batch.b);
+    tl_batch.b.n = 0;
+    return hipGetLastError();
+}
 static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     int splits = 1;
+    bool slab = false;
     if (g.epilogue == EPI_PLAIN && g.beta == 1.f && g.ldc == g.N && tl_plan.scratch && tl_plan.n < kMaxSplitK) {
         splits = choose_splits(g.M, g.N, g.K);
         int same = 0;
@@ -368,18 +429,37 @@ static hipError_t gemm(GemmArgs g, bool bf16, hipStream_t st) {
         // no room, or a 5th split GEMM into one C: run it unsplit.  An unsplit GEMM adds into C directly, BEFORE the
         // slabs of earlier split ones are added at the flush -- a fixed order either way.
         if (same >= 4 || tl_plan.used + (size_t)splits * g.M * g.N > tl_plan.cap) splits = 1;
+        // (inside a batch two GEMMs may accumulate into one C -- the two halves' gradients of a weight: only GEMMs that write
+        // slabs of their own are batched; an unsplit one is launched behind everything queued so far, as it always was)
+        slab = tl_batch.on && splits > 1;
     }
     const bool pipe = bf16 && gemm_pipe_ok(g);
+    if (tl_batch.on && !(pipe && slab && tl_batch.b.n < kMaxBatch)) {      // not for the batch: everything queued so far goes first
+        hipError_t e = gemm_batch_flush(st);
+        if (e != hipSuccess) return e;
+        gemm_batch_begin();
+        slab = false;
+    }
     const int bk = pipe ? 64 : (bf16 ? 32 : 16);
     g.kchunk = ((g.K + splits - 1) / splits + bk - 1) / bk * bk;
     splits = (g.K + g.kchunk - 1) / g.kchunk;
     g.partial = nullptr;
+    slab = slab && splits > 1;
     if (splits > 1) {
         g.partial = tl_plan.scratch + tl_plan.used;
         tl_plan.e[tl_plan.n++] = SplitKEntry{g.C, g.partial, (long)g.M * g.N, splits, g.alpha};
         tl_plan.used += (size_t)splits * g.M * g.N;
     }
     dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, splits);
+    if (pipe && tl_batch.on && slab) {
+        GemmBatchArgs& b = tl_batch.b;
+        const int i = b.n++;
+        b.g[i] = g; b.gx[i] = grid.x; b.gy[i] = grid.y; b.nz[i] = grid.z;
+        b.am[i] = gemm_pipe_mode(g.A, g.sam, g.sak, g.M, g.K); b.bm[i] = gemm_pipe_mode(g.B, g.sbn, g.sbk, g.N, g.K);
+        tl_batch.blocks += (int)(grid.x * grid.y * grid.z);
+        b.first[i + 1] = tl_batch.blocks;
+        return hipSuccess;
+    }
     if (pipe) {
         const int am = gemm_pipe_mode(g.A, g.sam, g.sak, g.M, g.K), bm = gemm_pipe_mode(g.B, g.sbn, g.sbk, g.N, g.K);
         if (am == 0)      gemm_pipe_launch_b<0>(bm, grid, st, g);
@@ -452,12 +532,12 @@ __global__ void __launch_bounds__(256) critic_outgrad_kernel(const float* __rest
 // a unit that is active on equally many generated and data rows is a sum of +c and -c terms, exactly zero in the
 // reference's arithmetic; fp32 partial sums (3c, 5c, ...) round, leave ~1e-8 of noise, and Adam (eps 1e-8) turns
 // that noise into full-size steps of the bias.
-__global__ void __launch_bounds__(1024) colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int batch, int n,
-                                                      float beta) {
+// (axpy_to: instead of `out`, the sums s go to axpy_to[n] += axpy_a * (float)s -- a column sum into a scratch vector followed by
+// axpy_kernel, in one go)
+__device__ __forceinline__ void colsum_block(const float* __restrict__ X, float* __restrict__ out, int batch, int n, float beta,
+                                             int bx, double (&red)[64][64], double (&red2)[16][64], float* axpy_to, float axpy_a) {
     const int cq = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    const int col = blockIdx.x * 64 + 4 * cq;
-    __shared__ double red[64][64];
-    __shared__ double red2[16][64];
+    const int col = bx * 64 + 4 * cq;
     double s[4] = {0., 0., 0., 0.};
     if (col + 3 < n && (n & 3) == 0) {
 #pragma unroll 4
@@ -478,13 +558,42 @@ __global__ void __launch_bounds__(1024) colsum_kernel(const float* __restrict__ 
         red2[g][c] = (red[4 * g][c] + red[4 * g + 1][c]) + (red[4 * g + 2][c] + red[4 * g + 3][c]);
     }
     __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < n) {
+    if (threadIdx.x < 64 && bx * 64 + threadIdx.x < n) {
         double t = 0.;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red2[g][threadIdx.x];
-        float* o = out + blockIdx.x * 64 + threadIdx.x;
-        *o = (float)(t + (beta != 0.f ? (double)beta * (double)*o : 0.));
+        if (axpy_to) {
+            float* y = axpy_to + bx * 64 + threadIdx.x;
+            *y = __builtin_fmaf(axpy_a, (float)(t + 0.), *y);
+        } else {
+            float* o = out + bx * 64 + threadIdx.x;
+            *o = (float)(t + (beta != 0.f ? (double)beta * (double)*o : 0.));
+        }
     }
+}
+__global__ void __launch_bounds__(1024) colsum_kernel(const float* __restrict__ X, float* __restrict__ out, int batch, int n,
+                                                      float beta) {
+    __shared__ double red[64][64];
+    __shared__ double red2[16][64];
+    colsum_block(X, out, batch, n, beta, blockIdx.x, red, red2, nullptr, 0.f);
+}
+// the column sums of a critic update on the row-block path in ONE launch (bias gradients of every layer, the w_out term of the
+// penalty added straight into its gradient)
+struct ColsumBatchArgs {
+    const float* X[10]; float* out[10]; int batch[10], n[10], first[11]; float beta[10]; float* axpy_to[10]; float axpy_a[10]; int cnt;
+    // one more workgroup (the last) for the update's statistics (critic_stats_block) when stats != nullptr
+    const float* dvals; const float* dnorm; float* stats; int ng, nd, np; float lmd;
+};
+__global__ void __launch_bounds__(1024) colsum_batch_kernel(ColsumBatchArgs a) {
+    __shared__ double red[64][64];
+    __shared__ double red2[16][64];
+    if ((int)blockIdx.x == a.first[a.cnt]) {
+        critic_stats_block(a.dvals, a.dnorm, a.stats, a.ng, a.nd, a.np, a.lmd, *reinterpret_cast<float (*)[3][256]>(&red[0][0]));
+        return;
+    }
+    int p = 0;
+    while (p + 1 < a.cnt && (int)blockIdx.x >= a.first[p + 1]) ++p;
+    colsum_block(a.X[p], a.out[p], a.batch[p], a.n[p], a.beta[p], blockIdx.x - a.first[p], red, red2, a.axpy_to[p], a.axpy_a[p]);
 }
 
 // gradient-penalty head: per sample norm of g[:, :nx]; writes ghat = 2 (norm-1)/norm * g_x / batch (zero
@@ -494,11 +603,9 @@ __global__ void __launch_bounds__(256) gp_head_kernel(const float* __restrict__ 
     __shared__ float red[256];
     float local = 0.f;
     for (int b = threadIdx.x; b < batch; b += 256) {
-        float s = 0.f;
-        for (int j = 0; j < nx; ++j) { const float v = g[(long)b * n0 + j]; s += v * v; }
-        const float nrm = sqrtf(s);
-        local += (nrm - 1.f) * (nrm - 1.f);
-        const float coef = (nrm > 0.f) ? 2.f * (nrm - 1.f) / nrm / (float)batch : 0.f;
+        float coef;
+        const float d = critic_gp_row(g + (long)b * n0, nx, batch, coef);
+        local = __builtin_fmaf(d, d, local);
         for (int j = 0; j < n0; ++j) ghat[(long)b * n0 + j] = (j < nx) ? coef * g[(long)b * n0 + j] : 0.f;
     }
     red[threadIdx.x] = local;
@@ -528,11 +635,11 @@ __global__ void __launch_bounds__(256) two_means_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) fill_updown_kernel(float* up, int ng, int nd) {
     // upstream of mean D(xg) - mean D(xd) for the concatenated [xg; xd] batch
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ng + nd; i += gridDim.x * 256)
-        up[i] = (i < ng) ? 1.f / (float)ng : -1.f / (float)nd;
+        up[i] = critic_updown(i, ng, nd);
 }
 
 // stats[3] = mean D(xg) - mean D(xd) + lmd * penalty
-__global__ void loss_combine_kernel(float* stats, float lmd) { stats[3] = stats[0] - stats[1] + lmd * stats[2]; }
+__global__ void loss_combine_kernel(float* stats, float lmd) { stats[3] = critic_loss_value(stats[0], stats[1], stats[2], lmd); }
 
 // gx[b][j] = s * v0[b][j], j < nx   (tuning-curve part of the input gradient)
 __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restrict__ v0, float* __restrict__ gx, int batch,
@@ -544,7 +651,7 @@ __global__ void __launch_bounds__(256) gather_scale_kernel(const float* __restri
 }
 
 __global__ void __launch_bounds__(256) axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
-    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += gridDim.x * 256L) y[e] += a * x[e];
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < n; e += gridDim.x * 256L) y[e] = __builtin_fmaf(a, x[e], y[e]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -645,7 +752,7 @@ size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int b
     long per_row = 0, maxd = 0;
     for (int l = 0; l <= nlayers; ++l) { per_row += dims[l]; if (dims[l] > maxd) maxd = dims[l]; }
     return (size_t)(2L * batch_gd * per_row + batch_gd + 3L * batch_p * per_row + batch_p + maxd + 64) +
-           critic_splitk_scratch_floats(dims, nlayers, batch_gd + batch_p);
+           critic_splitk_scratch_floats(dims, nlayers, batch_gd + batch_p) + critic_rows_workspace_floats(dims, nlayers, batch_p);
 }
 
 // D values for a batch (inference / accuracy): out[batch]
@@ -739,7 +846,9 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
     if (nc && ((ng && !cg) || (nd && !cd) || (np && !cp))) return hipErrorInvalidValue;   // conditions for all inputs or for none
     const int L = nlayers, nx = dims[0] - nc;
     const int bgd = ng + nd;
-    if ((e = hipMemsetAsync(grads, 0, net.nparams * sizeof(float), st)) != hipSuccess) return e;
+    // (the row-block path of wide plain critics zeroes the gradient in its weight-packing launch)
+    const bool rows_path = bf16 && bgd > 0 && np > 0 && critic_rows_supported(dims, nlayers);
+    if (!rows_path && (e = hipMemsetAsync(grads, 0, net.nparams * sizeof(float), st)) != hipSuccess) return e;
     float* p = ws;
     // ---------------- (1) mean D(xg) - mean D(xd) on the concatenated batch -------------------
     float *h[10], *v[10];
@@ -775,6 +884,77 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
         }
         ~JoinScope() { (void)join(); }
     } join_scope{fk, st};
+    // ---------------- wide plain critics on bf16 operands: the row-local chains of both halves in ONE launch (ssn_critic_rows.hip),
+    // then the weight-gradient GEMMs, whose operands are all there, on the three streams.  Same bits as the chains below.
+    if (rows_path) {
+        if (eps) hipLaunchKernelGGL(critic_step_inputs_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, xd, cg, eps, xp_out,
+                                    h[0], hp[0], ng, nx, hide_cell_type, nc);
+        else {
+            hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, cg, h[0], ng, nx, hide_cell_type, nc);
+            hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nd * dims[0])), dim3(256), 0, st, xd, cd, h[0] + (long)ng * dims[0], nd, nx, hide_cell_type, nc);
+            hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type, nc);
+        }
+        RowsArgs ra{};
+        ra.L = L; ra.leak = leak;
+        for (int l = 0; l <= L; ++l) { ra.dims[l] = dims[l]; ra.h[l] = h[l]; ra.v[l] = v[l]; ra.hp[l] = hp[l]; ra.vp[l] = vp[l]; ra.ep[l] = ep[l]; }
+        ra.up = up; ra.dvals = dvals; ra.ng = ng; ra.nd = nd; ra.np = np; ra.nx = nx;
+        float* const rws = p + critic_splitk_scratch_floats(dims, nlayers, bgd + np);
+        ra.dnorm = rws;
+        if ((e = critic_rows_pack(params, dims, L, rws + np, ra, grads, net.nparams, st)) != hipSuccess) return e;
+        if ((e = critic_rows_launch(ra, st)) != hipSuccess) return e;
+        // every operand of the weight gradients is there: ONE launch for the GEMMs (split over K into slabs of their own, in the
+        // order of the chains below), one for the bias sums, the w_out term of the penalty and the statistics, one for the slabs
+        // (`par`: every weight-gradient GEMM of both halves is split over K -- the condition of the three streams below; any other
+        // shape issues them one by one, in the order and with the direct additions of the chains below)
+        if (par) gemm_batch_begin();
+        struct BatchScope { ~BatchScope() { tl_batch.on = false; tl_batch.b.n = 0; } } batch_scope;
+        ColsumBatchArgs cs{};
+        auto add_colsum = [&](const float* X, float* out, int batch, int n, float beta, float* axpy_to, float axpy_a) {
+            const int i = cs.cnt++;
+            cs.X[i] = X; cs.out[i] = out; cs.batch[i] = batch; cs.n[i] = n; cs.beta[i] = beta; cs.axpy_to[i] = axpy_to; cs.axpy_a[i] = axpy_a;
+            cs.first[i + 1] = cs.first[i] + (n + 63) / 64;
+        };
+        {
+            GemmArgs g{};                               // d/dw_out = sum_b up_b h_L[b][:]
+            g.A = h[L]; g.sam = 1; g.sak = dims[L];
+            g.B = up; g.sbk = 1; g.sbn = 1;
+            g.C = grads + (net.nparams - dims[L]); g.ldc = 1; g.M = dims[L]; g.N = 1; g.K = bgd;
+            g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+        }
+        long off = net.nparams - dims[L];
+        for (int l = L - 1; l >= 0; --l) {              // dW_l += h_l^T v_{l+1},  db_l += colsum(v_{l+1})
+            const int nin = dims[l], nout = dims[l + 1];
+            off -= nout;
+            const long off_b = off;
+            off -= (long)nin * nout;
+            GemmArgs g{};
+            g.A = h[l]; g.sam = 1; g.sak = nin;
+            g.B = v[l + 1]; g.sbk = nout; g.sbn = 1;
+            g.C = grads + off; g.ldc = nout; g.M = nin; g.N = nout; g.K = bgd;
+            g.alpha = 1.f; g.beta = 1.f; g.epilogue = EPI_PLAIN;
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+            add_colsum(v[l + 1], grads + off_b, bgd, nout, 1.f, nullptr, 0.f);
+        }
+        off = 0;
+        for (int l = 0; l < L; ++l) {                   // dW_l += lmd e_l^T v'_{l+1}
+            const int nin = dims[l], nout = dims[l + 1];
+            GemmArgs g{};
+            g.A = ep[l]; g.sam = 1; g.sak = nin;
+            g.B = vp[l + 1]; g.sbk = nout; g.sbn = 1;
+            g.C = grads + off; g.ldc = nout; g.M = nin; g.N = nout; g.K = np;
+            g.alpha = lmd; g.beta = 1.f; g.epilogue = EPI_PLAIN;
+            if ((e = gemm(g, bf16, st)) != hipSuccess) return e;
+            off += (long)nin * nout + nout;
+        }
+        if ((e = gemm_batch_flush(st)) != hipSuccess) return e;
+        // d/dw_out[k] += lmd * sum_b e_L[b][k]   (behind the GEMMs: one of them may have added into that gradient directly)
+        add_colsum(ep[L], tmp, np, dims[L], 0.f, grads + (net.nparams - dims[L]), lmd);
+        cs.dvals = dvals; cs.dnorm = ra.dnorm; cs.stats = stats; cs.ng = ng; cs.nd = nd; cs.np = np; cs.lmd = lmd;
+        hipLaunchKernelGGL(colsum_batch_kernel, dim3(cs.first[cs.cnt] + 1), dim3(1024), 0, st, cs);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return critic_splitk_flush(st);
+    }
     if (eps)        // (in front of the fork: the penalty half reads hp[0])
         hipLaunchKernelGGL(critic_step_inputs_kernel, dim3(blocks_for((long)ng * dims[0])), dim3(256), 0, st, xg, xd, cg, eps, xp_out,
                            h[0], hp[0], ng, nx, hide_cell_type, nc);

@@ -207,6 +207,25 @@ hipError_t critic_norm_loss_grad(const float* params, const int* dims, const int
                                  int nd, int np, float lmd, int hide, float* grads, float* stats, float* dvals, float* ws,
                                  bool bf16, hipStream_t st, int act = 0);
 
+// ssn_critic_rows.hip: wide plain critics (hidden widths multiples of 32 up to 512), the row-local part of an update in one launch
+struct RowsPackSeg { const float* src; unsigned short* dst; int nin, nout, NT, KS, kind; long start; };
+struct RowsPackArgs { RowsPackSeg seg[19]; int nseg; long total; float* zero; long nzero; };    // zero[0:nzero] = 0 by the blocks behind `total`
+struct RowsArgs {
+    int L, dims[10];
+    const float* b[9]; const float* wout; float leak;
+    const unsigned short* pf[9];     // B fragments of op(B)(k, n) = W_l[k][n]   (forward, second chain of the penalty)
+    const unsigned short* pb[9];     // ... of op(B)(k, i) = W_l[i][k]            (backward chains)
+    const unsigned short* po;        // ... of the column w_out
+    float* h[10]; float* v[10]; float* up; float* dvals;           // rows of [xg; xd]: activations, backward chain, upstream, D
+    float* hp[10]; float* vp[10]; float* ep[10]; float* dnorm;     // penalty rows: ..., second chain, norm - 1 per row
+    int ng, nd, np, nx;
+};
+bool critic_rows_supported(const int* dims, int nlayers);
+size_t critic_rows_workspace_floats(const int* dims, int nlayers, int batch_p);
+hipError_t critic_rows_pack(const float* params, const int* dims, int L, float* ws_pack, RowsArgs& ra, float* zero, long nzero, hipStream_t st);
+hipError_t critic_rows_launch(const RowsArgs& ra, hipStream_t st);
+hipError_t critic_rows_stats(const float* dvals, const float* dnorm, float* stats, int ng, int nd, int np, float lmd, hipStream_t st);
+
 // ssn_critic_fused.hip: critics whose layer widths are all <= 128 (3 launches per update; fp32 arithmetic)
 bool critic_fused_supported(const int* dims, int nlayers);
 size_t critic_fused_workspace_floats(const int* dims, int nlayers, int batch_gd, int batch_p);

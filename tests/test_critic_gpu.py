@@ -277,6 +277,57 @@ def test_pipelined_bf16_gemm_agrees_with_the_general_kernel():
         np.testing.assert_allclose(res['1'][key], want, rtol=1e-5, atol=2e-6 * np.abs(want).max(), err_msg=key)
 
 
+def test_rows_path_matches_layer_path():
+    """Wide plain critics on bf16 operands run the row-local part of an update as ONE launch (`critic_rows_kernel`,
+    ssn_critic_rows.hip: a workgroup walks its 32 rows through forward, backward chain, penalty head and second chain);
+    `SSN_CRITIC_ROWS=0` keeps the layer-by-layer chain of GEMM launches.  Same instruction, same operand rounding, same k
+    order, same orders of the cross-row sums: statistics, D values and EVERY gradient are equal bit for bit -- at the C3 shape,
+    with a ragged last row block, with odd tile counts (widths 96 / 160 / 32), with a leaky nonlinearity, without
+    conditions, and through the one-call step (parameters after the optimizer, record tail, penalty points)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from tc_gan_amd.critic import Critic, Updater\n"
+        "res = {}\n"
+        "cases = (('c3', 1024, [512, 512, 512], 'rectify', True), ('ragged', 1000, [512, 64], 'rectify', True),\n"
+        "         ('odd', 77, [96, 160, 32], 'leaky_rectify', True), ('one', 33, [32], 'very_leaky_rectify', True),\n"
+        "         ('nocond', 300, [256, 128], 'rectify', False))\n"
+        "for tag, batch, layers, nl, conditional in cases:\n"
+        "    rs = np.random.RandomState(len(layers) * 7 + batch)\n"
+        "    c = Critic(8, layers, precision='bf16', seed=5, nonlinearity=nl, conditional=conditional)\n"
+        "    xg, xd = (torch.as_tensor(rs.rand(batch, 8) * 5, device='cuda', dtype=torch.float32) for _ in range(2))\n"
+        "    xp = 0.25 * xg + 0.75 * xd\n"
+        "    cond = torch.as_tensor(np.stack([np.full(batch, 20.), rs.rand(batch) * 2 - 1, rs.randint(0, 2, batch)], 1),\n"
+        "                           device='cuda', dtype=torch.float32) if conditional else None\n"
+        "    res['stats_' + tag] = c.loss_grad(xg, cond, xd, cond, xp, cond, 10.0).cpu().numpy()\n"
+        "    res['grads_' + tag] = c.grads.cpu().numpy()\n"
+        "    res['dvals_' + tag] = c._dvals.cpu().numpy()\n"
+        "    half = batch // 2\n"
+        "    res['stats2_' + tag] = c.loss_grad(xg[:half], None if cond is None else cond[:half], xd, cond, xp[:half + 3],\n"
+        "                                        None if cond is None else cond[:half + 3], 3.0).cpu().numpy()\n"
+        "    res['grads2_' + tag] = c.grads.cpu().numpy()\n"
+        "    upd = Updater(learning_rate=1e-3, update_name='adam-wgan')\n"
+        "    eps = torch.as_tensor(rs.rand(batch), device='cuda', dtype=torch.float32)\n"
+        "    for it in range(2):\n"
+        "        xp2, tail = c.step(upd, xg, xd, cond, eps, 10.0)\n"
+        "    res['step_xp_' + tag] = xp2.cpu().numpy(); res['step_tail_' + tag] = tail.cpu().numpy()\n"
+        "    res['step_params_' + tag] = c.params.cpu().numpy(); res['step_stats_' + tag] = c.stats.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **res)\n" % root)
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for form in ('0', '1'):
+            path = os.path.join(tmp, 'rows%s.npz' % form)
+            subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, SSN_CRITIC_ROWS=form), timeout=300)
+            res[form] = dict(np.load(path))
+    for key, want in res['0'].items():
+        assert np.isfinite(want).all() and np.abs(want).max() > 0, key
+        np.testing.assert_array_equal(res['1'][key], want, err_msg=key)
+
+
 def test_generator_side_input_gradient():
     c, params_o, xg, xd, xp, cond = _setup(96, 8, [64, 64], seed=11)
     x = og.t64(xg).clone().requires_grad_(True)
