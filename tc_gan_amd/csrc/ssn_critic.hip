@@ -755,6 +755,18 @@ size_t critic_workspace_floats(const int* dims, int nlayers, int batch_gd, int b
            critic_splitk_scratch_floats(dims, nlayers, batch_gd + batch_p) + critic_rows_workspace_floats(dims, nlayers, batch_p);
 }
 
+// Wide plain critics on bf16 operands: D (mode 0) or D and the input gradient (mode 1) of `batch` rows whose input block h0 is
+// built, in two launches -- weights to B fragments, the row-block kernel (ssn_critic_rows.hip).  `free_ws`: workspace behind h0.
+static hipError_t critic_rows_eval(const float* params, const int* dims, int nlayers, float* h0, int batch, float* dvals, int mode,
+                                   float* gx, float scale, int nx, float leak, float* free_ws, hipStream_t st) {
+    RowsArgs ra{};
+    ra.L = nlayers; ra.leak = leak; ra.mode = mode; ra.nx = nx; ra.dvals = dvals; ra.gx = gx; ra.scale = scale;
+    for (int l = 0; l <= nlayers; ++l) ra.dims[l] = dims[l];
+    if (mode == 0) { ra.h[0] = h0; ra.ng = batch; } else { ra.hp[0] = h0; ra.np = batch; }
+    hipError_t e = critic_rows_pack(params, dims, nlayers, free_ws, ra, nullptr, 0, st);
+    return e != hipSuccess ? e : critic_rows_launch(ra, st);
+}
+
 // D values for a batch (inference / accuracy): out[batch]
 hipError_t critic_forward(const float* params, const int* dims, int nlayers, const float* x, const float* cond, int batch,
                           int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st, float leak) {
@@ -765,6 +777,8 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
     float* p = ws;
     for (int l = 0; l <= nlayers; ++l) { h[l] = p; p += (long)batch * dims[l]; }
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type, nc);
+    if (bf16 && batch > 0 && critic_rows_supported(dims, nlayers))
+        return critic_rows_eval(params, dims, nlayers, h[0], batch, out, 0, nullptr, 0.f, nx, leak, h[1], st);
     return critic_forward_pass(net, h, out, batch, bf16, st);
 }
 
@@ -785,6 +799,8 @@ hipError_t critic_forward2(const float* params, const int* dims, int nlayers, co
     for (int l = 0; l <= nlayers; ++l) { h[l] = p; p += (long)batch * dims[l]; }
     if (na > 0) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)na * dims[0])), dim3(256), 0, st, xa, ca, h[0], na, nx, hide_cell_type, nc);
     if (nb > 0) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nb * dims[0])), dim3(256), 0, st, xb, cb, h[0] + (long)na * dims[0], nb, nx, hide_cell_type, nc);
+    if (bf16 && critic_rows_supported(dims, nlayers))
+        return critic_rows_eval(params, dims, nlayers, h[0], batch, out, 0, nullptr, 0.f, nx, leak, h[1], st);
     return critic_forward_pass(net, h, out, batch, bf16, st);
 }
 
@@ -895,7 +911,7 @@ hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, c
             hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)np * dims[0])), dim3(256), 0, st, xp, cp, hp[0], np, nx, hide_cell_type, nc);
         }
         RowsArgs ra{};
-        ra.L = L; ra.leak = leak;
+        ra.L = L; ra.leak = leak; ra.mode = 2;
         for (int l = 0; l <= L; ++l) { ra.dims[l] = dims[l]; ra.h[l] = h[l]; ra.v[l] = v[l]; ra.hp[l] = hp[l]; ra.vp[l] = vp[l]; ra.ep[l] = ep[l]; }
         ra.up = up; ra.dvals = dvals; ra.ng = ng; ra.nd = nd; ra.np = np; ra.nx = nx;
         float* const rws = p + critic_splitk_scratch_floats(dims, nlayers, bgd + np);
@@ -1043,6 +1059,11 @@ hipError_t critic_input_grad(const float* params, const int* dims, int nlayers, 
     for (int l = 0; l <= L; ++l) { v[l] = p; p += (long)batch * dims[l]; }
     float* dv = p; p += batch;
     hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)batch * dims[0])), dim3(256), 0, st, x, cond, h[0], batch, nx, hide_cell_type, nc);
+    if (bf16 && batch > 0 && critic_rows_supported(dims, nlayers)) {
+        if ((e = critic_rows_eval(params, dims, nlayers, h[0], batch, dv, 1, gx, scale, nx, leak, p, st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dv, stats, batch, 0);
+        return hipGetLastError();
+    }
     if ((e = critic_forward_pass(net, h, dv, batch, bf16, st)) != hipSuccess) return e;
     hipLaunchKernelGGL(two_means_kernel, dim3(1), dim3(256), 0, st, dv, stats, batch, 0);
     hipLaunchKernelGGL(critic_outgrad_kernel, dim3(blocks_for((long)batch * dims[L])), dim3(256), 0, st, h[L], net.wout, (const float*)nullptr, v[L], batch, dims[L], net.leak);

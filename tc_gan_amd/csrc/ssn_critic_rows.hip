@@ -185,6 +185,9 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
     __shared__ float G[RW_RB][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int L = a.L;
+    // mode 2: the update (penalty blocks + [xg; xd] blocks); mode 0: D of ng + nd rows only; mode 1: D and the input gradient of np rows
+    const int mode = a.mode;
+    const bool keep = mode == 2;                         // the fp32 copies are for the weight-gradient GEMMs
     const int nbp = (a.np + RW_RB - 1) / RW_RB;
     const bool pen = (int)blockIdx.x < nbp;
     const int blk = pen ? blockIdx.x : blockIdx.x - nbp;
@@ -197,9 +200,10 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
     auto pass_at = [&](int i) {
         RowsPass ps{nullptr, 0, 0};
         if (i < L) { ps.pack = a.pf[i]; ps.KS = (a.dims[i] + 15) / 16; ps.NT = a.dims[i + 1] / 32; }
+        else if (mode == 0) {}
         else if (i < 2 * L - 1) { const int l = 2 * L - 1 - i; ps.pack = a.pb[l]; ps.KS = a.dims[l + 1] / 16; ps.NT = a.dims[l] / 32; }
         else if (pen && i == 2 * L - 1) { ps.pack = a.pb[0]; ps.KS = a.dims[1] / 16; ps.NT = 1; }
-        else if (pen && i < 3 * L) { const int l = i - 2 * L; ps.pack = a.pf[l]; ps.KS = (a.dims[l] + 15) / 16; ps.NT = a.dims[l + 1] / 32; }
+        else if (pen && mode == 2 && i < 3 * L) { const int l = i - 2 * L; ps.pack = a.pf[l]; ps.KS = (a.dims[l] + 15) / 16; ps.NT = a.dims[l + 1] / 32; }
         return ps;
     };
     bf16x8 q[RW_TPW][RW_DEPTH];
@@ -228,14 +232,14 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
     for (int l = 0; l < L; ++l) {
         const int N = a.dims[l + 1], NT = N / 32;
         run_pass(acc);
-        rows_finish<0>(acc, N, NT, r0, nrows, a.b[l], leak, mk, hh(l + 1), Abuf[cur ^ 1], wave, lane);
+        rows_finish<0>(acc, N, NT, r0, nrows, a.b[l], leak, mk, keep ? hh(l + 1) : nullptr, Abuf[cur ^ 1], wave, lane);
         maskw[l + 1][tid] = mk;
         cur ^= 1;
         __syncthreads();
     }
     const int NL = a.dims[L], NTL = NL / 32, KSL = NL / 16;
-    // ---- D = h_L w_out ([xg; xd] rows; the penalty half never uses its D)
-    if (!pen && wave == 0) {
+    // ---- D = h_L w_out ([xg; xd] rows; the penalty half of an update never uses its D)
+    if ((!pen || mode == 1) && wave == 0) {
         f32x16 d;
 #pragma unroll
         for (int i = 0; i < 16; ++i) d[i] = 0.f;
@@ -252,6 +256,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
             }
         }
     }
+    if (mode == 0) return;
     if (!pen && tid < RW_RB && r0 + tid < nrows) a.up[r0 + tid] = critic_updown(r0 + tid, a.ng, a.nd);
     // ---- v_L = m_L * w_out * up   (critic_outgrad_kernel; the penalty half: up = 1)
     {
@@ -269,7 +274,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
                 const float v = wn * (pen ? 1.f : critic_updown(r0 + m, a.ng, a.nd));
                 const float o = ((bits >> (16 * j + reg)) & 1u) ? v : leak * v;
                 Abuf[cur ^ 1][m * RW_LDA + n] = rows_bf16(o);
-                if (r0 + m < nrows) rows_store(vL + (long)(r0 + m) * NL + n, o);
+                if (keep && r0 + m < nrows) rows_store(vL + (long)(r0 + m) * NL + n, o);
             }
         }
     }
@@ -280,7 +285,7 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
         const int N = a.dims[l], NT = N / 32;
         run_pass(acc);
         mk = maskw[l][tid];
-        rows_finish<1>(acc, N, NT, r0, nrows, nullptr, leak, mk, vv(l), Abuf[cur ^ 1], wave, lane);
+        rows_finish<1>(acc, N, NT, r0, nrows, nullptr, leak, mk, keep ? vv(l) : nullptr, Abuf[cur ^ 1], wave, lane);
         cur ^= 1;
         __syncthreads();
     }
@@ -295,6 +300,13 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
             for (int reg = 0; reg < 16; ++reg) G[(reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)][n] = acc[0][reg];
         }
         __syncthreads();
+        if (mode == 1) {                                  // gx = scale * g[:, 0:nx]   (gather_scale_kernel)
+            for (int e = tid; e < RW_RB * a.nx; e += 64 * RW_WAVES) {
+                const int m = e / a.nx, j = e % a.nx;
+                if (r0 + m < nrows) a.gx[(long)(r0 + m) * a.nx + j] = a.scale * G[m][j];
+            }
+            return;
+        }
         const int kp = 16 * ((n0 + 15) / 16);
         if (tid < RW_RB) {
             const int m = tid;

@@ -219,6 +219,8 @@ struct RowsArgs {
     float* h[10]; float* v[10]; float* up; float* dvals;           // rows of [xg; xd]: activations, backward chain, upstream, D
     float* hp[10]; float* vp[10]; float* ep[10]; float* dnorm;     // penalty rows: ..., second chain, norm - 1 per row
     int ng, nd, np, nx;
+    int mode;                        // 2: the update; 0: D of the ng + nd rows of h[0] only; 1: D and the input gradient of the np rows of hp[0]
+    float* gx; float scale;          // mode 1: gx[np][nx] = scale * dD/dx
 };
 bool critic_rows_supported(const int* dims, int nlayers);
 size_t critic_rows_workspace_floats(const int* dims, int nlayers, int batch_p);

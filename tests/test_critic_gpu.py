@@ -283,7 +283,8 @@ def test_rows_path_matches_layer_path():
     `SSN_CRITIC_ROWS=0` keeps the layer-by-layer chain of GEMM launches.  Same instruction, same operand rounding, same k
     order, same orders of the cross-row sums: statistics, D values and EVERY gradient are equal bit for bit -- at the C3 shape,
     with a ragged last row block, with odd tile counts (widths 96 / 160 / 32), with a leaky nonlinearity, without
-    conditions, and through the one-call step (parameters after the optimizer, record tail, penalty points)."""
+    conditions, through the one-call step (parameters after the optimizer, record tail, penalty points), and for the other
+    users of the kernel: `forward`, the generator side's `input_grad`, the accuracy of two stacked batches."""
     import os
     import subprocess
     import sys
@@ -310,6 +311,10 @@ def test_rows_path_matches_layer_path():
         "    res['stats2_' + tag] = c.loss_grad(xg[:half], None if cond is None else cond[:half], xd, cond, xp[:half + 3],\n"
         "                                        None if cond is None else cond[:half + 3], 3.0).cpu().numpy()\n"
         "    res['grads2_' + tag] = c.grads.cpu().numpy()\n"
+        "    res['fwd_' + tag] = c.forward(xd, cond).cpu().numpy()\n"
+        "    gx, dmean = c.input_grad(xg, cond, scale=-1.0 / batch)\n"
+        "    res['gx_' + tag] = gx.cpu().numpy(); res['gxmean_' + tag] = dmean.cpu().numpy().reshape(1)\n"
+        "    res['acc_' + tag] = c.accuracy_device(xg[:half], None if cond is None else cond[:half], xd, cond).cpu().numpy()\n"
         "    upd = Updater(learning_rate=1e-3, update_name='adam-wgan')\n"
         "    eps = torch.as_tensor(rs.rand(batch), device='cuda', dtype=torch.float32)\n"
         "    for it in range(2):\n"
