@@ -632,7 +632,7 @@ hipError_t launch_interpolate(const float* eps, const float* xd, const float* xg
 
 // Adjoint of the conditional prober's gather tuning_curve[k][s] = time_avg[ids[k]][s][probes[k]] (cwgan.py:91-98):
 // g_ta[b][s][m] = sum over the samples k with ids[k] == b and probes[k] == m of g[k][s], zero elsewhere.  One workgroup
-// per model b zeroes its slab and lets thread s add the matching samples in k order: deterministic whatever the
+// per model b (ONE wave) zeroes its slab and lets thread s add the matching samples in k order: deterministic whatever the
 // collisions, no atomics, no sort, no host wait.
 template <typename T>
 __global__ void __launch_bounds__(64) probe_scatter_kernel(const T* __restrict__ g, const long* __restrict__ ids,
@@ -641,9 +641,18 @@ __global__ void __launch_bounds__(64) probe_scatter_kernel(const T* __restrict__
     T* slab = g_ta + (size_t)b * NB * M;
     for (int i = threadIdx.x; i < NB * M; i += 64) slab[i] = (T)0;
     __syncthreads();
-    for (int s = threadIdx.x; s < NB; s += 64)
-        for (int k = 0; k < n; ++k)
-            if (ids[k] == b) slab[(size_t)s * M + probes[k]] += g[(size_t)k * NB + s];
+    // the wave looks at 64 samples at a time (one ballot), then walks the matches in k order: the additions of a (stimulus,
+    // probe) cell are made by one thread in the order of the plain loop over k (round 4: every thread scanned all n ids itself)
+    for (int k0 = 0; k0 < n; k0 += 64) {
+        const int k = k0 + (int)threadIdx.x;
+        unsigned long long hit = __ballot(k < n && ids[k] == b);
+        while (hit) {
+            const int kk = k0 + __builtin_ctzll(hit);
+            hit &= hit - 1;
+            const long m = probes[kk];
+            for (int s = threadIdx.x; s < NB; s += 64) slab[(size_t)s * M + m] += g[(size_t)kk * NB + s];
+        }
+    }
 }
 template <typename T>
 hipError_t launch_probe_scatter(const T* g, const long* ids, const long* probes, T* g_ta, int n, int B, int NB, int M, hipStream_t st) {

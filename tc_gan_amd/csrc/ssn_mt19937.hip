@@ -593,7 +593,10 @@ static hipError_t device_tables(int need_level, DeviceTables** out) {
     if (!t->side) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if ((e = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, hi)) != hipSuccess) return e;
+        // (SSN_MT_PRIORITY=low|mid in the environment: A/B runs -- the default is the greatest priority the device offers)
+        const char* pe = getenv("SSN_MT_PRIORITY");
+        const int prio = (pe && pe[0] == 'l') ? lo : ((pe && pe[0] == 'm') ? (lo + hi) / 2 : hi);
+        if ((e = hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio)) != hipSuccess) return e;
         for (auto& tk : t->tickets) {
             if ((e = hipEventCreateWithFlags(&tk.done, hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipHostMalloc((void**)&tk.pinned, sizeof(uint32_t) * kN, hipHostMallocDefault)) != hipSuccess) return e;
