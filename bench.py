@@ -391,8 +391,56 @@ def run_c3(args, rank, world, local_rank, paper=False, z_mode='refstream', compa
                                    "NOT the reference's noise stream; the difference to ms_per_step is what continuing the RandomState costs"}
     if phases is not None:
         out['phases'] = phases
+    if not paper and rank == 0:
+        out['critic'] = _critic_update_roofline(gan, models)
     out['world_size'] = world
     return out
+
+
+def _critic_update_roofline(gan, rows):
+    """north_star: "MFMA utilisation reported against gfx950 peak" for the critic's bf16 GEMMs.  Device time of ONE critic loss +
+    gradient at the loop's shape (3 x `rows` input rows), calls back to back behind a long fill so that the queue stays ahead of
+    the device (HIP events on torch's stream: the calls launch there), against the ALGORITHMIC flops of the update: forward of the
+    3 x rows, backward chain of the 2 x rows of [xg; xd], input-gradient chain and second chain of the penalty rows, the
+    weight gradients of both halves (2 flops per multiply-add of every layer GEMM)."""
+    import numpy as np
+    import torch
+    from tc_gan_amd.critic import Critic
+    disc = gan.discriminator if hasattr(gan, 'discriminator') else gan.disc
+    c = getattr(disc, 'critic', disc)
+    layers = [int(d) for d in c.dims[1:]]
+    nx = c.nx
+    cc = Critic(nx, layers, precision='bf16' if c.precision == 0 else 'fp32', normalization='none', nonlinearity=c.nonlinearity)
+    rs = np.random.RandomState(0)
+    xg, xd = (torch.as_tensor(rs.rand(rows, nx) * 5, device='cuda', dtype=torch.float32) for _ in range(2))
+    xp = 0.5 * (xg + xd)
+    cond = torch.as_tensor(np.stack([np.full(rows, 20.), rs.rand(rows), np.zeros(rows)], 1), device='cuda', dtype=torch.float32)
+    big = torch.empty(1 << 27, device='cuda')
+
+    def run(n):
+        big.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            cc.loss_grad(xg, cond, xd, cond, xp, cond, 10.0)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n * 1e3
+    run(3)
+    us = min(run(6), run(6))
+    dims = [nx + 3] + layers
+    per_row = sum(dims[l] * dims[l + 1] for l in range(len(layers))) + layers[-1]      # multiply-adds of one row's pass
+    hidden = sum(dims[l] * dims[l + 1] for l in range(1, len(layers)))                 # ... of the backward chain (no input layer)
+    macs = 3 * rows * per_row + 2 * rows * hidden + rows * (hidden + dims[0] * dims[1]) + rows * per_row + 3 * rows * per_row
+    tf = 2.0 * macs / (us * 1e-6) * 1e-12
+    peak = 2516.8
+    return {'loss_grad_us': us, 'algorithmic_gflop': 2.0 * macs * 1e-9, 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+            'bound': 'mfma', 'mfma_dtype': 'bf16 (fp32 master values rounded to nearest even, fp32 accumulate)',
+            'rows': 3 * rows, 'layers': layers,
+            'path': 'row-block kernel + batched weight gradients (ssn_critic_rows.hip, 9 launches)'
+                    if os.environ.get('SSN_CRITIC_ROWS', '1') != '0' and c.precision == 0 else 'layer-by-layer GEMM chain',
+            'note': 'device time of one loss + gradient (no optimizer step), back-to-back calls; the update is bound by the '
+                    "CUs' 64 B/clock path from L2 (every 32-row block reads all packed weights per layer) and by launch count, not by the matrix pipe"}
 
 
 def run_c5(args, rank, world, local_rank):
