@@ -37,7 +37,8 @@ ENTRIES = {
     'c2': ('c2_mixed_pmc_summary.csv', 'ssn::solve_tile_mixed_kernel', 'solve_tile_mixed_kernel per launch at C2; algorithmic 665.2 MB'),
     'c3': ('duo_forward_pmc_summary.csv', 'ssn::gen_forward_duo_kernel<208, false',
            'gen_forward_duo_kernel<208, false, ...> per launch (critic-phase forwards, no trajectory stores); algorithmic: W 164 MB + '
-           'ext / outputs 26 MB; the excess is the second pass over W after the max |W| pass of the prologue'),
+           'ext / outputs 26 MB; W is read once since the one-pass prologue (401 MB before it); the excess is the scratch of the prologue '
+           '(148-208 B per lane, written and read once: the fp32 units of W beside the lane constants)'),
     'c3_save': ('duo_forward_save_pmc_summary.csv', 'ssn::gen_forward_duo_kernel<208, true', 'the trajectory-saving forward of the generator step'),
     'c5': ('c5_sparse_pmc_summary.csv', 'ssn::ff_forward_sparse_lattice_kernel', 'ff_forward_sparse_lattice_kernel per launch; algorithmic 4.28 GB'),
     'c2nb8': ('duo_solver_pmc_summary.csv', 'ssn::solve_duo_kernel', 'solve_duo_kernel<208> per launch at C2 with 8 stimuli; algorithmic 734 MB'),
