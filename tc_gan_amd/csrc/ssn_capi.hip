@@ -747,7 +747,7 @@ int ssn_critic_input_grad_norm(const float* params, const int* dims, const int* 
 // zero = plain layers, leak as in the _leaky entry points.
 static int critic_accuracy_forwards(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
                                     const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type,
-                                    float* dvals, float* workspace, int precision, void* stream);
+                                    float* dvals, float* workspace, int precision, void* stream, bool inputs_ready = false);
 int ssn_critic_accuracy(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
                         const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type, float* acc,
                         float* dvals, float* workspace, int precision, void* stream) {
@@ -758,14 +758,14 @@ int ssn_critic_accuracy(const float* params, const int* dims, const int* layer_n
 }
 static int critic_accuracy_forwards(const float* params, const int* dims, const int* layer_norm, int nlayers, float leak, const float* xg,
                                     const float* cg, const float* xd, const float* cd, int ng, int nd, int hide_cell_type,
-                                    float* dvals, float* workspace, int precision, void* stream) {
+                                    float* dvals, float* workspace, int precision, void* stream, bool inputs_ready) {
     bool norm = false;
     for (int l = 0; layer_norm && l < nlayers; ++l) norm = norm || layer_norm[l] != 0;
     if (!norm && !(cg && cd && (fused_ok(dims, nlayers, ng) || fused_ok(dims, nlayers, nd)))) {
         // plain layers on the layer-by-layer path: ONE pass over the stacked rows [xg; xd] (the values of two separate
         // forwards, bit for bit; narrow critics keep their single-launch forwards)
         SSN_TRY(ssn::critic_forward2(params, dims, nlayers, xg, cg, ng, xd, cd, nd, hide_cell_type, dvals, workspace, precision == 0,
-                                     (hipStream_t)stream, leak));
+                                     (hipStream_t)stream, leak, inputs_ready));
         return 0;
     }
     const struct { const float* x; const float* c; int n; float* out; } part[2] = {{xg, cg, ng, dvals}, {xd, cd, nd, dvals + ng}};
@@ -877,8 +877,10 @@ static int critic_step_impl(const ssn_critic_step* a, const double* gate, double
     if (rc) return rc;
     const long nparams = ssn_critic_num_params(a->dims, a->nlayers);
     if ((rc = optimizer_step_gated(a->params, a->grads, a->opt_s1, a->opt_s2, nparams, a->opt, gate, gate_bound, stream))) return rc;
+    // (the loss pass of the one-launch-inputs form left the input block of [xg; xd] at the head of the workspace, where the
+    // stacked forward of the accuracy builds it: same rows, same conditions -- not built again)
     if ((rc = critic_accuracy_forwards(a->params, a->dims, a->layer_norm, a->nlayers, a->leak, a->xg, a->cond, a->xd, a->cond, n, n,
-                                       a->hide_cell_type, a->acc_dvals, a->workspace, a->precision, stream))) return rc;
+                                       a->hide_cell_type, a->acc_dvals, a->workspace, a->precision, stream, one_launch_inputs))) return rc;
     if (a->nseg > 0 && (!a->seg_bounds || !a->seg_ws)) { g_last_error = "ssn_critic_step_run: invalid argument"; return SSN_ERR_BASE + (int)hipErrorInvalidValue; }
     // accuracy, sums of squares and the head of the record: the chunk sums, then ONE finishing launch (same bits as
     // ssn_critic_accuracy + ssn_segment_sqnorms2_f32 + the head kernel)

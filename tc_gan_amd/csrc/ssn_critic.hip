@@ -788,7 +788,7 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
 // out[na + nb]; ws as critic_forward with batch = na + nb (<= 2 max(na, nb): what the callers reserve).
 hipError_t critic_forward2(const float* params, const int* dims, int nlayers, const float* xa, const float* ca, int na,
                            const float* xb, const float* cb, int nb, int hide_cell_type, float* out, float* ws, bool bf16,
-                           hipStream_t st, float leak) {
+                           hipStream_t st, float leak, bool inputs_ready) {
     CriticNet net;
     if (!parse_net(params, dims, nlayers, net, leak)) return hipErrorInvalidValue;
     if ((ca == nullptr) != (cb == nullptr) && na > 0 && nb > 0) return hipErrorInvalidValue;
@@ -797,8 +797,8 @@ hipError_t critic_forward2(const float* params, const int* dims, int nlayers, co
     float* h[10];
     float* p = ws;
     for (int l = 0; l <= nlayers; ++l) { h[l] = p; p += (long)batch * dims[l]; }
-    if (na > 0) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)na * dims[0])), dim3(256), 0, st, xa, ca, h[0], na, nx, hide_cell_type, nc);
-    if (nb > 0) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nb * dims[0])), dim3(256), 0, st, xb, cb, h[0] + (long)na * dims[0], nb, nx, hide_cell_type, nc);
+    if (na > 0 && !inputs_ready) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)na * dims[0])), dim3(256), 0, st, xa, ca, h[0], na, nx, hide_cell_type, nc);
+    if (nb > 0 && !inputs_ready) hipLaunchKernelGGL(critic_input_kernel, dim3(blocks_for((long)nb * dims[0])), dim3(256), 0, st, xb, cb, h[0] + (long)na * dims[0], nb, nx, hide_cell_type, nc);
     if (bf16 && critic_rows_supported(dims, nlayers))
         return critic_rows_eval(params, dims, nlayers, h[0], batch, out, 0, nullptr, 0.f, nx, leak, h[1], st);
     return critic_forward_pass(net, h, out, batch, bf16, st);

@@ -182,7 +182,8 @@ hipError_t critic_forward(const float* params, const int* dims, int nlayers, con
                           int hide_cell_type, float* out, float* ws, bool bf16, hipStream_t st, float leak = 0.f);
 hipError_t critic_forward2(const float* params, const int* dims, int nlayers, const float* xa, const float* ca, int na,
                            const float* xb, const float* cb, int nb, int hide_cell_type, float* out, float* ws, bool bf16,
-                           hipStream_t st, float leak = 0.f);
+                           hipStream_t st, float leak = 0.f, bool inputs_ready = false);
+// (inputs_ready: ws already starts with the input block of [xa; xb] -- critic_loss_grad on the same rows leaves it there)
 hipError_t critic_loss_grad(const float* params, const int* dims, int nlayers, const float* xg, const float* cg,
                             const float* xd, const float* cd, const float* xp, const float* cp, int ng, int nd, int np,
                             float lmd, int hide_cell_type, float* grads, float* stats, float* dvals, float* ws, bool bf16,
