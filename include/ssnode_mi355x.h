@@ -527,6 +527,11 @@ int ssn_stimulus_amp_f32(const float *bandwidths, const float *contrasts, float 
                          float *ext, int B, int NB, int N, void *stream);
 int ssn_stimulus_amp_f64(const double *bandwidths, const double *contrasts, double smoothness, const double *amp,
                          double *ext, int B, int NB, int N, void *stream);
+/* The same with the amplification formed in the launch (networks/ssn.py:679-686): amp[b][m] = 1 + v(m) * zin[b][m], rounded as
+ * the two fp32 operations of `1 + vs[None, :] * zin`.  zin: device [B][2N]; v: device, one value per neuron (nv = 2N), per
+ * population (nv = 2: neurons 0..N-1 take v[0], the others v[1]) or one for all (nv = 1). */
+int ssn_stimulus_hetero_f32(const float *bandwidths, const float *contrasts, float smoothness, const float *zin, const float *v,
+                            int nv, float *ext, int B, int NB, int N, void *stream);
 
 /* I/O nonlinearity on arrays (device pointers), the device function the solver
  * kernels use: out[i] = io(v[i]).  p->k, n, rate_soft_bound, rate_hard_bound,

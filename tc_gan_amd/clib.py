@@ -108,6 +108,8 @@ libssnode.ssn_stimulus_f32.argtypes = [c_void_p, c_void_p, c_float, c_void_p, c_
 libssnode.ssn_stimulus_f64.argtypes = [c_void_p, c_void_p, c_double, c_void_p, c_int, c_int, c_int, c_void_p]
 libssnode.ssn_stimulus_amp_f32.argtypes = [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
 libssnode.ssn_stimulus_amp_f64.argtypes = [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_hetero_f32.argtypes = [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]
+libssnode.ssn_stimulus_hetero_f32.restype = c_int
 libssnode.ssn_stimulus_amp_f32.restype = c_int
 libssnode.ssn_stimulus_amp_f64.restype = c_int
 libssnode.ssn_io_eval_f32.argtypes = [c_void_p, c_void_p, c_long, _pp, c_void_p]
@@ -337,7 +339,7 @@ DECLARED_SYMBOLS = (
     'ssn_critic_input_grad', 'ssn_optimizer_step',
     'ssn_ff_forward_sparse_f32', 'ssn_ff_backward_sparse_f32', 'ssn_ff_forward_f32', 'ssn_ff_backward_f32', 'ssn_moment_sums_f32', 'ssn_moment_loss_grad_f32',
     'ssn_build_dw_f32', 'ssn_build_dw_f64', 'ssn_ss_grad_system_f32', 'ssn_ss_grad_system_f64',
-    'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
+    'ssn_stimulus_amp_f32', 'ssn_stimulus_amp_f64', 'ssn_stimulus_hetero_f32', 'ssn_gen_backward_ext_f32', 'ssn_gen_backward_ext_f64',
     'ssn_critic_norm_workspace_floats', 'ssn_critic_forward_norm', 'ssn_critic_loss_grad_norm',
     'ssn_critic_input_grad_norm', 'ssn_philox_uniform_f32', 'ssn_philox_uniform_f64',
     'ssn_weight_grad_f32', 'ssn_weight_grad_f64', 'ssn_lu_solve_f32', 'ssn_lu_solve_f64',

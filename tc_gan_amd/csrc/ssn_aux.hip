@@ -110,6 +110,37 @@ hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T*
     hipLaunchKernelGGL((stimulus_kernel<T>), dim3(blocks), dim3(256), 0, st, bw, con, (T)1 / smooth, amp, NB, ext, N, total);
     return hipGetLastError();
 }
+// The heterogeneous-input stimulus with its amplification formed in the launch: gain = 1 + v z_in (networks/ssn.py:679-686),
+// the two roundings of the torch expression `1 + vs[None, :] * zin` that used to be three small launches in front of this one.
+// v: per neuron [2N] (nv = 2N), per population [2] (first N neurons v[0], the others v[1]) or one value [1].
+__global__ void __launch_bounds__(256) stimulus_hetero_kernel(const float* __restrict__ bw, const float* __restrict__ con, float inv_l,
+                                                              const float* __restrict__ zin, const float* __restrict__ v, int nv,
+                                                              int NB, float* __restrict__ ext, int N, long total) {
+    const int M = 2 * N;
+    const float step = (N > 1) ? 1.f / (float)(N - 1) : 0.f;
+    for (long e = blockIdx.x * 256L + threadIdx.x; e < total; e += (long)gridDim.x * 256L) {
+        const int m = (int)(e % M);
+        const long bs = e / M;
+        const int i = m >= N ? m - N : m;
+        const float x = -0.5f + step * (float)i;
+        const float hb = bw[bs] * 0.5f;
+        const float s1 = 1.f / (1.f + exp(-(x + hb) * inv_l));
+        const float s2 = 1.f / (1.f + exp(-(hb - x) * inv_l));
+        const float vm = v[nv == M ? m : (nv == 2 ? (m >= N ? 1 : 0) : 0)];
+        float t = vm * zin[(bs / NB) * M + m];
+        asm volatile("" : "+v"(t));                      // (the product is rounded before the addition: no contraction into one fma)
+        const float gain = 1.f + t;
+        ext[e] = gain * con[bs] * s1 * s2;
+    }
+}
+hipError_t launch_stimulus_hetero(const float* bw, const float* con, float smooth, const float* zin, const float* v, int nv, float* ext,
+                                  int B, int NB, int N, hipStream_t st) {
+    const long total = (long)B * NB * 2 * N;
+    if (total == 0) return hipSuccess;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(stimulus_hetero_kernel, dim3(blocks), dim3(256), 0, st, bw, con, 1.f / smooth, zin, v, nv, NB, ext, N, total);
+    return hipGetLastError();
+}
 template hipError_t launch_stimulus<float>(const float*, const float*, float, const float*, float*, int, int, int, hipStream_t);
 template hipError_t launch_stimulus<double>(const double*, const double*, double, const double*, double*, int, int, int, hipStream_t);
 

@@ -1336,6 +1336,15 @@ int ssn_stimulus_amp_f32(const float* bw, const float* con, float smoothness, co
     SSN_TRY(ssn::launch_stimulus<float>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));
     return 0;
 }
+int ssn_stimulus_hetero_f32(const float* bw, const float* con, float smoothness, const float* zin, const float* v, int nv, float* ext,
+                            int B, int NB, int N, void* stream) {
+    if (!zin || !v || (nv != 1 && nv != 2 && nv != 2 * N) || B < 0 || NB < 0 || N < 1) {
+        g_last_error = "ssn_stimulus_hetero: invalid argument";
+        return SSN_ERR_BASE + (int)hipErrorInvalidValue;
+    }
+    SSN_TRY(ssn::launch_stimulus_hetero(bw, con, smoothness, zin, v, nv, ext, B, NB, N, (hipStream_t)stream));
+    return 0;
+}
 int ssn_stimulus_amp_f64(const double* bw, const double* con, double smoothness, const double* amp, double* ext, int B,
                          int NB, int N, void* stream) {
     SSN_TRY(ssn::launch_stimulus<double>(bw, con, smoothness, amp, ext, B, NB, N, (hipStream_t)stream));

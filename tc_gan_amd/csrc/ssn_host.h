@@ -268,6 +268,8 @@ hipError_t launch_moment_loss_grad(const float* x, const double* sums, double Bg
 // jds12_dev: J, D, S as device T[12] instead of the host's jds12 (which may then be null)
 template <typename T> hipError_t launch_build_w(const T* z, const T* jds12, T* W, int B, int N, hipStream_t st, const T* jds12_dev = nullptr);
 template <typename T> hipError_t launch_stimulus(const T* bw, const T* con, T smooth, const T* amp, T* ext, int B, int NB, int N, hipStream_t st);
+hipError_t launch_stimulus_hetero(const float* bw, const float* con, float smooth, const float* zin, const float* v, int nv, float* ext,
+                                  int B, int NB, int N, hipStream_t st);
 template <typename T> hipError_t launch_io_eval(const T* v, T* out, long count, const IoConsts<T>& io, hipStream_t st);
 template <typename T> hipError_t launch_philox_uniform(unsigned long long seed, unsigned long long offset, T* out, unsigned long long n, hipStream_t st);
 template <typename T> hipError_t launch_build_w_philox(unsigned long long seed, unsigned long long offset, const T* jds12, T* W, T* zout, int B, int N, hipStream_t st);

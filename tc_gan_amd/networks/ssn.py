@@ -131,6 +131,9 @@ def device_rand(rng, shape, tdtype, rows=None, tail=None):
 
 # (A/B switch: TCGAN_MT_FUSE_W=0 keeps the draw and the W build in two launches)
 _FUSE_W = __import__('os').environ.get('TCGAN_MT_FUSE_W', '1') != '0'
+# (A/B switch: TCGAN_STIM_HETERO=0 forms 1 + v z_in of the heterogeneous-input models with torch operations in front of the
+# stimulus launch, as until round 5, instead of inside it -- same bits)
+_STIM_HETERO = __import__('os').environ.get('TCGAN_STIM_HETERO', '1') != '0'
 # (A/B switch: TCGAN_MT_TAIL=0 draws zs_in of the heterogeneous-input models on the host, after fetching the state behind zs)
 _TAIL = __import__('os').environ.get('TCGAN_MT_TAIL', '1') != '0'
 
@@ -500,16 +503,25 @@ class TuningCurveGenerator(object):
             self._ext_base = (stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
                               if self.heteroin and save else None)
             return ext, z, W
+        zin = vsrc = None
         if self.heteroin:
-            vs = self._input_variability()
             if isinstance(model_zs_in, PhiloxAmp):
                 zin, amp = model_zs_in.materialize()                      # device noise outside the one-call path (fp64)
             else:
                 zin = (model_zs_in.to(self.tdtype) if torch.is_tensor(model_zs_in)      # (drawn on the device: `gen_noise`)
                        else to_device(model_zs_in, self.tdtype))          # (pinned staging: no wait for queued kernels)
-                amp = 1 + vs[None, :] * zin                               # ssn.py:679-684
+                if self.tdtype == torch.float32 and _STIM_HETERO:
+                    # 1 + v z_in inside the stimulus launch (same two roundings): V where the optimizer launch left it (one
+                    # value per population), or the cached per-neuron vector of the host's V
+                    pd = self.__dict__.get('_params_dev')
+                    vsrc = pd['V'].to(self.tdtype).reshape(-1) if pd is not None else self._input_variability()
+                else:
+                    amp = 1 + self._input_variability()[None, :] * zin    # ssn.py:679-684
             self._zin = zin
-        ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)
+        if vsrc is not None:
+            ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, zin=zin, v=vsrc)
+        else:
+            ext = stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype, amp=amp)
         # the un-amplified stimulus is only needed by the V gradient of a BPTT step
         self._ext_base = (stimulus_batch(bw, con, self.smoothness, self.num_sites, dtype=self.dtype)
                           if self.heteroin and save else None)

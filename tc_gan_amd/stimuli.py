@@ -15,10 +15,11 @@ from .clib import libssnode
 from .utils import to_device
 
 
-def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32', amp=None):
+def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32', amp=None, zin=None, v=None):
     """Device form: `bandwidths`, `contrasts` of shape (B, NB) -> CUDA tensor (B, NB, 2*num_sites)
     (networks/ssn.py:177-188).  `amp` (B, 2*num_sites): per-draw input amplification of the
-    heterogeneous-input SSN (ssn.py:679-686)."""
+    heterogeneous-input SSN (ssn.py:679-686) -- or `zin` (B, 2*num_sites) and `v` (1, 2 or 2*num_sites values), float32 device
+    tensors: amp = 1 + v * zin formed in the stimulus launch itself (`ssn_stimulus_hetero_f32`; the bits of the torch expression)."""
     import torch
     clib.require_gpu()
     td = {'float32': torch.float32, 'float64': torch.float64}[str(np.dtype(dtype))]
@@ -27,6 +28,14 @@ def stimulus_batch(bandwidths, contrasts, smoothness, num_sites, dtype='float32'
     assert bw.shape == con.shape and bw.dim() == 2
     B, NB = bw.shape
     ext = torch.empty((B, NB, 2 * num_sites), device='cuda', dtype=td)
+    if zin is not None:
+        assert amp is None and td == torch.float32 and zin.is_cuda and v.is_cuda and zin.dtype == v.dtype == torch.float32
+        zin, v = zin.contiguous(), v.contiguous().reshape(-1)
+        assert zin.shape == (B, 2 * num_sites) and v.numel() in (1, 2, 2 * num_sites)
+        clib.check(libssnode.ssn_stimulus_hetero_f32(bw.data_ptr(), con.data_ptr(), ctypes.c_float(smoothness), zin.data_ptr(),
+                                                     v.data_ptr(), int(v.numel()), ext.data_ptr(), int(B), int(NB), int(num_sites),
+                                                     clib.stream_ptr()), 'ssn_stimulus_hetero_f32')
+        return ext
     fn, ct = ((libssnode.ssn_stimulus_amp_f32, ctypes.c_float) if td == torch.float32
               else (libssnode.ssn_stimulus_amp_f64, ctypes.c_double))
     if amp is not None:

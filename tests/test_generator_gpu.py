@@ -693,3 +693,30 @@ def test_two_draw_kernel_free_running_form_gives_the_same_bits():
         np.testing.assert_array_equal(res['1'][key], res['0'][key], err_msg=key)
     # (the window penalties are per-lane sums; the lock-step form adds the row tile it finishes behind its chain first)
     np.testing.assert_allclose(res['1']['pen'], res['0']['pen'], rtol=1e-5)
+
+
+def test_heterogeneous_input_stimulus_forms_its_amplification_in_the_launch():
+    """`ssn_stimulus_hetero_f32`: the stimulus of the heterogeneous-input models (networks/ssn.py:679-686) with amp = 1 + v z_in
+    formed inside the launch -- the same two fp32 roundings as the torch expression in front of `ssn_stimulus_amp_f32`, so the
+    same bits; v per neuron, per population and as one value; refuses a v of any other length."""
+    import torch
+    from tc_gan_amd import clib
+    from tc_gan_amd.stimuli import stimulus_batch
+    rs = np.random.RandomState(3)
+    B, NB, N = 37, 8, 101
+    bw = torch.as_tensor(rs.rand(B, NB) * 0.9 + 0.05, device='cuda', dtype=torch.float32)
+    con = torch.as_tensor(rs.rand(B, NB) * 30, device='cuda', dtype=torch.float32)
+    for zin in (torch.as_tensor(rs.choice(2, (B, 2 * N)) * 2.0 - 1, device='cuda', dtype=torch.float32),
+                torch.as_tensor(rs.rand(B, 2 * N) * 2 - 1, device='cuda', dtype=torch.float32)):
+        for v in (torch.as_tensor(rs.rand(2 * N) * 0.7, device='cuda', dtype=torch.float32),
+                  torch.as_tensor([0.31, 0.057], device='cuda', dtype=torch.float32),
+                  torch.as_tensor([0.173], device='cuda', dtype=torch.float32)):
+            vs = v if v.numel() == 2 * N else (v.expand(2) if v.numel() == 1 else v).repeat_interleave(N)
+            want = stimulus_batch(bw, con, 0.1, N, amp=1 + vs[None, :] * zin)
+            got = stimulus_batch(bw, con, 0.1, N, zin=zin, v=v)
+            assert torch.equal(got, want)
+    ext = torch.empty((B, NB, 2 * N), device='cuda')
+    v3 = torch.zeros(3, device='cuda')
+    rc = clib.libssnode.ssn_stimulus_hetero_f32(bw.data_ptr(), con.data_ptr(), 0.1, zin.data_ptr(), v3.data_ptr(), 3, ext.data_ptr(),
+                                                B, NB, N, clib.stream_ptr())
+    assert rc != 0
