@@ -667,7 +667,7 @@ def main():
             out['secondary'] = {k: sec[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
                                                     'higher_is_better', 'scaling', 'dtype', 'data', 'config', 'roofline',
                                                     'last_gen_loss')}
-            for key in ('fp32_mfma', 'fused_backward', 'philox_z', 'phases', 'gen_kernel', 'forward_variant', 'z_mode', 'host_draw_ms'):
+            for key in ('fp32_mfma', 'fused_backward', 'philox_z', 'phases', 'gen_kernel', 'forward_variant', 'z_mode', 'host_draw_ms', 'critic'):
                 if key in sec:
                     out['secondary'][key] = sec[key]
         if args.workload == 'c2' and args.extras and world == 1:
