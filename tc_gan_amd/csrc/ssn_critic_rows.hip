@@ -11,18 +11,23 @@
 //   critic_pack_kernel   the weights as bf16 MFMA B-fragments, once per update: for every layer the operand of the forward
 //                        form  op(B)(k, n) = W_l[k][n]  and of the transposed form  op(B)(k, i) = W_l[i][k], tile by tile
 //                        ([n tile][k step][lane][8 values] = one coalesced 1 KB read per MFMA), and w_out as a one-column tile;
-//   critic_rows_kernel   one workgroup (8 waves) per 32 rows.  The A operand (the rows' current activations, bf16) lives in
+//   critic_rows_kernel   one workgroup (16 waves) per 32 rows.  The A operand (the rows' current activations, bf16) lives in
 //                        LDS, two buffers in ping-pong, one barrier per layer; B fragments stream from L2 (3 MB of packed
-//                        weights: every XCD's L2 holds them all) eight k steps ahead; every wave owns the n tiles w, w + 8 of
-//                        the layer's output, finishes them (bias + nonlinearity or mask), writes them to the next A buffer
+//                        weights: every XCD's L2 holds them all) eight k steps ahead, the first eight of a pass requested in
+//                        front of the epilogue of the pass before; every wave owns the n tiles w, w + 16, ... of the layer's
+//                        output (one at 512 wide), finishes them (bias + nonlinearity or mask), writes them to the next A buffer
 //                        and, as fp32, to the global arrays the weight-gradient GEMMs read afterwards (h, v, e: the layout of
 //                        critic_loss_grad's workspace).  The activation masks never leave the lane: the lane that finished
 //                        h_l[m][n] is the one that masks v_l[m][n] and e_l[m][n] (same tile, same accumulator layout).
 //
+// (Not to be confused with critic_rows_kernel<RB> of ssn_critic_fused.hip, the fp32 row-block kernel of the small critics: this
+// one takes RowsArgs and is no template.)  The kernel has three modes: the update (2), D only (0: forward, accuracy), D and the
+// input gradient (1: the generator side).
+//
 // SAME BITS as the layer-by-layer path: same instruction (v_mfma_f32_32x32x16_bf16), same operand rounding (fp32 master
 // values to bf16 by round-to-nearest-even), same k order of every accumulation, same epilogue expressions; the penalty head is
 // the per-row loop of gp_head_kernel (critic_gp_row), and the cross-row sums (mean D(xg), mean D(xd), penalty) are taken by
-// critic_stats_kernel in the orders of two_means_kernel / gp_head_kernel / loss_combine_kernel.
+// critic_stats_block (one workgroup of colsum_batch_kernel) in the orders of two_means_kernel / gp_head_kernel / loss_combine_kernel.
 // tests/test_critic_gpu.py::test_rows_path_matches_layer_path compares loss, statistics and every gradient bit for bit.
 //
 // Reference semantics: networks/cwgan.py:123-214, simple_discriminator.py:139-165 (restated in oracle/gan_torch.py).
@@ -332,12 +337,6 @@ __global__ void __launch_bounds__(64 * RW_WAVES) critic_rows_kernel(RowsArgs a) 
     }
 }
 
-__global__ void __launch_bounds__(256) critic_stats_kernel(const float* __restrict__ d, const float* __restrict__ dnorm,
-                                                           float* __restrict__ stats, int ng, int nd, int np, float lmd) {
-    __shared__ float red[3][256];
-    critic_stats_block(d, dnorm, stats, ng, nd, np, lmd, red);
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
@@ -400,9 +399,4 @@ hipError_t critic_rows_launch(const RowsArgs& ra, hipStream_t st) {
     hipLaunchKernelGGL(critic_rows_kernel, dim3(nb), dim3(64 * RW_WAVES), 0, st, ra);
     return hipGetLastError();
 }
-hipError_t critic_rows_stats(const float* dvals, const float* dnorm, float* stats, int ng, int nd, int np, float lmd, hipStream_t st) {
-    hipLaunchKernelGGL(critic_stats_kernel, dim3(1), dim3(256), 0, st, dvals, dnorm, stats, ng, nd, np, lmd);
-    return hipGetLastError();
-}
-
 }  // namespace ssn

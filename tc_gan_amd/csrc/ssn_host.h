@@ -227,7 +227,6 @@ bool critic_rows_supported(const int* dims, int nlayers);
 size_t critic_rows_workspace_floats(const int* dims, int nlayers, int batch_p);
 hipError_t critic_rows_pack(const float* params, const int* dims, int L, float* ws_pack, RowsArgs& ra, float* zero, long nzero, hipStream_t st);
 hipError_t critic_rows_launch(const RowsArgs& ra, hipStream_t st);
-hipError_t critic_rows_stats(const float* dvals, const float* dnorm, float* stats, int ng, int nd, int np, float lmd, hipStream_t st);
 
 // ssn_critic_fused.hip: critics whose layer widths are all <= 128 (3 launches per update; fp32 arithmetic)
 bool critic_fused_supported(const int* dims, int nlayers);
