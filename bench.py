@@ -437,7 +437,7 @@ def _critic_update_roofline(gan, rows):
     return {'loss_grad_us': us, 'algorithmic_gflop': 2.0 * macs * 1e-9, 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
             'bound': 'mfma', 'mfma_dtype': 'bf16 (fp32 master values rounded to nearest even, fp32 accumulate)',
             'rows': 3 * rows, 'layers': layers,
-            'path': 'row-block kernel + batched weight gradients (ssn_critic_rows.hip, 9 launches)'
+            'path': 'row-block kernel + batched weight gradients (ssn_critic_rows.hip, 8 launches)'
                     if os.environ.get('SSN_CRITIC_ROWS', '1') != '0' and c.precision == 0 else 'layer-by-layer GEMM chain',
             'note': 'device time of one loss + gradient (no optimizer step), back-to-back calls; the update is bound by the '
                     "CUs' 64 B/clock path from L2 (every 32-row block reads all packed weights per layer) and by launch count, not by the matrix pipe"}
